@@ -1,0 +1,5 @@
+"""oracle/ -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package.  The product (cartoonsegmentation_amd) never does.
+"""
