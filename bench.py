@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the MI355X hot path (BASELINE.json metric) on N GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one 1024x1024 frame per rank (weak scaling: every
+rank owns its own frames; outputs are gathered to rank 0 over RCCL inside the
+timed region).  Inputs are synthetic, seeded and already resident in HBM when timing starts.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed on the launch stream) and `cpu_baseline` (the oracle timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # same guide: fp32-input MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--workload", default="auto", help="auto | warp | frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters, warm=3):
+    """average duration of fn() measured with HIP events on torch's current stream (= launch stream)"""
+    for _ in range(warm):
+        fn()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    en.synchronize()
+    return st.elapsed_time(en) / iters
+
+
+class Workload:
+    frames_per_step = 1
+    dtype = "f32"
+
+    def attach(self, world, dist, device):
+        self.world, self.dist = world, dist
+        self.gather_list = None
+        if dist is not None and dist.get_rank() == 0:
+            self.gather_list = [torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
+
+    def step_and_gather(self):
+        """one frame on this rank, then the per-rank gather of the uint8 output to rank 0"""
+        frame = self.step()
+        if self.dist is not None:
+            self.dist.gather(frame, self.gather_list, dst=0)
+        return frame
+
+    def extra(self):
+        return {}
+
+
+class WarpWorkload(Workload):
+    """process_shift -> render_pointcloud(C=4) -> fill_disocclusion -> uint8 (kenburns_effect.py:1027-1040)"""
+    name = "kenburns-warp-frame"
+
+    def __init__(self, size, rank, device):
+        from cartoonsegmentation_amd import ops, synth
+        self.ops, self.H, self.W = ops, size, size
+        sc = synth.warp_scene(size, size, 1234 + rank)
+        self.scene = sc
+        disp = torch.from_numpy(sc['disp']).to(device)
+        disp = disp / disp.max() * sc['baseline']                       # kenburns_effect.py:928
+        self.depth, self.valid, pts, _ = ops.disparity_to_points(disp, sc['focal'], sc['baseline'])
+        self.pts = pts.view(1, 3, -1).contiguous()
+        self.rgb = torch.from_numpy(sc['rgb']).to(device)
+        self.dep = self.depth.view(1, 1, -1).contiguous()
+        dmin = float(self.depth.min().item())
+        loc = int(self.depth.argmin().item())
+        settings, common = synth.shift_request(sc, dmin, (loc % size, loc // size))
+        self.shift = ops.shift_vector(settings, common)
+        self.wf = ops.WarpFrame(size, size, device)
+        self.P = size * size
+        self.N = self.pts.shape[2]
+
+    def step(self):
+        frame, _ = self.wf(self.pts, self.rgb, self.dep, self.scene['focal'], self.scene['baseline'], self.shift)
+        return frame
+
+    def config(self, world):
+        return {"workload": "warp-only: process_shift+render_pointcloud(C=4,N=P)+fill_disocclusion+uint8, %dx%d"
+                            % (self.W, self.H), "frames_per_gpu_step": 1, "parallelism": "frames sharded x%d" % world,
+                "note": "PARTIAL frame: seg+depth stages not included in this workload"}
+
+    # B_warp = 155*P bytes per frame for N=P, C=4; per-kernel shares in DESIGN.md
+    def algorithmic_bytes(self):
+        return 155.0 * self.P
+
+    def extra(self):
+        ms = event_time_ms(self.step, 50)
+        ach = self.algorithmic_bytes() / (ms * 1e-3) / 1e9
+        return {"warp_chain": {"algorithmic_bytes_per_frame": self.algorithmic_bytes(), "us_per_frame": round(ms * 1e3, 2),
+                               "achieved_GBps": round(ach, 1), "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4)}}
+
+    def roofline(self):
+        """dominant kernel = k_update_output (scatter of 4 corners x 5 channels): 68*P algorithmic bytes"""
+        ops, sc = self.ops, self.scene
+        ps = ops.shift_points(self.pts, self.shift)
+        data = torch.cat([self.rgb, self.dep], 1).contiguous()
+        zee = ops.pointrender_degrid(ops.pointrender_update_zee(ps, self.W, self.H, sc['focal'], sc['baseline']))
+        acc = torch.zeros(1, 5, self.H, self.W, device=ps.device)
+        from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, i64, f64, check
+
+        def launch():
+            check(load().csm_pointrender_update_output(ptr(ps), ptr(data), ptr(zee), i32(1), i32(4), i64(self.N),
+                                                       i32(self.H), i32(self.W), f64(sc['focal']), f64(sc['baseline']),
+                                                       ptr(acc), stream_ptr()))
+        ms = event_time_ms(launch, 50)
+        alg = (12 + 16) * self.N + 8.0 * 5 * self.P
+        ach = alg / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "k_update_output<C=4>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": load_traffic("k_update_output"),
+                "algorithmic_bytes_per_launch": alg, "launch_us": round(ms * 1e3, 2)}
+
+    def cpu_baseline(self, seconds):
+        from oracle import warp as orc
+        pts, rgb, dep = self.pts.cpu().numpy(), self.rgb.cpu().numpy(), self.dep.cpu().numpy()
+        rgbd = np.concatenate([rgb, dep], 1)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            orc.warp_frame(pts, rgbd, self.H, self.W, self.scene['focal'], self.scene['baseline'],
+                           np.asarray(self.shift, np.float32), degrid_mode=1)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 64:
+                break
+        return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d warp frames %dx%d, oracle/warp_oracle.c single thread" % (n, self.W, self.H)}
+
+
+def make_workload(kind, size, rank, device, world, dist):
+    if kind in ("auto", "warp"):
+        wl = WarpWorkload(size, rank, device)
+    else:
+        raise SystemExit("unknown workload %r" % kind)
+    wl.attach(world, dist, device)
+    return wl
+
+
+def load_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc pass (profiles/traffic.json), or None"""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(kernel_key)
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    wl = make_workload(a.workload, a.size, rank, device, world, dist)
+
+    for _ in range(a.warmup):
+        wl.step_and_gather()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        wl.step_and_gather()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        frames = a.steps * world * wl.frames_per_step
+        out = {"metric": "frames/sec at 1024x1024 (seg+depth+warp)", "value": round(frames / dt, 3),
+               "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+               "config": wl.config(world)}
+        out["roofline"] = wl.roofline()
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline(a.cpu_seconds)
+        out.update(wl.extra())
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+"""Torch-facing operators with the reference's signatures, backed by libcsm355.so.
+
+Each function mirrors the reference operator cited in its docstring (paths relative to
+/root/reference): same argument meaning, same returned tensors, Python exceptions on error.
+Tensors must live on the MI355X; a CPU tensor raises (the reference hard-codes CUDA as well,
+SURVEY F5).
+"""
+import torch
+
+from . import _lib
+from ._lib import check, f32, f64, i32, i64, ptr, stream_ptr
+
+
+def _dev(t, name):
+    if not t.is_cuda:
+        raise _lib.CsmError("%s must be a device tensor (got %s); libcsm355 has no CPU path" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise _lib.CsmError("%s must be float32" % name)
+    return t.contiguous()
+
+
+def pointrender_update_zee(tenInput, intWidth, intHeight, fltFocal, fltBaseline, tenZee=None):
+    """kernel_pointrender_updateZee -- anime_3dkenburns/models/utils.py:63-149"""
+    tenInput = _dev(tenInput, "tenInput")
+    B, _, N = tenInput.shape
+    if tenZee is None:
+        tenZee = tenInput.new_full([B, 1, intHeight, intWidth], 1000000.0)
+    check(_lib.load().csm_pointrender_update_zee(ptr(tenInput), i32(B), i64(N), i32(intHeight), i32(intWidth),
+                                                 f64(fltFocal), f64(fltBaseline), ptr(tenZee), stream_ptr()), "update_zee")
+    return tenZee
+
+
+def pointrender_degrid(tenZee):
+    """kernel_pointrender_updateDegrid (Jacobi form) -- models/utils.py:152-212"""
+    tenZee = _dev(tenZee, "tenZee")
+    B, _, H, W = tenZee.shape
+    out = torch.empty_like(tenZee)
+    check(_lib.load().csm_pointrender_degrid(ptr(tenZee), ptr(out), i32(B), i32(H), i32(W), stream_ptr()), "degrid")
+    return out
+
+
+def pointrender_update_output(tenInput, tenData, tenZee, fltFocal, fltBaseline):
+    """kernel_pointrender_updateOutput -- models/utils.py:215-313; returns accum [B,C+1,H,W]"""
+    tenInput, tenData, tenZee = _dev(tenInput, "tenInput"), _dev(tenData, "tenData"), _dev(tenZee, "tenZee")
+    B, C, N = tenData.shape
+    _, _, H, W = tenZee.shape
+    acc = tenInput.new_zeros([B, C + 1, H, W])
+    check(_lib.load().csm_pointrender_update_output(ptr(tenInput), ptr(tenData), ptr(tenZee), i32(B), i32(C), i64(N),
+                                                    i32(H), i32(W), f64(fltFocal), f64(fltBaseline), ptr(acc),
+                                                    stream_ptr()), "update_output")
+    return acc
+
+
+def render_pointcloud(tenInput, tenData, intWidth, intHeight, fltFocal, fltBaseline):
+    """render_pointcloud -- anime_3dkenburns/models/utils.py:56-315
+    tenInput [B,3,N], tenData [B,C,N] -> (tenRender [B,C,H,W], tenExisting [B,1,H,W])"""
+    tenInput, tenData = _dev(tenInput, "tenInput"), _dev(tenData, "tenData")
+    B, C, N = tenData.shape
+    if tenInput.shape[0] != B or tenInput.shape[1] != 3 or tenInput.shape[2] != N:
+        raise _lib.CsmError("render_pointcloud: tenInput must be [B,3,N] matching tenData [B,C,N]")
+    zee = tenInput.new_empty([2, B, intHeight, intWidth])
+    acc = tenInput.new_empty([B, C + 1, intHeight, intWidth])
+    render = tenInput.new_empty([B, C, intHeight, intWidth])
+    existing = tenInput.new_empty([B, 1, intHeight, intWidth])
+    check(_lib.load().csm_render_pointcloud(ptr(tenInput), ptr(tenData), i32(B), i32(C), i64(N), i32(intWidth),
+                                            i32(intHeight), f64(fltFocal), f64(fltBaseline), ptr(zee), ptr(acc),
+                                            ptr(render), ptr(existing), stream_ptr()), "render_pointcloud")
+    return render, existing
+
+
+def fill_disocclusion(tenInput, tenDepth):
+    """fill_disocclusion -- anime_3dkenburns/common.py:145-248"""
+    tenInput, tenDepth = _dev(tenInput, "tenInput"), _dev(tenDepth, "tenDepth")
+    B, C, H, W = tenInput.shape
+    out = torch.empty_like(tenInput)
+    check(_lib.load().csm_fill_disocclusion(ptr(tenInput), ptr(tenDepth), ptr(out), i32(B), i32(C), i32(H), i32(W),
+                                            stream_ptr()), "fill_disocclusion")
+    return out
+
+
+def spatial_filter(tenInput, strType):
+    """spatial_filter -- anime_3dkenburns/models/utils.py:9-40 ('laplacian' is the hot-path mode)"""
+    if strType != 'laplacian':
+        raise NotImplementedError("spatial_filter(%r): only 'laplacian' is on the hot path" % strType)
+    tenInput = _dev(tenInput, "tenInput")
+    B, C, H, W = tenInput.shape
+    out = torch.empty_like(tenInput)
+    check(_lib.load().csm_spatial_filter_laplacian(ptr(tenInput), ptr(out), i32(B * C), i32(H), i32(W), stream_ptr()),
+          "spatial_filter")
+    return out
+
+
+def depth_to_points(tenDepth, fltFocal):
+    """depth_to_points -- anime_3dkenburns/models/utils.py:43-50"""
+    tenDepth = _dev(tenDepth, "tenDepth")
+    B, _, H, W = tenDepth.shape
+    pts = tenDepth.new_empty([B, 3, H, W])
+    check(_lib.load().csm_depth_to_points(ptr(tenDepth), ptr(pts), i32(B), i32(H), i32(W), f64(fltFocal), stream_ptr()),
+          "depth_to_points")
+    return pts
+
+
+def disparity_to_points(tenDisparity, fltFocal, fltBaseline):
+    """kenburns_effect.py:929-933 fused: normalised disparity -> depth, valid, points, unaltered"""
+    d = _dev(tenDisparity, "tenDisparity")
+    H, W = d.shape[-2:]
+    depth, valid = torch.empty_like(d), torch.empty_like(d)
+    pts, un = d.new_empty([1, 3, H, W]), d.new_empty([1, 3, H, W])
+    check(_lib.load().csm_disparity_to_points(ptr(d), f32(float(d.max().item())), i32(H), i32(W), f64(fltFocal),
+                                              f64(fltBaseline), ptr(depth), ptr(valid), ptr(pts), ptr(un), stream_ptr()),
+          "disparity_to_points")
+    return depth, valid, pts, un
+
+
+def shift_vector(objSettings, objCommon):
+    """scalar part of process_shift -- anime_3dkenburns/common.py:60-72 (python floats, like the reference)"""
+    cd = objCommon['objDepthrange'][0] + (objSettings['fltDepthTo'] - objSettings['fltDepthFrom'])
+    fu, fv = objCommon['objDepthrange'][2][0], objCommon['objDepthrange'][2][1]
+    tu, tv = fu + objSettings['fltShiftU'], fv + objSettings['fltShiftV']
+    w2, h2, f = objCommon['intWidth'] / 2.0, objCommon['intHeight'] / 2.0, objCommon['fltFocal']
+    fx, fy = ((fu - w2) * cd) / f, ((fv - h2) * cd) / f
+    tx, ty = ((tu - w2) * cd) / f, ((tv - h2) * cd) / f
+    return [fx - tx, fy - ty, objSettings['fltDepthTo'] - objSettings['fltDepthFrom']]
+
+
+def _f32x3(shift):
+    s = torch.tensor([float(v) for v in shift], dtype=torch.float32)  # FloatTensor rounding, common.py:74
+    return f32(s[0].item()), f32(s[1].item()), f32(s[2].item())
+
+
+def shift_points(tenPoints, shift):
+    """tensor part of process_shift -- common.py:74-81; shift = 3 python floats"""
+    tenPoints = _dev(tenPoints, "tenPoints")
+    B, _, N = tenPoints.shape
+    sx, sy, sz = _f32x3(shift)
+    out = torch.empty_like(tenPoints)
+    check(_lib.load().csm_process_shift(ptr(tenPoints), ptr(out), i32(B), i64(N), sx, sy, sz, stream_ptr()), "process_shift")
+    return out
+
+
+def process_shift(objSettings, objCommon):
+    """process_shift -- anime_3dkenburns/common.py:59-84 -> (tenPoints, tenShift)"""
+    shift = shift_vector(objSettings, objCommon)
+    pts = objSettings['tenPoints']
+    tenShift = torch.tensor(shift, dtype=torch.float32).view(1, 3, 1).to(pts.device)
+    return shift_points(pts, shift), tenShift
+
+
+class WarpFrame:
+    """Fused per-frame warp of KenBurnsPipeline.process_kenburns (kenburns_effect.py:1027-1040):
+    process_shift -> render_pointcloud(cat[rgb,depth]) -> fill_disocclusion -> uint8 HWC.
+    Owns the scratch so the frame loop allocates nothing."""
+
+    def __init__(self, H, W, device, keep_render=False):
+        self.H, self.W = H, W
+        n = _lib.load().csm_warp_frame_scratch_floats(i32(H), i32(W))
+        self.scratch = torch.empty(n, dtype=torch.float32, device=device)
+        self.frame = torch.empty((H, W, 3), dtype=torch.uint8, device=device)
+        self.render = torch.empty((1, 4, H, W), dtype=torch.float32, device=device) if keep_render else None
+
+    def __call__(self, tenPoints, tenImage, tenDepth, fltFocal, fltBaseline, shift, stream=None):
+        N = tenPoints.shape[2]
+        sx, sy, sz = _f32x3(shift)
+        st = stream_ptr() if stream is None else stream
+        check(_lib.load().csm_warp_frame(ptr(tenPoints), ptr(tenImage), ptr(tenDepth), i64(N), i32(self.H), i32(self.W),
+                                         f64(fltFocal), f64(fltBaseline), sx, sy, sz, ptr(self.scratch),
+                                         ptr(self.render), ptr(self.frame), st), "warp_frame")
+        return self.frame, self.render

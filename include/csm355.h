@@ -1,0 +1,97 @@
+/*
+ * csm355.h -- C ABI of libcsm355.so: the MI355X (gfx950) hot path of CartoonSegmentation.
+ *
+ * Drop-in boundary: the reference has no plugin ABI for this path; its
+ * operator boundary is utils/cupy_utils.py::launch_kernel(name, src)(grid, block,
+ * args=[int32 n, raw device pointers...]) (utils/cupy_utils.py:7-13) -- caller-owned,
+ * pre-allocated torch buffers, raw pointers, nothing returned.  This header keeps that
+ * convention: plain pointers + sizes, caller-allocated outputs, an explicit HIP stream,
+ * int status (0 = ok; message via csm_last_error()).  No torch types.
+ *
+ * All tensors are contiguous fp32 unless stated; layouts are the reference's
+ * (NCHW / [B,C,N]).  Every function is asynchronous on `stream` (a hipStream_t cast
+ * to void*; NULL = the null stream) and re-entrant per stream.
+ *
+ * Reference citations are relative to /root/reference.
+ */
+#ifndef CSM355_H
+#define CSM355_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSM_OK 0
+#define CSM_ERR_ARG 1
+#define CSM_ERR_HIP 2
+#define CSM_ERR_NAN 3
+
+/* thread-local message of the last non-zero status */
+const char *csm_last_error(void);
+/* library/ABI version (major*1000 + minor) and build info string */
+int csm_version(void);
+const char *csm_build_info(void);
+
+/* ------------------------------------------------------------------------------------
+ * Ken Burns warp operators
+ * ---------------------------------------------------------------------------------- */
+
+/* kernel_pointrender_updateZee   anime_3dkenburns/models/utils.py:63-149
+ * pts [B,3,N]; zee [B,1,H,W] must hold 1e6 on entry (models/utils.py:59). */
+int csm_pointrender_update_zee(const float *pts, int B, int64_t N, int H, int W, double focal,
+                               double baseline, float *zee, void *stream);
+
+/* kernel_pointrender_updateDegrid   models/utils.py:152-212
+ * Deterministic (Jacobi) form: reads zee_in, writes zee_out (must not alias). */
+int csm_pointrender_degrid(const float *zee_in, float *zee_out, int B, int H, int W, void *stream);
+
+/* kernel_pointrender_updateOutput   models/utils.py:215-313
+ * data [B,C,N] WITHOUT the ones channel; accum [B,C+1,H,W] must be zero on entry;
+ * channel C of accum receives the bilinear weight itself (the reference's appended
+ * ones channel, models/utils.py:57). */
+int csm_pointrender_update_output(const float *pts, const float *data, const float *zee, int B, int C,
+                                  int64_t N, int H, int W, double focal, double baseline, float *accum,
+                                  void *stream);
+
+/* render_pointcloud   models/utils.py:56-315  (fill + 3 kernels + divide)
+ * scratch: zee_scratch 2*B*H*W floats, accum_scratch B*(C+1)*H*W floats.
+ * outputs: render [B,C,H,W], existing [B,1,H,W]. */
+int csm_render_pointcloud(const float *pts, const float *data, int B, int C, int64_t N, int W, int H,
+                          double focal, double baseline, float *zee_scratch, float *accum_scratch,
+                          float *render, float *existing, void *stream);
+
+/* fill_disocclusion   anime_3dkenburns/common.py:145-248
+ * in [B,C,H,W], depth [B,1,H,W] -> out [B,C,H,W] (out is fully written; no pre-clone needed) */
+int csm_fill_disocclusion(const float *in, const float *depth, float *out, int B, int C, int H, int W,
+                          void *stream);
+
+/* spatial_filter(x,'laplacian')   models/utils.py:12-24 ; x,out [BC,H,W] */
+int csm_spatial_filter_laplacian(const float *in, float *out, int BC, int H, int W, void *stream);
+
+/* depth_to_points   models/utils.py:43-50 ; depth [B,1,H,W] -> pts [B,3,H,W] */
+int csm_depth_to_points(const float *depth, float *pts, int B, int H, int W, double focal, void *stream);
+
+/* kenburns_effect.py:928-933 fused: normalised disparity [1,1,H,W] (already /max*baseline) ->
+ * depth, valid, points (depth*valid), unaltered points.  disp_max = max(disparity). */
+int csm_disparity_to_points(const float *disp, float disp_max, int H, int W, double focal, double baseline,
+                            float *depth, float *valid, float *pts, float *unaltered, void *stream);
+
+/* tensor part of process_shift   common.py:74-81 ; shift = float32(sx,sy,sz) */
+int csm_process_shift(const float *pts, float *out, int B, int64_t N, float sx, float sy, float sz,
+                      void *stream);
+
+/* One output frame of KenBurnsPipeline.process_kenburns (kenburns_effect.py:1027-1040), fused:
+ * process_shift -> render_pointcloud(cat[rgb, depth]) -> fill_disocclusion(render,
+ * render[3]*(existing>0)) -> uint8 HWC frame.
+ * pts [1,3,N], rgb [1,3,N], depth [1,1,N]; scratch >= csm_warp_frame_scratch_floats(H,W) floats.
+ * outputs: render_filled [1,4,H,W] (may be NULL), frame_u8 [H,W,3]. */
+size_t csm_warp_frame_scratch_floats(int H, int W);
+int csm_warp_frame(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W,
+                   double focal, double baseline, float sx, float sy, float sz, float *scratch,
+                   float *render_filled, uint8_t *frame_u8, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSM355_H */

@@ -289,7 +289,8 @@ void orc_disparity_to_points(int H, int W, double focal, double baseline, const 
     for (int64_t i = 0; i < P; ++i) if (disp_in[i] > mx) mx = disp_in[i];
     for (int64_t i = 0; i < P; ++i) disp[i] = disp_in[i] / mx * (float)baseline;
     float fb = (float)(focal * baseline);
-    for (int64_t i = 0; i < P; ++i) depth[i] = fb / (disp[i] + 0.00001f);
+    /* python: float / Tensor  ==  Tensor.__rtruediv__  ==  tensor.reciprocal() * float  (two roundings) */
+    for (int64_t i = 0; i < P; ++i) depth[i] = (1.0f / (disp[i] + 0.00001f)) * fb;
     float mx2 = -INFINITY;
     for (int64_t i = 0; i < P; ++i) if (disp[i] > mx2) mx2 = disp[i];
     float *nd = (float *)malloc(P * sizeof(float)), *lap = (float *)malloc(P * sizeof(float));

@@ -1,0 +1,185 @@
+"""GPU parity: libcsm355 warp kernels (through the C ABI / ops.py)  vs  oracle + golden fixtures.
+
+Bit-exact where the algorithm is order independent (z-buffer, degrid, fill, point-wise);
+fp32 atomicAdd accumulation order is not deterministic on any GPU (nor in the reference),
+so accumulators/renders use north_star's 1e-3 relative tolerance.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import warp as orc  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+RENDER_CASES = sorted(glob.glob(os.path.join(GOLDEN, "warp_*.npz")))
+IDS = [os.path.basename(p)[:-4] for p in RENDER_CASES]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from cartoonsegmentation_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close_frac(a, b, rtol=1e-3, atol=1e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) <= atol + rtol * np.abs(b)).mean())
+
+
+@pytest.mark.parametrize("path", RENDER_CASES, ids=IDS)
+def test_stages_vs_golden_and_oracle(ops, path):
+    g = dict(np.load(path))
+    H, W, C = int(g['H']), int(g['W']), int(g['C'])
+    focal, baseline = float(g['focal']), float(g['baseline'])
+    # process_shift: bit exact vs the reference
+    ps = ops.shift_points(dev(g['pts']), [float(v) for v in g['shift']])
+    assert np.array_equal(ps.cpu().numpy(), g['pts_shift'])
+    # z-buffer: bit exact vs the reference (atomic min is order independent)
+    zee = ops.pointrender_update_zee(ps, W, H, focal, baseline)
+    assert np.array_equal(zee.cpu().numpy(), g['zee_after_zee'])
+    # degrid: bit exact vs the oracle's Jacobi form
+    zd = ops.pointrender_degrid(zee)
+    zd_o = orc.degrid(g['zee_after_zee'], 1)
+    assert np.array_equal(zd.cpu().numpy(), zd_o)
+    # accumulate: same z-buffer as the fixture -> compare with the reference accumulators
+    zin = dev(g['zee_after_degrid_inplace'])
+    acc = ops.pointrender_update_output(ps, dev(g['data']), zin, focal, baseline).cpu().numpy()
+    data1 = np.concatenate([g['data'], np.ones_like(g['data'][:, :1])], 1)
+    acc_o = orc.update_output(g['pts_shift'], data1, g['zee_after_degrid_inplace'], focal, baseline)
+    assert np.array_equal(acc != 0, acc_o != 0)          # same coverage decisions
+    assert close_frac(acc, acc_o, 1e-4, 1e-5) == 1.0
+    if 'accum' in g:
+        assert close_frac(acc, g['accum'], 1e-4, 1e-5) == 1.0
+
+
+@pytest.mark.parametrize("path", RENDER_CASES, ids=IDS)
+def test_render_pointcloud(ops, path):
+    g = dict(np.load(path))
+    H, W = int(g['H']), int(g['W'])
+    focal, baseline = float(g['focal']), float(g['baseline'])
+    render, existing = ops.render_pointcloud(dev(g['pts_shift']), dev(g['data']), W, H, focal, baseline)
+    render, existing = render.cpu().numpy(), existing.cpu().numpy()
+    r1, e1 = orc.render_pointcloud(g['pts_shift'], g['data'], W, H, focal, baseline, degrid_mode=1)
+    assert np.array_equal(existing > 0, e1 > 0)
+    assert close_frac(existing, e1, 1e-4, 1e-6) == 1.0
+    assert close_frac(render, r1) >= 0.999
+    # against the reference fixture (in-place racy degrid): wherever the two degrid semantics agree
+    r0, e0 = orc.render_pointcloud(g['pts_shift'], g['data'], W, H, focal, baseline, degrid_mode=0)
+    agree = np.broadcast_to((e0 == e1), r0.shape) & (np.abs(r0 - r1) <= 1e-6 + 1e-5 * np.abs(r1))
+    assert agree.mean() > 0.9
+    ok = np.abs(render - g['render']) <= 1e-5 + 1e-3 * np.abs(g['render'])
+    assert ok[agree].mean() >= 0.999
+
+
+@pytest.mark.parametrize("path", [p for p in RENDER_CASES if 'c4' in p], ids=[i for i in IDS if 'c4' in i])
+def test_fill_disocclusion_bit_exact(ops, path):
+    g = dict(np.load(path))
+    out = ops.fill_disocclusion(dev(g['render']), dev(g['fill_depth'])).cpu().numpy()
+    assert np.array_equal(out, g['filled'])
+
+
+def test_discfill_synthetic_holes(ops):
+    g = dict(np.load(os.path.join(GOLDEN, "discfill_48x40.npz")))
+    out = ops.fill_disocclusion(dev(g['img']), dev(g['depth'])).cpu().numpy()
+    assert np.array_equal(out, g['out'])
+
+
+def test_pointwise(ops):
+    g = dict(np.load(os.path.join(GOLDEN, "pointwise_72x56.npz")))
+    focal, baseline = float(g['focal']), float(g['baseline'])
+    depth, valid, pts, un = [t.cpu().numpy() for t in ops.disparity_to_points(dev(g['disp']), focal, baseline)]
+    d_o, dep_o, val_o, pts_o, un_o = orc.disparity_to_points(g['disp_raw'], focal, baseline)
+    assert np.array_equal(depth, dep_o) and np.array_equal(valid, val_o)
+    assert np.array_equal(pts, pts_o) and np.array_equal(un, un_o)
+    assert np.array_equal(depth, g['depth']) and np.array_equal(un, g['unaltered'])
+    nd = g['disp'] / g['disp'].max()
+    lap = ops.spatial_filter(dev(nd), 'laplacian').cpu().numpy()
+    assert np.array_equal(lap, orc.spatial_filter_laplacian(nd))
+    assert np.abs(lap - g['lap']).max() < 2e-6
+    p2 = ops.depth_to_points(dev(g['depth']), focal).cpu().numpy()
+    assert np.array_equal(p2, g['unaltered'])
+
+
+def _frame_case(ops, H, W, seed, extra=0):
+    from cartoonsegmentation_amd import synth
+    sc = synth.warp_scene(H, W, seed)
+    disp_o, depth_o, valid_o, pts_o, un_o = orc.disparity_to_points(sc['disp'], sc['focal'], sc['baseline'])
+    dmin = float(depth_o.min()); loc = np.unravel_index(int(depth_o.argmin()), (H, W))
+    settings, common = synth.shift_request(sc, dmin, (loc[1], loc[0]))
+    shift = ops.shift_vector(settings, common)
+    assert np.array_equal(np.asarray(shift, np.float32), orc.shift_vector(settings, common))
+    pts = pts_o.reshape(1, 3, -1); rgb = sc['rgb']; dep = depth_o.reshape(1, 1, -1)
+    if extra:
+        g = np.random.default_rng(seed)
+        idx = g.integers(0, H * W, extra)
+        pts = np.concatenate([pts, un_o.reshape(1, 3, -1)[:, :, idx] + g.normal(0, 2, (1, 3, extra)).astype(np.float32)], 2)
+        rgb = np.concatenate([rgb, rgb[:, :, idx]], 2); dep = np.concatenate([dep, dep[:, :, idx]], 2)
+    return sc, pts, rgb, dep, shift
+
+
+@pytest.mark.parametrize("H,W,extra", [(96, 128, 0), (250, 333, 5000), (1024, 1024, 0)])
+def test_warp_frame_fused_vs_oracle(ops, H, W, extra):
+    sc, pts, rgb, dep, shift = _frame_case(ops, H, W, 1234, extra)
+    wf = ops.WarpFrame(H, W, 'cuda', keep_render=True)
+    frame, render = wf(dev(pts), dev(rgb), dev(dep), sc['focal'], sc['baseline'], shift)
+    frame, render = frame.cpu().numpy(), render.cpu().numpy()
+    filled_o, existing_o, frame_o = orc.warp_frame(pts, np.concatenate([rgb, dep], 1), H, W, sc['focal'], sc['baseline'],
+                                                   np.asarray(shift, np.float32), degrid_mode=1)
+    assert (existing_o == 0).mean() > 0.001, "scene must contain disocclusions"
+    assert close_frac(render, filled_o) >= 0.999
+    diff = np.abs(frame.astype(np.int32) - frame_o.astype(np.int32))
+    assert (diff <= 1).mean() >= 0.999 and (diff == 0).mean() >= 0.99
+    # unfused operators give the same frame as the fused path
+    ps = ops.shift_points(dev(pts), shift)
+    r, e = ops.render_pointcloud(ps, dev(np.concatenate([rgb, dep], 1)), W, H, sc['focal'], sc['baseline'])
+    f2 = ops.fill_disocclusion(r, r[:, 3:4] * (e > 0.0).float())
+    assert close_frac(f2.cpu().numpy(), render, 1e-3, 1e-5) >= 0.9995
+
+
+def test_properties_full_size(ops):
+    """size independent properties at BASELINE's 1024x1024: identity warp, linearity in the data,
+    z-buffer determinism."""
+    H = W = 1024
+    sc, pts, rgb, dep, _ = _frame_case(ops, H, W, 4321)
+    dpts, drgb = dev(pts), dev(rgb)
+    f, b = sc['focal'], sc['baseline']
+    r0, e0 = ops.render_pointcloud(dpts, drgb, W, H, f, b)       # no shift: every valid point lands on its own pixel
+    valid = (dpts[:, 2:3] > 0).view(1, 1, H, W)
+    img = drgb.view(1, 3, H, W)
+    m = valid.expand_as(img) & (e0 > 0.999).expand_as(img)
+    assert m.float().mean() > 0.5
+    assert torch.allclose(r0[m], img[m], rtol=1e-3, atol=2e-3)
+    ps = ops.shift_points(dpts, [11.0, -7.0, -3.0])
+    z1 = ops.pointrender_update_zee(ps, W, H, f, b); z2 = ops.pointrender_update_zee(ps, W, H, f, b)
+    assert torch.equal(z1, z2)
+    d2 = torch.rand_like(drgb)
+    ra, ea = ops.render_pointcloud(ps, drgb, W, H, f, b)
+    rb, eb = ops.render_pointcloud(ps, d2, W, H, f, b)
+    rc, ec = ops.render_pointcloud(ps, 0.25 * drgb + 0.5 * d2, W, H, f, b)
+    assert torch.equal(ea > 0, ec > 0)
+    assert torch.allclose(rc, 0.25 * ra + 0.5 * rb, rtol=1e-3, atol=1e-4)
+
+
+def test_edge_cases(ops):
+    H, W = 20, 30
+    empty = torch.zeros(1, 3, 0, device='cuda'); edata = torch.zeros(1, 4, 0, device='cuda')
+    r, e = ops.render_pointcloud(empty, edata, W, H, 15.0, 40.0)
+    assert float(r.abs().max()) == 0.0 and float(e.abs().max()) == 0.0
+    out = ops.fill_disocclusion(r, r[:, 3:4])        # all-hole image: nothing to march to -> unchanged
+    assert torch.equal(out, r)
+    # points behind the camera / outside the image are skipped (models/utils.py:82, bounds checks)
+    pts = torch.tensor([[[0.0, 1e4, -1e4, 0.0], [0.0, 0.0, 0.0, 0.0], [-5.0, 10.0, 10.0, 0.0005]]], device='cuda')
+    r, e = ops.render_pointcloud(pts, torch.ones(1, 2, 4, device='cuda'), W, H, 15.0, 40.0)
+    assert float(e.sum()) == 0.0
+    with pytest.raises(Exception):
+        ops.render_pointcloud(torch.zeros(1, 3, 4), torch.zeros(1, 2, 4), W, H, 15.0, 40.0)   # CPU tensors: no fallback
