@@ -1,0 +1,459 @@
+// nets.hip -- layer-program executor for the dense nets of the hot path (ISNet refine, LeReS depth,
+// RTMDet-Ins) on gfx950.  C ABI: csm_run_program (include/csm355.h).
+//
+// Design (CDNA4-first, not a cuDNN call sequence):
+//   * activations NHWC fp32; a tensor view = (base, channels, channel pitch) so torch.cat is free;
+//   * every dense / grouped convolution is ONE implicit-GEMM kernel on the exact-fp32 matrix pipe
+//     (v_mfma_f32_32x32x2_f32, 157 TF/s peak): M = output pixels, N = output channels,
+//     K = taps x input channels.  256-thread blocks = 4 waves in a WM x WN grid, each wave owns
+//     32 x (32*TN) outputs.  K is consumed in chunks of 32 channels of one tap: the A tile
+//     (BM pixels x 128 B, fully coalesced because NHWC keeps a pixel's channels contiguous) and the
+//     pre-packed weight tile (BN x 128 B) are register-staged into LDS (row pitch 36 floats =>
+//     conflict-free ds_read_b128) and double buffered, one barrier per chunk.
+//   * folded-BN bias initialises the accumulator; activation / residual are fused in the epilogue.
+//   * grouped 3x3 (ResNeXt, 32 groups) runs on the same kernel as block-diagonal 32-channel
+//     super-groups (zero-padded weights): fmaf(x, 0, acc) is exact, so numerics are unchanged.
+//   * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous range of M tiles so
+//     that the 3x3 halo re-reads of neighbouring tiles hit the same 4 MiB L2.
+// Numerical contract: see include/csm355.h (one fmaf chain per output, fixed K order).
+#include "csm_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- shared scalar math (restated independently in oracle/nets_oracle.c) -----------------------
+__device__ __forceinline__ float csm_expf(float x) {
+    x = fminf(fmaxf(x, -87.0f), 88.0f);
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float e = fmaf(p, r * r, r) + 1.0f;
+    return e * __int_as_float(((int)n + 127) << 23);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case CSM_ACT_RELU: return fmaxf(v, 0.0f);
+        case CSM_ACT_SILU: return v / (1.0f + csm_expf(-v));
+        case CSM_ACT_PRELU: return v >= 0.0f ? v : v * slope;
+        case CSM_ACT_HSIGMOID: return fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
+        case CSM_ACT_SIGMOID: return 1.0f / (1.0f + csm_expf(-v));
+        default: return v;
+    }
+}
+
+struct View {           // NHWC view
+    float *p;
+    int n, h, w, c, ld;
+};
+
+struct ConvArgs {
+    View in, out, res;
+    const float *w, *bias, *slope;
+    int kh, kw, stride, pad, dil;
+    int groups, cin_g, cout_g, npad;   // npad = cout_g rounded up to 32 (packed weight rows)
+    int act, res_mode;
+    int M;                             // n*ho*wo
+    int ncb;                           // ceil(cin_g / 32)
+    int m_tiles;
+};
+
+constexpr int kLdsLd = 36;  // floats per LDS row: 32 + 4 pad (conflict-free b128 reads, see MI355X LDS notes)
+
+// Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
+template <int WM, int WN, int TN>
+__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
+    constexpr int BM = 32 * WM, BN = 32 * WN * TN;
+    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int kStage = (BM + BN) * kLdsLd;   // floats per pipeline stage: A rows then B rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // XCD-aware M-tile remap (speed only): block b runs on XCD b%8; give each XCD a contiguous tile range.
+    int mt;
+    {
+        const int nt = a.m_tiles, b = blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = b & 7, loc = b >> 3;
+        mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int m0 = mt * BM, n0 = blockIdx.y * BN, g = blockIdx.z;
+    const int ho = a.out.h, wo = a.out.w;
+    const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
+
+    // per-thread A rows (output pixels) -> input origin
+    int rn[A_IT], riy[A_IT], rix[A_IT]; bool rvalid[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        int row = (tid + 256 * it) >> 3;
+        int m = m0 + row;
+        rvalid[it] = m < a.M;
+        int mm = rvalid[it] ? m : 0;
+        int n = mm / (ho * wo), rem = mm - n * ho * wo;
+        int oy = rem / wo, ox = rem - oy * wo;
+        rn[it] = n; riy[it] = oy * a.stride - a.pad; rix[it] = ox * a.stride - a.pad;
+    }
+    const int c4 = (tid & 7) * 4;
+    const int T = a.kh * a.kw * a.ncb;
+    const float *wbase = a.w + (int64_t)g * T * a.npad * 32;
+
+    float4 ra[A_IT], rb[B_IT];
+    auto gload = [&](int chunk) {
+        int tap = chunk / a.ncb, cb = chunk - tap * a.ncb;
+        int kh = tap / a.kw, kw = tap - kh * a.kw;
+        int c = cb * 32 + c4;
+        bool cv = c < a.cin_g;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int iy = riy[it] + kh * a.dil, ix = rix[it] + kw * a.dil;
+            bool v = rvalid[it] && cv && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+            const float *p = a.in.p + ((int64_t)(rn[it] * a.in.h + iy) * a.in.w + ix) * a.in.ld + cin_off + c;
+            ra[it] = v ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int row = (tid + 256 * it) >> 3;
+            bool v = n0 + row < a.npad;
+            const float *p = wbase + ((int64_t)chunk * a.npad + n0 + row) * 32 + c4;
+            rb[it] = v ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int row = (tid + 256 * it) >> 3;
+            *reinterpret_cast<float4 *>(lds + buf * kStage + row * kLdsLd + c4) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int row = (tid + 256 * it) >> 3;
+            *reinterpret_cast<float4 *>(lds + buf * kStage + (BM + row) * kLdsLd + c4) = rb[it];
+        }
+    };
+
+    // accumulators start at the (folded-BN) bias
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        int n = n0 + 32 * (TN * wn + tn) + li;
+        float b = (a.bias && n < a.cout_g) ? a.bias[cout_off + n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tn][r] = b;
+    }
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < T; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < T) gload(chunk + 1);
+        int cb = chunk % a.ncb;
+        int rem = a.cin_g - cb * 32;
+        int nkb = rem >= 32 ? 4 : (rem + 7) >> 3;
+        const float *A = lds + buf * kStage + (32 * wm + li) * kLdsLd + 4 * lh;
+        const float *B = lds + buf * kStage + (BM + 32 * TN * wn + li) * kLdsLd + 4 * lh;
+        for (int kb = 0; kb < nkb; ++kb) {
+            float4 af = *reinterpret_cast<const float4 *>(A + kb * 8);
+            float4 bf[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<const float4 *>(B + tn * 32 * kLdsLd + kb * 8);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[tn].x, acc[tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[tn].y, acc[tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[tn].z, acc[tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[tn].w, acc[tn], 0, 0, 0);
+        }
+        if (chunk + 1 < T) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column li (channel), rows (r&3)+8*(r>>2)+4*lh of the 32x32 tile
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        int n = n0 + 32 * (TN * wn + tn) + li;
+        if (n >= a.cout_g) continue;
+        float slope = a.slope ? a.slope[cout_off + n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int m = m0 + 32 * wm + row;
+            if (m >= a.M) continue;
+            float v = acc[tn][r];
+            if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
+            v = apply_act(v, a.act, slope);
+            if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
+            a.out.p[(int64_t)m * a.out.ld + cout_off + n] = v;
+        }
+    }
+}
+
+// depthwise conv (RTMDet CSPNeXt 5x5): lane = (pixel, 4 channels); weights [tap][C]; fmaf chain over taps
+struct DwArgs { View in, out; const float *w, *bias, *slope; int kh, kw, stride, pad, dil, act; };
+__global__ __launch_bounds__(256) void k_dwconv(DwArgs a) {
+    const int c4n = a.out.c >> 2;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)a.out.n * a.out.h * a.out.w * c4n;
+    if (idx >= total) return;
+    int c = (int)(idx % c4n) * 4; int64_t pix = idx / c4n;
+    int ox = (int)(pix % a.out.w); int64_t t = pix / a.out.w; int oy = (int)(t % a.out.h); int n = (int)(t / a.out.h);
+    float4 acc = a.bias ? *reinterpret_cast<const float4 *>(a.bias + c) : make_float4(0, 0, 0, 0);
+    for (int kh = 0; kh < a.kh; ++kh) {
+        int iy = oy * a.stride - a.pad + kh * a.dil;
+        if (iy < 0 || iy >= a.in.h) continue;
+        for (int kw = 0; kw < a.kw; ++kw) {
+            int ix = ox * a.stride - a.pad + kw * a.dil;
+            if (ix < 0 || ix >= a.in.w) continue;
+            float4 x = *reinterpret_cast<const float4 *>(a.in.p + ((int64_t)(n * a.in.h + iy) * a.in.w + ix) * a.in.ld + c);
+            float4 w = *reinterpret_cast<const float4 *>(a.w + (int64_t)(kh * a.kw + kw) * a.out.c + c);
+            acc.x = fmaf(x.x, w.x, acc.x); acc.y = fmaf(x.y, w.y, acc.y);
+            acc.z = fmaf(x.z, w.z, acc.z); acc.w = fmaf(x.w, w.w, acc.w);
+        }
+    }
+    float4 s = a.slope ? *reinterpret_cast<const float4 *>(a.slope + c) : make_float4(0, 0, 0, 0);
+    acc.x = apply_act(acc.x, a.act, s.x); acc.y = apply_act(acc.y, a.act, s.y);
+    acc.z = apply_act(acc.z, a.act, s.z); acc.w = apply_act(acc.w, a.act, s.w);
+    *reinterpret_cast<float4 *>(a.out.p + pix * a.out.ld + c) = acc;
+}
+
+// max pooling (window clipped to the input; ceil_mode handled by the host-computed output size)
+__global__ __launch_bounds__(256) void k_maxpool(View in, View out, int k, int stride, int pad) {
+    const int c4n = out.c >> 2;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)out.n * out.h * out.w * c4n;
+    if (idx >= total) return;
+    int c = (int)(idx % c4n) * 4; int64_t pix = idx / c4n;
+    int ox = (int)(pix % out.w); int64_t t = pix / out.w; int oy = (int)(t % out.h); int n = (int)(t / out.h);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int ky = 0; ky < k; ++ky) {
+        int iy = oy * stride - pad + ky;
+        if (iy < 0 || iy >= in.h) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            int ix = ox * stride - pad + kx;
+            if (ix < 0 || ix >= in.w) continue;
+            float4 x = *reinterpret_cast<const float4 *>(in.p + ((int64_t)(n * in.h + iy) * in.w + ix) * in.ld + c);
+            m.x = fmaxf(m.x, x.x); m.y = fmaxf(m.y, x.y); m.z = fmaxf(m.z, x.z); m.w = fmaxf(m.w, x.w);
+        }
+    }
+    *reinterpret_cast<float4 *>(out.p + pix * out.ld + c) = m;
+}
+
+// torch upsample_bilinear2d index/lambda (aten UpSample.h: area_pixel_compute_source_index + guard)
+__device__ __forceinline__ void src_index(int dst, int in_size, int out_size, float scale, bool align, int &i0, int &i1,
+                                          float &l0, float &l1) {
+    if (in_size == out_size) { i0 = i1 = dst; l0 = 1.0f; l1 = 0.0f; return; }
+    float real;
+    if (align) real = scale * (float)dst;
+    else { real = scale * ((float)dst + 0.5f) - 0.5f; if (real < 0.0f) real = 0.0f; }
+    i0 = min((int)real, in_size - 1);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = fminf(fmaxf(real - (float)i0, 0.0f), 1.0f);
+    l0 = 1.0f - l1;
+}
+
+// bilinear resize, generic channel count (float4 fast path when c%4==0 and pitches allow)
+__global__ __launch_bounds__(256) void k_bilinear(View in, View out, int align, float sh, float sw) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)out.n * out.h * out.w * out.c;
+    if (idx >= total) return;
+    int c = (int)(idx % out.c); int64_t pix = idx / out.c;
+    int ox = (int)(pix % out.w); int64_t t = pix / out.w; int oy = (int)(t % out.h); int n = (int)(t / out.h);
+    int y0, y1, x0, x1; float hl0, hl1, wl0, wl1;
+    src_index(oy, in.h, out.h, sh, align != 0, y0, y1, hl0, hl1);
+    src_index(ox, in.w, out.w, sw, align != 0, x0, x1, wl0, wl1);
+    const float *P = in.p + (int64_t)n * in.h * in.w * in.ld + c;
+    float p00 = P[((int64_t)y0 * in.w + x0) * in.ld], p01 = P[((int64_t)y0 * in.w + x1) * in.ld];
+    float p10 = P[((int64_t)y1 * in.w + x0) * in.ld], p11 = P[((int64_t)y1 * in.w + x1) * in.ld];
+    out.p[pix * out.ld + c] = hl0 * (wl0 * p00 + wl1 * p01) + hl1 * (wl0 * p10 + wl1 * p11);
+}
+
+__global__ __launch_bounds__(256) void k_nearest(View in, View out) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)out.n * out.h * out.w * (out.c >> 2);
+    if (idx >= total) return;
+    int c4n = out.c >> 2;
+    int c = (int)(idx % c4n) * 4; int64_t pix = idx / c4n;
+    int ox = (int)(pix % out.w); int64_t t = pix / out.w; int oy = (int)(t % out.h); int n = (int)(t / out.h);
+    int fy = out.h / in.h, fx = out.w / in.w;
+    int iy = oy / fy, ix = ox / fx;
+    *reinterpret_cast<float4 *>(out.p + pix * out.ld + c) =
+        *reinterpret_cast<const float4 *>(in.p + ((int64_t)(n * in.h + iy) * in.w + ix) * in.ld + c);
+}
+
+// out = act(a + b), or unary act / copy when b.p == nullptr
+__global__ __launch_bounds__(256) void k_eltwise(View a, View b, View out, int act, int mode) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)out.n * out.h * out.w * out.c;
+    if (idx >= total) return;
+    int c = (int)(idx % out.c); int64_t pix = idx / out.c;
+    float v = a.p[pix * a.ld + c];
+    if (mode == 1) v = v + b.p[pix * b.ld + c];
+    else if (mode == 2) { int64_t n = pix / ((int64_t)out.h * out.w); v = v * b.p[n * b.ld + c]; }
+    out.p[pix * out.ld + c] = apply_act(v, act, 0.0f);
+}
+
+// global average pool with a fixed, oracle-reproducible reduction tree:
+// 256 strided partial sums (sequential), then a binary tree 128,64,...,1, then / (h*w).
+__global__ __launch_bounds__(256) void k_gavgpool(View in, View out) {
+    __shared__ float part[256];
+    int c = blockIdx.x, n = blockIdx.y;
+    int hw = in.h * in.w;
+    const float *P = in.p + (int64_t)n * hw * in.ld + c;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < hw; i += 256) s += P[(int64_t)i * in.ld];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out.p[(int64_t)n * out.ld + c] = part[0] / (float)hw;
+}
+
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ src, int csrc, View out) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)out.n * out.h * out.w * out.c;
+    if (idx >= total) return;
+    int c = (int)(idx % out.c); int64_t pix = idx / out.c;
+    int64_t hw = (int64_t)out.h * out.w; int64_t n = pix / hw, p = pix - n * hw;
+    out.p[pix * out.ld + c] = c < csrc ? src[(n * csrc + c) * hw + p] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_nhwc_to_nchw(View in, float *__restrict__ dst) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t hw = (int64_t)in.h * in.w;
+    int64_t total = (int64_t)in.n * in.c * hw;
+    if (idx >= total) return;
+    int64_t p = idx % hw; int64_t t = idx / hw; int c = (int)(t % in.c); int64_t n = t / in.c;
+    dst[idx] = in.p[(n * hw + p) * in.ld + c];
+}
+
+template <int WM, int WN, int TN>
+int launch_conv(const ConvArgs &a0, hipStream_t st) {
+    constexpr int BM = 32 * WM, BN = 32 * WN * TN;
+    ConvArgs a = a0;
+    a.m_tiles = (a.M + BM - 1) / BM;
+    size_t lds = (size_t)2 * (BM + BN) * kLdsLd * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_mfma<WM, WN, TN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups);
+    k_conv_mfma<WM, WN, TN><<<grid, 256, lds, st>>>(a);
+    return csm::check_launch("k_conv_mfma");
+}
+
+inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+static int make_view(const csm_tensor_desc *tensors, int n_tensors, int id, float *workspace, void *const *ext,
+                     int n_ext, View &v) {
+    if (id < 0 || id >= n_tensors) { csm::set_error("tensor id %d out of range", id); return CSM_ERR_ARG; }
+    const csm_tensor_desc &t = tensors[id];
+    float *base;
+    if (t.ext >= 0) {
+        if (t.ext >= n_ext || !ext[t.ext]) { csm::set_error("ext slot %d missing", t.ext); return CSM_ERR_ARG; }
+        base = (float *)ext[t.ext];
+    } else base = workspace;
+    v.p = base + t.offset; v.n = t.n; v.h = t.h; v.w = t.w; v.c = t.c; v.ld = t.ld;
+    return CSM_OK;
+}
+
+extern "C" int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
+                               const float *weights, float *workspace, void *const *ext, int n_ext, void *stream) {
+    CSM_REQUIRE(ops && tensors && n_ops >= 0 && n_tensors > 0);
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n_ops; ++i) {
+        const csm_op &op = ops[i];
+        View in{}, in1{}, out{};
+        int rc = make_view(tensors, n_tensors, op.in0, workspace, ext, n_ext, in); if (rc) return rc;
+        rc = make_view(tensors, n_tensors, op.out, workspace, ext, n_ext, out); if (rc) return rc;
+        if (op.in1 >= 0) { rc = make_view(tensors, n_tensors, op.in1, workspace, ext, n_ext, in1); if (rc) return rc; }
+        switch (op.kind) {
+            case CSM_OP_CONV: {
+                ConvArgs a{};
+                a.in = in; a.out = out; a.res = in1;
+                a.w = weights + op.w_off; a.bias = op.b_off >= 0 ? weights + op.b_off : nullptr;
+                a.slope = op.aux_off >= 0 ? weights + op.aux_off : nullptr;
+                a.kh = op.kh; a.kw = op.kw; a.stride = op.stride; a.pad = op.pad; a.dil = op.dil;
+                a.groups = op.groups; a.cin_g = op.cin_g; a.cout_g = op.cout_g; a.npad = (op.cout_g + 31) / 32 * 32;
+                a.act = op.act; a.res_mode = op.in1 >= 0 ? op.res_mode : 0;
+                a.M = out.n * out.h * out.w; a.ncb = (op.cin_g + 31) / 32;
+                if ((in.ld & 3) || (op.cin_g & 3) || (((uintptr_t)in.p) & 15)) {
+                    csm::set_error("op %d: conv input must be 16-byte aligned with channels %% 4 == 0", i); return CSM_ERR_ARG;
+                }
+                // tile choice: wide N when there are many output channels, narrow M when the map is small
+                int64_t blocks128 = (int64_t)((a.M + 127) / 128) * ((op.cout_g + 63) / 64) * op.groups;
+                if (op.cout_g <= 32) rc = a.M >= 64 * 256 ? launch_conv<4, 1, 1>(a, st) : launch_conv<2, 2, 1>(a, st);
+                else if (blocks128 >= 256) rc = launch_conv<4, 1, 2>(a, st);
+                else if (a.M > 64) rc = launch_conv<2, 2, 1>(a, st);
+                else rc = launch_conv<1, 4, 1>(a, st);
+                if (rc) return rc;
+                break;
+            }
+            case CSM_OP_DWCONV: {
+                if ((in.ld & 3) || (out.ld & 3) || (out.c & 3)) { csm::set_error("op %d: dwconv needs c%%4==0", i); return CSM_ERR_ARG; }
+                DwArgs a{in, out, weights + op.w_off, op.b_off >= 0 ? weights + op.b_off : nullptr,
+                         op.aux_off >= 0 ? weights + op.aux_off : nullptr, op.kh, op.kw, op.stride, op.pad, op.dil, op.act};
+                k_dwconv<<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(a);
+                break;
+            }
+            case CSM_OP_MAXPOOL:
+                if ((in.ld & 3) || (out.ld & 3) || (out.c & 3)) { csm::set_error("op %d: maxpool needs c%%4==0", i); return CSM_ERR_ARG; }
+                k_maxpool<<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, out, op.kh, op.stride, op.pad);
+                break;
+            case CSM_OP_BILINEAR: {
+                bool align = op.flags & 1;
+                float sh, sw;
+                if (align) { sh = out.h > 1 ? (float)(in.h - 1) / (float)(out.h - 1) : 0.0f; sw = out.w > 1 ? (float)(in.w - 1) / (float)(out.w - 1) : 0.0f; }
+                else { sh = (float)in.h / (float)out.h; sw = (float)in.w / (float)out.w; }
+                k_bilinear<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw);
+                break;
+            }
+            case CSM_OP_NEAREST:
+                if ((in.ld & 3) || (out.ld & 3) || (out.c & 3)) { csm::set_error("op %d: nearest needs c%%4==0", i); return CSM_ERR_ARG; }
+                k_nearest<<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, out);
+                break;
+            case CSM_OP_ADD:
+                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act, 1);
+                break;
+            case CSM_OP_SCALE:
+                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act, 2);
+                break;
+            case CSM_OP_ACT:
+            case CSM_OP_COPY:
+                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.kind == CSM_OP_ACT ? op.act : 0, 0);
+                break;
+            case CSM_OP_GAVGPOOL:
+                k_gavgpool<<<dim3(in.c, in.n), 256, 0, st>>>(in, out);
+                break;
+            case CSM_OP_NCHW_TO_NHWC:
+                k_nchw_to_nhwc<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in.p, in.c, out);
+                break;
+            case CSM_OP_NHWC_TO_NCHW:
+                k_nhwc_to_nchw<<<blocks_for((int64_t)in.n * in.h * in.w * in.c), 256, 0, st>>>(in, out.p);
+                break;
+            default:
+                csm::set_error("op %d: unknown kind %d", i, op.kind);
+                return CSM_ERR_ARG;
+        }
+        rc = csm::check_launch("program op");
+        if (rc) { csm::set_error("op %d (kind %d) launch failed", i, op.kind); return rc; }
+    }
+    return CSM_OK;
+}

@@ -183,83 +183,196 @@ __global__ __launch_bounds__(kBlock) void k_update_output(const float *__restric
 }
 
 // models/utils.py:315  render = acc[:C]/(acc[C]+1e-7), existing = acc[C].clone()
-// MASK: also emit kenburns_effect.py:1039's  render[3]*(existing>0)  (C==4 only)
-template <bool MASK>
 __global__ __launch_bounds__(kBlock) void k_finalize(const float *__restrict__ accum, int B, int C, int64_t plane,
-                                                      float *__restrict__ render, float *__restrict__ existing,
-                                                      float *__restrict__ mask) {
+                                                      float *__restrict__ render, float *__restrict__ existing) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= plane) return;
     int b = blockIdx.y;
     const float *A = accum + (int64_t)b * (C + 1) * plane;
     float e = A[(int64_t)C * plane + i];
     float den = e + 0.0000001f;
-    float last = 0.0f;
-    for (int c = 0; c < C; ++c) {
-        last = A[(int64_t)c * plane + i] / den;
-        render[((int64_t)b * C + c) * plane + i] = last;
-    }
-    if (existing) existing[(int64_t)b * plane + i] = e;
-    if (MASK) mask[(int64_t)b * plane + i] = last * (e > 0.0f ? 1.0f : 0.0f);
+    for (int c = 0; c < C; ++c) render[((int64_t)b * C + c) * plane + i] = A[(int64_t)c * plane + i] / den;
+    existing[(int64_t)b * plane + i] = e;
 }
 
-struct Dirs { float x[16], y[16]; };
+__device__ __forceinline__ uint8_t to_u8(float v) {  // (x*255).clip(0,255).astype(uint8)  kenburns_effect.py:1040
+    float u = v * 255.0f;
+    u = u < 0.0f ? 0.0f : (u > 255.0f ? 255.0f : u);
+    return (uint8_t)u;
+}
 
-// kernel_discfill_updateOutput  (common.py:149-245).  U8: also write the uint8 HWC frame
-// (kenburns_effect.py:1040) from channels 0..2.
-template <bool U8>
-__global__ __launch_bounds__(kBlock) void k_discfill(const float *__restrict__ in, const float *__restrict__ depth,
-                                                      float *__restrict__ out, uint8_t *__restrict__ frame, int C,
-                                                      int H, int W, Dirs dirs) {
-    int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    int y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    int b = blockIdx.z;
-    if (x >= W || y >= H) return;
+// ---- disocclusion fill (common.py:145-248), restructured for CDNA4 ---------------------------
+// The reference runs one thread per pixel and lets hole pixels march 32 rays sequentially; on a
+// 64-wide machine that serialises ~32 x (ray length) dependent L2 round trips behind a handful of
+// active lanes.  Here pass 1 streams every pixel once (copy / normalise / uint8 / valid-byte) and
+// compacts hole pixels into a list; pass 2 gives every hole 32 lanes (16 directions x {from,to}),
+// each lane marching ONE ray with 4 speculative loads in flight, then a 16-lane argmin picks the
+// direction exactly like the sequential loop (shortest distance, first direction wins ties).
+
+struct HoleWork {
+    uint8_t *valid;   // [B*P] 1 = depth > 0
+    int *holes;       // [B*P] flat pixel ids
+    int *count;       // 1
+};
+
+// pass 1, generic operator: out <- in, valid <- depth > 0, holes <- pixels with depth <= 0
+__global__ __launch_bounds__(kBlock) void k_fill_prepare(const float *__restrict__ in, const float *__restrict__ depth,
+                                                          float *__restrict__ out, int C, int64_t plane, HoleWork hw) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= plane) return;
+    int b = blockIdx.y;
+    bool ok = (double)depth[(int64_t)b * plane + i] > 0.0;                           // common.py:160
+    hw.valid[(int64_t)b * plane + i] = ok ? 1 : 0;
+    for (int c = 0; c < C; ++c) out[((int64_t)b * C + c) * plane + i] = in[((int64_t)b * C + c) * plane + i];
+    if (!ok) hw.holes[atomicAdd(hw.count, 1)] = (int)((int64_t)b * plane + i);
+}
+
+// pass 1, frame path: normalise the accumulators (models/utils.py:315), depth mask
+// render[3]*(existing>0) (kenburns_effect.py:1039), uint8 frame (:1040), valid byte, hole list.
+__global__ __launch_bounds__(kBlock) void k_finalize_frame(const float *__restrict__ accum, int64_t plane,
+                                                            float *__restrict__ render, uint8_t *__restrict__ frame,
+                                                            HoleWork hw) {
+    // 4 consecutive pixels per lane: float4 loads from the 5 accumulator planes, one 12-byte frame store
+    int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (i0 >= plane) return;
+    float a[5][4];
+    const bool full = i0 + 3 < plane && (plane & 3) == 0;
+    if (full) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            float4 t = *reinterpret_cast<const float4 *>(accum + c * plane + i0);
+            a[c][0] = t.x; a[c][1] = t.y; a[c][2] = t.z; a[c][3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            for (int j = 0; j < 4; ++j) a[c][j] = i0 + j < plane ? accum[c * plane + i0 + j] : 0.0f;
+    }
+    float r[4][4]; uint8_t ok[4], px[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float e = a[4][j], den = e + 0.0000001f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c][j] = a[c][j] / den;
+        float m = r[3][j] * (e > 0.0f ? 1.0f : 0.0f);
+        ok[j] = (double)m > 0.0 ? 1 : 0;
+        px[3 * j + 0] = to_u8(r[0][j]); px[3 * j + 1] = to_u8(r[1][j]); px[3 * j + 2] = to_u8(r[2][j]);
+    }
+    if (full) {
+        *reinterpret_cast<uint32_t *>(hw.valid + i0) = ok[0] | (ok[1] << 8) | (ok[2] << 16) | ((uint32_t)ok[3] << 24);
+        uint32_t w0 = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);
+        uint32_t w1 = px[4] | (px[5] << 8) | (px[6] << 16) | ((uint32_t)px[7] << 24);
+        uint32_t w2 = px[8] | (px[9] << 8) | (px[10] << 16) | ((uint32_t)px[11] << 24);
+        uint32_t *F = reinterpret_cast<uint32_t *>(frame + i0 * 3);
+        F[0] = w0; F[1] = w1; F[2] = w2;
+        if (render) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<float4 *>(render + c * plane + i0) = make_float4(r[c][0], r[c][1], r[c][2], r[c][3]);
+        }
+    } else {
+        for (int j = 0; j < 4 && i0 + j < plane; ++j) {
+            hw.valid[i0 + j] = ok[j];
+            for (int c = 0; c < 3; ++c) frame[(i0 + j) * 3 + c] = px[3 * j + c];
+            if (render) for (int c = 0; c < 4; ++c) render[c * plane + i0 + j] = r[c][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!ok[j] && i0 + j < plane) hw.holes[atomicAdd(hw.count, 1)] = (int)(i0 + j);
+}
+
+__constant__ float kDirX[16] = {-1, 0, 1, 1, -1, 1, 2, 2, -2, -1, 1, 2, 3, 3, 3, 3};   // common.py:168
+__constant__ float kDirY[16] = {1, 1, 1, 0, 2, 2, 1, -1, 3, 3, 3, 3, 2, 1, -1, -2};    // common.py:169
+
+// pass 2.  FRAME=false: values from `in`/`depth` (generic operator, C channels).
+//          FRAME=true : values recomputed from the accumulators (bit-identical to pass 1), C = 4, also patches the
+//                       uint8 frame.
+template <bool FRAME>
+__global__ __launch_bounds__(kBlock) void k_fill_holes(const float *__restrict__ src, const float *__restrict__ depth,
+                                                        float *__restrict__ out, uint8_t *__restrict__ frame, int C,
+                                                        int H, int W, HoleWork hw) {
+    const int lane32 = threadIdx.x & 31;
+    const int k = lane32 & 15;
+    const bool to = lane32 >= 16;
+    float dx = kDirX[k], dy = kDirY[k];
+    float nrm = sqrtf((dx * dx) + (dy * dy));                                        // common.py:172-175
+    dx /= nrm; dy /= nrm;
+    const float sx = to ? dx : -dx, sy = to ? dy : -dy;                              // a - d == a + (-d) exactly
+    const int slot = (blockIdx.x * kBlock + threadIdx.x) >> 5;
+    const int nslots = (gridDim.x * kBlock) >> 5;
+    const int count = *hw.count;
     const int64_t plane = (int64_t)H * W;
-    const float *D = depth + (int64_t)b * plane;
-    const float *I = in + (int64_t)b * C * plane;
-    int srcx = x, srcy = y;
-    if (!((double)D[(int64_t)y * W + x] > 0.0)) {
-        float shortest = 1000000.0f;
-        int fillx = -1, filly = -1;
-        for (int k = 0; k < 16; ++k) {
-            const float dx = dirs.x[k], dy = dirs.y[k];
-            float ffx = (float)x, ffy = (float)y; int ifx = 0, ify = 0;
-            for (;;) {
-                ffx -= dx; ifx = (int)roundf(ffx);
-                ffy -= dy; ify = (int)roundf(ffy);
-                if (ifx < 0 || ifx >= W) break;
-                if (ify < 0 || ify >= H) break;
-                if ((double)D[(int64_t)ify * W + ifx] > 0.0) break;
+    for (int h = slot; h < count; h += nslots) {
+        const int g = hw.holes[h];
+        const int b = (int)(g / plane);
+        const int i = (int)(g - (int64_t)b * plane);
+        const int y = i / W, x = i - y * W;
+        const uint8_t *V = hw.valid + (int64_t)b * plane;
+        float fx = (float)x, fy = (float)y;
+        int ix = 0, iy = 0;
+        bool ok = false;
+        for (;;) {                                                                   // common.py:186-193 / :197-204
+            constexpr int kAhead = 16;   // speculative steps per round trip: positions do not depend on the loads
+            int jx[kAhead], jy[kAhead], v[kAhead];
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                fx += sx; fy += sy;
+                jx[j] = (int)roundf(fx); jy[j] = (int)roundf(fy);
             }
-            if (ifx < 0 || ifx >= W || ify < 0 || ify >= H) continue;
-            float ftx = (float)x, fty = (float)y; int itx = 0, ity = 0;
-            for (;;) {
-                ftx += dx; itx = (int)roundf(ftx);
-                fty += dy; ity = (int)roundf(fty);
-                if (itx < 0 || itx >= W) break;
-                if (ity < 0 || ity >= H) break;
-                if ((double)D[(int64_t)ity * W + itx] > 0.0) break;
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                bool inb = jx[j] >= 0 && jx[j] < W && jy[j] >= 0 && jy[j] < H;
+                v[j] = inb ? (int)V[(int64_t)jy[j] * W + jx[j]] : 2;
             }
-            if (itx < 0 || itx >= W || ity < 0 || ity >= H) continue;
-            float ddx = (float)(itx - ifx), ddy = (float)(ity - ify);
-            float dist = sqrtf(ddx * ddx + ddy * ddy);
-            if (shortest > dist) {
-                fillx = ifx; filly = ify;
-                if (D[(int64_t)ify * W + ifx] < D[(int64_t)ity * W + itx]) { fillx = itx; filly = ity; }
-                shortest = dist;
+            int stop = -1;
+#pragma unroll
+            for (int j = kAhead - 1; j >= 0; --j) if (v[j] != 0) stop = j;
+            if (stop >= 0) {
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) if (j == stop) { ix = jx[j]; iy = jy[j]; ok = v[j] == 1; }
+                break;
             }
         }
-        if (fillx != -1 && filly != -1) { srcx = fillx; srcy = filly; }
-    }
-    const int64_t so = (int64_t)srcy * W + srcx, o = (int64_t)y * W + x;
-    for (int c = 0; c < C; ++c) {
-        float v = I[(int64_t)c * plane + so];
-        if (out) out[((int64_t)b * C + c) * plane + o] = v;
-        if (U8 && c < 3) {
-            float u = v * 255.0f;
-            u = u < 0.0f ? 0.0f : (u > 255.0f ? 255.0f : u);
-            frame[o * 3 + c] = (uint8_t)u;
+        // pair the from/to rays of one direction (lanes k and k+16)
+        int ox = __shfl_xor(ix, 16), oy = __shfl_xor(iy, 16);
+        bool ook = __shfl_xor((int)ok, 16) != 0;
+        int fromx = to ? ox : ix, fromy = to ? oy : iy, tox = to ? ix : ox, toy = to ? iy : oy;
+        float ddx = (float)(tox - fromx), ddy = (float)(toy - fromy);
+        float dist = sqrtf(ddx * ddx + ddy * ddy);                                    // common.py:208
+        bool cand = ok && ook && (1000000.0f > dist);                                 // fltShortest starts at 1e6, strict >
+        float best = cand ? dist : INFINITY;
+        int bestk = cand ? k : 16;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {                                     // 16-lane lexicographic (dist, k) min
+            float od = __shfl_xor(best, off); int okk = __shfl_xor(bestk, off);
+            if (od < best || (od == best && okk < bestk)) { best = od; bestk = okk; }
+        }
+        if (bestk < 16) {
+            const int base = threadIdx.x & 32 & 63;  // 0 or 32 within the wave
+            const int srcl = base + bestk;            // the "from" lane of the winning direction
+            int wfx = __shfl(fromx, srcl), wfy = __shfl(fromy, srcl), wtx = __shfl(tox, srcl), wty = __shfl(toy, srcl);
+            const int64_t of = (int64_t)wfy * W + wfx, ot = (int64_t)wty * W + wtx;
+            float dfrom, dto;
+            if (FRAME) {
+                float ef = src[4 * plane + of], et = src[4 * plane + ot];
+                dfrom = (src[3 * plane + of] / (ef + 0.0000001f)) * (ef > 0.0f ? 1.0f : 0.0f);
+                dto = (src[3 * plane + ot] / (et + 0.0000001f)) * (et > 0.0f ? 1.0f : 0.0f);
+            } else {
+                dfrom = depth[(int64_t)b * plane + of]; dto = depth[(int64_t)b * plane + ot];
+            }
+            const int64_t so = dfrom < dto ? ot : of;                                 // common.py:214-217
+            if (FRAME) {
+                if (lane32 < 4) {
+                    float es = src[4 * plane + so];
+                    float v = src[(int64_t)lane32 * plane + so] / (es + 0.0000001f);
+                    if (out) out[(int64_t)lane32 * plane + i] = v;
+                    if (lane32 < 3) frame[(int64_t)i * 3 + lane32] = to_u8(v);
+                }
+            } else {
+                for (int c = lane32; c < C; c += 32)
+                    out[((int64_t)b * C + c) * plane + i] = src[((int64_t)b * C + c) * plane + so];
+            }
         }
     }
 }
@@ -347,18 +460,6 @@ ProjConst make_proj(int H, int W, double focal, double baseline) {
     return pc;
 }
 
-Dirs make_dirs() {  // common.py:168-176 (host IEEE fp32 == device IEEE fp32)
-    const float dx[16] = {-1, 0, 1, 1, -1, 1, 2, 2, -2, -1, 1, 2, 3, 3, 3, 3};
-    const float dy[16] = {1, 1, 1, 0, 2, 2, 1, -1, 3, 3, 3, 3, 2, 1, -1, -2};
-    Dirs d;
-    for (int k = 0; k < 16; ++k) {
-        volatile float n = sqrtf((dx[k] * dx[k]) + (dy[k] * dy[k]));
-        volatile float qx = dx[k] / n, qy = dy[k] / n;
-        d.x[k] = qx; d.y[k] = qy;
-    }
-    return d;
-}
-
 inline dim3 grid2d(int W, int H, int B, int bx, int by) { return dim3(csm::cdiv(W, bx), csm::cdiv(H, by), B); }
 
 }  // namespace
@@ -368,7 +469,7 @@ inline dim3 grid2d(int W, int H, int B, int bx, int by) { return dim3(csm::cdiv(
 // ------------------------------------------------------------------------------------------
 extern "C" int csm_pointrender_update_zee(const float *pts, int B, int64_t N, int H, int W, double focal,
                                           double baseline, float *zee, void *stream) {
-    CSM_REQUIRE(pts && zee && B > 0 && N >= 0 && H > 0 && W > 0);
+    CSM_REQUIRE(zee && (pts || N == 0) && B > 0 && N >= 0 && H > 0 && W > 0);
     if (N == 0) return CSM_OK;
     int64_t total = (int64_t)B * N;
     k_update_zee<false><<<csm::cdiv(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(
@@ -400,7 +501,7 @@ static int launch_update_output(const float *pts, const float *d0, int C0, const
 extern "C" int csm_pointrender_update_output(const float *pts, const float *data, const float *zee, int B, int C,
                                              int64_t N, int H, int W, double focal, double baseline, float *accum,
                                              void *stream) {
-    CSM_REQUIRE(pts && data && zee && accum && B > 0 && C > 0 && N >= 0 && H > 0 && W > 0);
+    CSM_REQUIRE(zee && accum && ((pts && data) || N == 0) && B > 0 && C > 0 && N >= 0 && H > 0 && W > 0);
     return launch_update_output(pts, data, C, nullptr, 0, B, N, H, W, focal, baseline, false, Shift{0, 0, 0}, zee,
                                 accum, (hipStream_t)stream);
 }
@@ -408,7 +509,7 @@ extern "C" int csm_pointrender_update_output(const float *pts, const float *data
 extern "C" int csm_render_pointcloud(const float *pts, const float *data, int B, int C, int64_t N, int W, int H,
                                      double focal, double baseline, float *zee_scratch, float *accum_scratch,
                                      float *render, float *existing, void *stream) {
-    CSM_REQUIRE(pts && data && zee_scratch && accum_scratch && render && existing);
+    CSM_REQUIRE(zee_scratch && accum_scratch && render && existing && ((pts && data) || N == 0));
     CSM_REQUIRE(B > 0 && C > 0 && N >= 0 && H > 0 && W > 0);
     hipStream_t st = (hipStream_t)stream;
     const int64_t plane = (int64_t)H * W;
@@ -426,17 +527,35 @@ extern "C" int csm_render_pointcloud(const float *pts, const float *data, int B,
     rc = launch_update_output(pts, data, C, nullptr, 0, B, N, H, W, focal, baseline, false, Shift{0, 0, 0}, zeeB,
                               accum_scratch, st);
     if (rc) return rc;
-    k_finalize<false><<<dim3(csm::cdiv(plane, kBlock), B), kBlock, 0, st>>>(accum_scratch, B, C, plane, render,
-                                                                             existing, nullptr);
+    k_finalize<<<dim3(csm::cdiv(plane, kBlock), B), kBlock, 0, st>>>(accum_scratch, B, C, plane, render, existing);
     return csm::check_launch("k_finalize");
 }
 
+static HoleWork carve_holework(void *scratch, int64_t npix) {
+    HoleWork hw;
+    char *p = (char *)scratch;
+    hw.count = (int *)p;                       // 16 bytes reserved
+    hw.holes = (int *)(p + 16);
+    hw.valid = (uint8_t *)(p + 16 + 4 * npix);
+    return hw;
+}
+
+extern "C" size_t csm_fill_disocclusion_scratch_bytes(int B, int H, int W) {
+    int64_t n = (int64_t)B * H * W;
+    return (size_t)(16 + 4 * n + ((n + 15) / 16) * 16);
+}
+
 extern "C" int csm_fill_disocclusion(const float *in, const float *depth, float *out, int B, int C, int H, int W,
-                                     void *stream) {
-    CSM_REQUIRE(in && depth && out && in != out && B > 0 && C > 0 && H > 0 && W > 0);
-    static const Dirs dirs = make_dirs();
-    k_discfill<false><<<grid2d(W, H, B, 32, 8), kBlock, 0, (hipStream_t)stream>>>(in, depth, out, nullptr, C, H, W, dirs);
-    return csm::check_launch("k_discfill");
+                                     void *scratch, void *stream) {
+    CSM_REQUIRE(in && depth && out && scratch && in != out && B > 0 && C > 0 && H > 0 && W > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t plane = (int64_t)H * W;
+    HoleWork hw = carve_holework(scratch, (int64_t)B * plane);
+    CSM_HIP(hipMemsetAsync(hw.count, 0, 16, st));
+    k_fill_prepare<<<dim3(csm::cdiv(plane, kBlock), B), kBlock, 0, st>>>(in, depth, out, C, plane, hw);
+    int rc = csm::check_launch("k_fill_prepare"); if (rc) return rc;
+    k_fill_holes<false><<<1024, kBlock, 0, st>>>(in, depth, out, nullptr, C, H, W, hw);
+    return csm::check_launch("k_fill_holes");
 }
 
 extern "C" int csm_spatial_filter_laplacian(const float *in, float *out, int BC, int H, int W, void *stream) {
@@ -463,27 +582,32 @@ extern "C" int csm_disparity_to_points(const float *disp, float disp_max, int H,
 
 extern "C" int csm_process_shift(const float *pts, float *out, int B, int64_t N, float sx, float sy, float sz,
                                  void *stream) {
-    CSM_REQUIRE(pts && out && B > 0 && N >= 0);
+    CSM_REQUIRE(((pts && out) || N == 0) && B > 0 && N >= 0);
     int64_t total = (int64_t)B * N;
     if (total == 0) return CSM_OK;
     k_process_shift<<<csm::cdiv(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(pts, out, N, total, Shift{sx, sy, sz});
     return csm::check_launch("k_process_shift");
 }
 
-extern "C" size_t csm_warp_frame_scratch_floats(int H, int W) { return (size_t)12 * (size_t)H * (size_t)W; }
+// scratch layout (floats): zeeA[P] | zeeB[P] | accum[5P] | hole work (16 B + 4P + P bytes)
+extern "C" size_t csm_warp_frame_scratch_floats(int H, int W) {
+    size_t P = (size_t)H * (size_t)W;
+    return 7 * P + (csm_fill_disocclusion_scratch_bytes(1, H, W) + 3) / 4 + 4;
+}
 
 extern "C" int csm_warp_frame(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W,
                               double focal, double baseline, float sx, float sy, float sz, float *scratch,
                               float *render_filled, uint8_t *frame_u8, void *stream) {
-    CSM_REQUIRE(pts && rgb && depth && scratch && frame_u8 && N >= 0 && H > 0 && W > 0);
+    CSM_REQUIRE(scratch && frame_u8 && N >= 0 && H > 0 && W > 0);
+    CSM_REQUIRE(N == 0 || (pts && rgb && depth));
     hipStream_t st = (hipStream_t)stream;
-    static const Dirs dirs = make_dirs();
     const int64_t plane = (int64_t)H * W;
-    float *zeeA = scratch, *zeeB = scratch + plane, *accum = scratch + 2 * plane;  // zeeA|zeeB|accum[5]|render[4]|mask
-    float *render = scratch + 7 * plane, *mask = scratch + 11 * plane;
+    float *zeeA = scratch, *zeeB = scratch + plane, *accum = scratch + 2 * plane;
+    HoleWork hw = carve_holework(scratch + 7 * plane, plane);
     Shift s{sx, sy, sz};
     ProjConst pc = make_proj(H, W, focal, baseline);
-    k_fill<<<1024, kBlock, 0, st>>>(zeeA, plane, 1000000.0f, accum, 5 * plane, 0.0f);
+    // one fill covers zee (1e6) and accum (0); the hole counter sits right behind accum and is zeroed with it
+    k_fill<<<2048, kBlock, 0, st>>>(zeeA, plane, 1000000.0f, accum, 5 * plane + 4, 0.0f);
     int rc = csm::check_launch("k_fill"); if (rc) return rc;
     if (N > 0) {
         k_update_zee<true><<<csm::cdiv(N, kBlock), kBlock, 0, st>>>(pts, N, N, pc, s, zeeA);
@@ -493,8 +617,8 @@ extern "C" int csm_warp_frame(const float *pts, const float *rgb, const float *d
     rc = csm::check_launch("k_degrid"); if (rc) return rc;
     rc = launch_update_output(pts, rgb, 3, depth, 1, 1, N, H, W, focal, baseline, true, s, zeeB, accum, st);
     if (rc) return rc;
-    k_finalize<true><<<dim3(csm::cdiv(plane, kBlock), 1), kBlock, 0, st>>>(accum, 1, 4, plane, render, nullptr, mask);
-    rc = csm::check_launch("k_finalize"); if (rc) return rc;
-    k_discfill<true><<<grid2d(W, H, 1, 32, 8), kBlock, 0, st>>>(render, mask, render_filled, frame_u8, 4, H, W, dirs);
-    return csm::check_launch("k_discfill");
+    k_finalize_frame<<<csm::cdiv((plane + 3) / 4, kBlock), kBlock, 0, st>>>(accum, plane, render_filled, frame_u8, hw);
+    rc = csm::check_launch("k_finalize_frame"); if (rc) return rc;
+    k_fill_holes<true><<<1024, kBlock, 0, st>>>(accum, nullptr, render_filled, frame_u8, 4, H, W, hw);
+    return csm::check_launch("k_fill_holes");
 }

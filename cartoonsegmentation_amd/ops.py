@@ -73,8 +73,10 @@ def fill_disocclusion(tenInput, tenDepth):
     tenInput, tenDepth = _dev(tenInput, "tenInput"), _dev(tenDepth, "tenDepth")
     B, C, H, W = tenInput.shape
     out = torch.empty_like(tenInput)
+    nbytes = _lib.load().csm_fill_disocclusion_scratch_bytes(i32(B), i32(H), i32(W))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=tenInput.device)
     check(_lib.load().csm_fill_disocclusion(ptr(tenInput), ptr(tenDepth), ptr(out), i32(B), i32(C), i32(H), i32(W),
-                                            stream_ptr()), "fill_disocclusion")
+                                            ptr(scratch), stream_ptr()), "fill_disocclusion")
     return out
 
 

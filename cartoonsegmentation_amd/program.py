@@ -1,0 +1,307 @@
+"""Lowering of a dense net into the layer program of libcsm355 (csm_op records, include/csm355.h).
+
+Host-side only (numpy + ctypes): weight import (BN folding, MFMA packing), tensor/liveness planning,
+op emission.  The same Program object yields
+  * the HIP program  (packed weights, super-grouped convs)      -> csm_run_program
+  * the oracle program (natural weights, real groups)           -> tests only (oracle/nets.py)
+so that the two executions share nothing but the op order and tensor plan.
+"""
+import ctypes
+
+import numpy as np
+
+# ---- C structs (must match include/csm355.h) -------------------------------------------------
+OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_BILINEAR, OP_NEAREST, OP_ADD, OP_GAVGPOOL, OP_SCALE = 1, 2, 3, 4, 5, 6, 7, 8
+OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_ACT, OP_COPY = 9, 10, 11, 12
+ACT = {None: 0, 'none': 0, 'relu': 1, 'silu': 2, 'prelu': 3, 'hsigmoid': 4, 'sigmoid': 5}
+
+
+class CsmTensorDesc(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_int64), ("ext", ctypes.c_int32), ("n", ctypes.c_int32), ("h", ctypes.c_int32),
+                ("w", ctypes.c_int32), ("c", ctypes.c_int32), ("ld", ctypes.c_int32)]
+
+
+class CsmOp(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("in0", ctypes.c_int32), ("in1", ctypes.c_int32), ("out", ctypes.c_int32),
+                ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("dil", ctypes.c_int32), ("groups", ctypes.c_int32), ("cin_g", ctypes.c_int32),
+                ("cout_g", ctypes.c_int32), ("act", ctypes.c_int32), ("res_mode", ctypes.c_int32),
+                ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64), ("aux_off", ctypes.c_int64),
+                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def fold_bn(w, b, gamma, beta, mean, var, eps):
+    """conv+BN(eval) -> conv: w' = w*s, b' = (b-mean)*s+beta, s = gamma/sqrt(var+eps); float64 math, fp32 result"""
+    w = np.asarray(w, np.float64)
+    s = np.asarray(gamma, np.float64) / np.sqrt(np.asarray(var, np.float64) + eps)
+    b0 = np.zeros(w.shape[0]) if b is None else np.asarray(b, np.float64)
+    return (w * s.reshape(-1, 1, 1, 1)).astype(np.float32), ((b0 - np.asarray(mean, np.float64)) * s
+                                                             + np.asarray(beta, np.float64)).astype(np.float32)
+
+
+def pack_conv_weights(w, groups):
+    """w [cout, cin_g, kh, kw] (fp32, folded) -> (packed fp32 1-D, super_groups, cin_sg, cout_sg)
+    packed layout: [sg][tap][cb][npad][32]  (npad = cout_sg rounded to 32; zero padded)"""
+    cout, cin_g, kh, kw = w.shape
+    if groups == 1:
+        sg, cin_sg, cout_sg = 1, cin_g, cout
+        wsg = w.reshape(1, cout, cin_g, kh, kw)
+    else:
+        cout_g = cout // groups
+        s = max(1, 32 // cin_g)
+        while groups % s:
+            s -= 1
+        sg, cin_sg, cout_sg = groups // s, s * cin_g, s * cout_g
+        wsg = np.zeros((sg, cout_sg, cin_sg, kh, kw), np.float32)
+        wg = w.reshape(groups, cout_g, cin_g, kh, kw)
+        for g in range(groups):
+            q, r = divmod(g, s)
+            wsg[q, r * cout_g:(r + 1) * cout_g, r * cin_g:(r + 1) * cin_g] = wg[g]
+    ncb, npad = (cin_sg + 31) // 32, (cout_sg + 31) // 32 * 32
+    full = np.zeros((sg, npad, ncb * 32, kh, kw), np.float32)
+    full[:, :cout_sg, :cin_sg] = wsg
+    packed = full.reshape(sg, npad, ncb, 32, kh, kw).transpose(0, 4, 5, 2, 1, 3)     # sg,kh,kw,cb,npad,32
+    return np.ascontiguousarray(packed).reshape(-1), sg, cin_sg, cout_sg
+
+
+class Buf:
+    def __init__(self, n, h, w, c, ext=-1, nchw=False):
+        self.n, self.h, self.w, self.c, self.ext, self.nchw = n, h, w, c, ext, nchw
+        self.offset = None
+        self.first, self.last = None, None
+        self.keep = False          # outputs / persistent tensors are never recycled
+
+
+class T:
+    """view of `c` channels starting at channel `coff` of a buffer"""
+    def __init__(self, prog, buf, coff, c):
+        self.prog, self.buf, self.coff, self.c = prog, buf, coff, c
+        self.id = len(prog.views)
+        prog.views.append(self)
+
+    n = property(lambda s: s.buf.n)
+    h = property(lambda s: s.buf.h)
+    w = property(lambda s: s.buf.w)
+
+    def slice(self, c0, c1):
+        return T(self.prog, self.buf, self.coff + c0, c1 - c0)
+
+    @property
+    def shape(self):
+        return (self.n, self.h, self.w, self.c)
+
+
+def _round4(c):
+    return (c + 3) // 4 * 4
+
+
+class Program:
+    def __init__(self, name=""):
+        self.name = name
+        self.views, self.bufs, self.ops = [], [], []      # ops: list of dict
+        self.w_hip, self.w_nat = [], []
+        self.n_hip = self.n_nat = 0
+        self.n_ext = 0
+        self.flops = 0
+        self.conv_bytes = 0
+
+    # ---- tensors --------------------------------------------------------------------------
+    def buffer(self, n, h, w, c):
+        b = Buf(n, h, w, c)
+        self.bufs.append(b)
+        return T(self, b, 0, c)
+
+    def ext_nchw(self, n, c, h, w):
+        """external (caller-owned) NCHW tensor, e.g. the net input / output"""
+        b = Buf(n, h, w, c, ext=self.n_ext, nchw=True)
+        self.n_ext += 1
+        self.bufs.append(b)
+        return T(self, b, 0, c)
+
+    def _w(self, hip, nat):
+        oh, on = self.n_hip, self.n_nat
+        hip, nat = np.ascontiguousarray(hip, np.float32).reshape(-1), np.ascontiguousarray(nat, np.float32).reshape(-1)
+        pad = (-hip.size) % 4
+        if pad:
+            hip = np.concatenate([hip, np.zeros(pad, np.float32)])
+        self.w_hip.append(hip); self.w_nat.append(nat)
+        self.n_hip += hip.size; self.n_nat += nat.size
+        return oh, on
+
+    def _emit(self, kind, in0, in1, out, **kw):
+        op = dict(kind=kind, in0=in0.id, in1=-1 if in1 is None else in1.id, out=out.id, kh=0, kw=0, stride=1, pad=0,
+                  dil=1, groups=1, cin_g=0, cout_g=0, act=0, res_mode=0, w_off=-1, b_off=-1, aux_off=-1, flags=0,
+                  nat=None)
+        op.update(kw)
+        i = len(self.ops)
+        for t in (in0, in1, out):
+            if t is None:
+                continue
+            b = t.buf
+            b.first = i if b.first is None else b.first
+            b.last = i
+        self.ops.append(op)
+        return out
+
+    # ---- ops ------------------------------------------------------------------------------
+    def to_nhwc(self, x_ext, c_pad=None):
+        c = _round4(x_ext.c) if c_pad is None else c_pad
+        out = self.buffer(x_ext.n, x_ext.h, x_ext.w, c)
+        return self._emit(OP_NCHW_TO_NHWC, x_ext, None, out)
+
+    def to_nchw(self, x, out_ext):
+        return self._emit(OP_NHWC_TO_NCHW, x, None, out_ext)
+
+    def conv(self, x, w, b=None, stride=1, pad=0, dil=1, groups=1, act=None, slope=None, res=None, res_mode=0, out=None):
+        """w [cout, cin/groups, kh, kw] fp32 (BN already folded); x channels may exceed w's cin only by zero padding"""
+        w = np.asarray(w, np.float32)
+        cout, cin_g, kh, kw = w.shape
+        if groups == 1 and x.c != cin_g:
+            assert x.c > cin_g and x.c == _round4(cin_g), (x.c, cin_g)
+            w = np.concatenate([w, np.zeros((cout, x.c - cin_g, kh, kw), np.float32)], 1)
+            cin_g = x.c
+        assert cin_g * groups == x.c, (cin_g, groups, x.c)
+        ho = (x.h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        wo = (x.w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        if out is None:
+            out = self.buffer(x.n, ho, wo, cout)
+        assert out.shape == (x.n, ho, wo, cout), (out.shape, (x.n, ho, wo, cout))
+        packed, sg, cin_sg, cout_sg = pack_conv_weights(w, groups)
+        w_h, w_n = self._w(packed, w)
+        b_h = b_n = a_h = a_n = -1
+        if b is not None:
+            b_h, b_n = self._w(b, b)
+        if slope is not None:
+            a_h, a_n = self._w(slope, slope)
+        self.flops += 2 * x.n * ho * wo * cout * cin_g * kh * kw
+        self.conv_bytes += 4 * (x.n * x.h * x.w * x.c + x.n * ho * wo * cout + w.size)
+        return self._emit(OP_CONV, x, res, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, groups=sg, cin_g=cin_sg,
+                          cout_g=cout_sg, act=ACT[act], res_mode=res_mode if res is not None else 0, w_off=w_h, b_off=b_h,
+                          aux_off=a_h, nat=dict(groups=groups, cin_g=cin_g, cout_g=cout // groups, w_off=w_n, b_off=b_n,
+                                                aux_off=a_n))
+
+    def dwconv(self, x, w, b=None, stride=1, pad=0, dil=1, act=None, out=None):
+        """depthwise: w [c,1,kh,kw]"""
+        w = np.asarray(w, np.float32)
+        c, _, kh, kw = w.shape
+        assert c == x.c and c % 4 == 0
+        ho = (x.h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        wo = (x.w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        if out is None:
+            out = self.buffer(x.n, ho, wo, c)
+        w_h, w_n = self._w(w.reshape(c, kh * kw).T, w)          # hip: [tap][c]
+        b_h = b_n = -1
+        if b is not None:
+            b_h, b_n = self._w(b, b)
+        self.flops += 2 * x.n * ho * wo * c * kh * kw
+        return self._emit(OP_DWCONV, x, None, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, act=ACT[act], w_off=w_h,
+                          b_off=b_h, nat=dict(w_off=w_n, b_off=b_n))
+
+    def maxpool(self, x, k, stride, pad=0, ceil_mode=False, out=None):
+        def osz(i):
+            num = i + 2 * pad - k
+            o = (-(-num // stride) if ceil_mode else num // stride) + 1
+            if ceil_mode and (o - 1) * stride >= i + pad:        # torch: last window must start inside input+left pad
+                o -= 1
+            return o
+        if out is None:
+            out = self.buffer(x.n, osz(x.h), osz(x.w), x.c)
+        return self._emit(OP_MAXPOOL, x, None, out, kh=k, kw=k, stride=stride, pad=pad)
+
+    def bilinear(self, x, size, align_corners=False, out=None):
+        if out is None:
+            out = self.buffer(x.n, size[0], size[1], x.c)
+        assert (out.h, out.w) == tuple(size)
+        return self._emit(OP_BILINEAR, x, None, out, flags=1 if align_corners else 0)
+
+    def nearest(self, x, factor, out=None):
+        if out is None:
+            out = self.buffer(x.n, x.h * factor, x.w * factor, x.c)
+        return self._emit(OP_NEAREST, x, None, out)
+
+    def add(self, a, b, act=None, out=None):
+        if out is None:
+            out = self.buffer(a.n, a.h, a.w, a.c)
+        return self._emit(OP_ADD, a, b, out, act=ACT[act])
+
+    def act(self, x, act, out=None):
+        if out is None:
+            out = self.buffer(x.n, x.h, x.w, x.c)
+        return self._emit(OP_ACT, x, None, out, act=ACT[act])
+
+    def copy(self, x, out):
+        return self._emit(OP_COPY, x, None, out)
+
+    def gavgpool(self, x):
+        out = self.buffer(x.n, 1, 1, x.c)
+        return self._emit(OP_GAVGPOOL, x, None, out)
+
+    def scale(self, x, s, out=None):
+        if out is None:
+            out = self.buffer(x.n, x.h, x.w, x.c)
+        return self._emit(OP_SCALE, x, s, out)
+
+    def keep(self, t):
+        t.buf.keep = True
+        return t
+
+    # ---- planning / serialisation -----------------------------------------------------------
+    def plan(self):
+        """greedy first-fit workspace plan over buffer lifetimes; returns workspace floats"""
+        ALIGN = 64
+        free, top = [], 0            # free: list of (offset, size)
+        by_first, by_last = {}, {}
+        for b in self.bufs:
+            if b.ext >= 0 or b.first is None:
+                continue
+            b.size = (b.n * b.h * b.w * b.c + ALIGN - 1) // ALIGN * ALIGN
+            by_first.setdefault(b.first, []).append(b)
+            if not b.keep:
+                by_last.setdefault(b.last, []).append(b)
+        for i in range(len(self.ops)):
+            for b in by_first.get(i, []):
+                best = None
+                for k, (off, sz) in enumerate(free):
+                    if sz >= b.size and (best is None or sz < free[best][1]):
+                        best = k
+                if best is None:
+                    b.offset = top; top += b.size
+                else:
+                    off, sz = free.pop(best)
+                    b.offset = off
+                    if sz > b.size:
+                        free.append((off + b.size, sz - b.size))
+            for b in by_last.get(i, []):
+                free.append((b.offset, b.size))
+                free.sort()
+                merged = []
+                for off, sz in free:
+                    if merged and merged[-1][0] + merged[-1][1] == off:
+                        merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+                    else:
+                        merged.append((off, sz))
+                free = merged
+        self.workspace_floats = top
+        return top
+
+    def serialise(self, oracle=False):
+        """-> (ops ctypes array, tensors ctypes array, weights fp32 ndarray)"""
+        if getattr(self, "workspace_floats", None) is None:
+            self.plan()
+        tens = (CsmTensorDesc * len(self.views))()
+        for i, v in enumerate(self.views):
+            b = v.buf
+            if b.ext >= 0:
+                tens[i] = CsmTensorDesc(0, b.ext, b.n, b.h, b.w, v.c, b.c)
+            else:
+                tens[i] = CsmTensorDesc(b.offset + v.coff, -1, b.n, b.h, b.w, v.c, b.c)
+        ops = (CsmOp * len(self.ops))()
+        for i, o in enumerate(self.ops):
+            d = dict(o)
+            nat = d.pop('nat')
+            if oracle and nat:
+                d.update(nat)
+            ops[i] = CsmOp(**{k: int(v) for k, v in d.items()}, reserved=0)
+        ws = self.w_nat if oracle else self.w_hip
+        weights = np.concatenate(ws) if ws else np.zeros(4, np.float32)
+        return ops, tens, weights

@@ -1,0 +1,38 @@
+"""Device-side execution of a lowered Program through libcsm355's csm_run_program."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, stream_ptr
+
+
+class CompiledProgram:
+    """weights + workspace resident in HBM; run() enqueues the whole net on the current stream
+    (no allocation, no host sync -> capturable in a hipGraph via torch.cuda.graph)."""
+
+    def __init__(self, prog, device, weights=None):
+        self.prog = prog
+        self.ops, self.tensors, w = prog.serialise(oracle=False)
+        self.device = torch.device(device)
+        self.weights = torch.from_numpy(w).to(self.device) if weights is None else weights
+        self.workspace = torch.empty(max(prog.workspace_floats, 64), dtype=torch.float32, device=self.device)
+        self.n_ext = prog.n_ext
+        self._ext = (ctypes.c_void_p * max(self.n_ext, 1))()
+
+    def run(self, *ext_tensors):
+        assert len(ext_tensors) == self.n_ext, (len(ext_tensors), self.n_ext)
+        for i, t in enumerate(ext_tensors):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.CsmError("program ext tensor %d must be a contiguous float32 device tensor" % i)
+            self._ext[i] = t.data_ptr()
+        check(_lib.load().csm_run_program(self.ops, ctypes.c_int(len(self.ops)), self.tensors,
+                                          ctypes.c_int(len(self.tensors)), ctypes.c_void_p(self.weights.data_ptr()),
+                                          ctypes.c_void_p(self.workspace.data_ptr()), self._ext, ctypes.c_int(self.n_ext),
+                                          stream_ptr()), "run_program(%s)" % self.prog.name)
+
+    def read_view(self, t):
+        """debug: copy a planned NHWC view out of the workspace as [n,h,w,c]"""
+        b = t.buf
+        full = self.workspace[b.offset:b.offset + b.n * b.h * b.w * b.c].view(b.n, b.h, b.w, b.c)
+        return full[..., t.coff:t.coff + t.c].clone()

@@ -31,14 +31,17 @@ def image_u8(H=1024, W=1024, seed=1234):
 
 
 def disparity(H=1024, W=1024, seed=1234):
-    """depth plane + 3 gaussian bumps (foreground objects); raw disparity > 0, float32 [H,W]"""
+    """depth plane + 3 flat-topped foreground objects with crisp silhouettes (discs with a
+    ~1.5 px wide sigmoid edge at every resolution, like segmented characters) so that camera moves open real disocclusions;
+    raw disparity > 0, float32 [H,W]"""
     g = np.random.default_rng(seed + 7)
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
     d = 6.0 + 8.0 * yy / H
     for _ in range(3):
         cx, cy = g.uniform(0.2, 0.8) * W, g.uniform(0.2, 0.8) * H
         s, a = g.uniform(0.06, 0.14) * min(H, W), g.uniform(10.0, 24.0)
-        d = d + a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2.0 * s * s))
+        r = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)
+        d = d + a / (1.0 + np.exp(np.clip((r - 2.0 * s) / 0.75, -60.0, 60.0)))
     return d.astype(np.float32)
 
 

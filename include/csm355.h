@@ -62,9 +62,11 @@ int csm_render_pointcloud(const float *pts, const float *data, int B, int C, int
                           float *render, float *existing, void *stream);
 
 /* fill_disocclusion   anime_3dkenburns/common.py:145-248
- * in [B,C,H,W], depth [B,1,H,W] -> out [B,C,H,W] (out is fully written; no pre-clone needed) */
+ * in [B,C,H,W], depth [B,1,H,W] -> out [B,C,H,W] (out is fully written; no pre-clone needed).
+ * scratch: csm_fill_disocclusion_scratch_bytes(B,H,W) bytes of device memory (hole list + valid map). */
+size_t csm_fill_disocclusion_scratch_bytes(int B, int H, int W);
 int csm_fill_disocclusion(const float *in, const float *depth, float *out, int B, int C, int H, int W,
-                          void *stream);
+                          void *scratch, void *stream);
 
 /* spatial_filter(x,'laplacian')   models/utils.py:12-24 ; x,out [BC,H,W] */
 int csm_spatial_filter_laplacian(const float *in, float *out, int BC, int H, int W, void *stream);
@@ -90,6 +92,64 @@ size_t csm_warp_frame_scratch_floats(int H, int W);
 int csm_warp_frame(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W,
                    double focal, double baseline, float sx, float sy, float sz, float *scratch,
                    float *render_filled, uint8_t *frame_u8, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Dense networks: a flat "layer program" executed on one stream (no allocation, graph-capturable)
+ *
+ * The reference runs these nets through torch nn.Modules (cuDNN); the replacement boundary is the
+ * module call: animeinsseg/models/animeseg_refine/isnet.py:578 (ISNetDIS.forward),
+ * depth_modules/leres/leres/multi_depth_model_woauxi.py:30 (RelDepthModel), mmdet RTMDet
+ * (call site animeinsseg/__init__.py:450).  The host (Python, cartoonsegmentation_amd/program.py)
+ * lowers a net into csm_op records + one packed fp32 weight buffer (BN folded); this library
+ * executes them with hand-written gfx950 kernels.  Activations are NHWC fp32 inside a caller-
+ * provided workspace; a tensor may be a channel slice of a wider buffer (ld = channel pitch), which
+ * is how torch.cat is realised without copies.
+ *
+ * Numerical contract (so the CPU oracle can be bit-exact): every convolution output is ONE fp32
+ * fmaf chain  acc = bias; for tap (kh,kw) row-major; for each aligned block of 8 input channels,
+ * channel order 0,4,1,5,2,6,3,7 (the v_mfma_f32_32x32x2_f32 lane order): acc = fmaf(x, w, acc).
+ * Epilogue order: (+residual if res_mode==1) -> activation -> (+residual if res_mode==2).
+ * SiLU/sigmoid use the polynomial expf documented in DESIGN.md.
+ * ---------------------------------------------------------------------------------- */
+enum csm_op_kind {
+    CSM_OP_CONV = 1,        /* dense or grouped conv on fp32 MFMA (implicit GEMM) */
+    CSM_OP_DWCONV = 2,      /* depthwise conv, direct */
+    CSM_OP_MAXPOOL = 3,     /* p: k, stride, pad (ceil_mode is implied by the output size) */
+    CSM_OP_BILINEAR = 4,    /* p[0]=align_corners; output size from the out tensor */
+    CSM_OP_NEAREST = 5,     /* nearest upsample, integer factor from sizes */
+    CSM_OP_ADD = 6,         /* out = act(in0 + in1) */
+    CSM_OP_GAVGPOOL = 7,    /* global average pool -> [n,1,1,c] */
+    CSM_OP_SCALE = 8,       /* out = in0 * in1[n,0,0,c] */
+    CSM_OP_NCHW_TO_NHWC = 9,/* in0 = ext NCHW tensor (c real channels) -> NHWC padded to out.c (zeros) */
+    CSM_OP_NHWC_TO_NCHW = 10,
+    CSM_OP_ACT = 11,        /* out = act(in0) */
+    CSM_OP_COPY = 12        /* out = in0 (slice copy) */
+};
+enum csm_act { CSM_ACT_NONE = 0, CSM_ACT_RELU = 1, CSM_ACT_SILU = 2, CSM_ACT_PRELU = 3, CSM_ACT_HSIGMOID = 4,
+               CSM_ACT_SIGMOID = 5 };
+
+typedef struct csm_tensor_desc {
+    int64_t offset;      /* floats from the workspace base (ext < 0) or from ext pointer slot `ext` */
+    int32_t ext;         /* -1: workspace; >=0: index into the ext pointer table of csm_run_program */
+    int32_t n, h, w, c;  /* logical NHWC shape (c = channels of this view) */
+    int32_t ld;          /* channel pitch in floats (>= c); NCHW ext tensors: ld is ignored */
+} csm_tensor_desc;
+
+typedef struct csm_op {
+    int32_t kind;
+    int32_t in0, in1, out;   /* tensor ids; in1 = residual / second operand, -1 if none */
+    int32_t kh, kw, stride, pad, dil;
+    int32_t groups;          /* CONV: number of super-groups (1 = dense); each maps cin_g -> cout_g channels */
+    int32_t cin_g, cout_g;
+    int32_t act, res_mode;   /* res_mode: 0 none, 1 add before act, 2 add after act */
+    int64_t w_off, b_off, aux_off;   /* float offsets into the weight buffer (aux = PReLU slopes); -1 = none */
+    int32_t flags, reserved;
+} csm_op;
+
+/* Execute ops[0..n_ops) in order on `stream`.  `weights` and `workspace` are device pointers;
+ * ext[i] are device pointers of external (caller-owned) tensors. */
+int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
+                    const float *weights, float *workspace, void *const *ext, int n_ext, void *stream);
 
 #ifdef __cplusplus
 }

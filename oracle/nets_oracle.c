@@ -1,0 +1,288 @@
+/*
+ * oracle/nets_oracle.c  --  TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU interpreter of the layer program (csm_op records, include/csm355.h) that the product
+ * executes with HIP kernels.  It is the bit-exact checker of the dense nets: every convolution
+ * output is one fp32 fmaf chain in the contract's order (bias first; taps row-major; aligned
+ * blocks of 8 input channels in the order 0,4,1,5,2,6,3,7), activations use the same polynomial
+ * expf, pooling / resize follow aten's index rules.
+ *
+ * Independence from the product: this file reads NATURAL weight layouts
+ * ([cout][cin_g][kh][kw] for convs, [c][kh][kw] for depthwise) -- the product's packed/padded
+ * MFMA layout is never seen here, so a packing bug cannot cancel out.
+ *
+ * Parity pin: oracle/nets (this interpreter run on programs lowered from the build's net
+ * definitions) is checked in tests/test_oracle_nets.py against fixtures produced by the
+ * reference's own torch modules (tests/golden/make_golden_nets.py: ISNetDIS isnet.py:524-645,
+ * LeReS network_auxi.py / Resnext_torch.py) -- tolerance 2e-4 relative (BN folding + summation
+ * order differ from torch's kernels).  RTMDet (mmdet 3.3.0, not in /root/reference): parity
+ * unpinned, see DESIGN.md.
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp (oracle/Makefile).  fmaf() is explicit, so
+ * -ffp-contract=off does not change it and -mfma only makes it one instruction.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/csm355.h"
+
+static float orc_expf(float x)
+{
+    x = fminf(fmaxf(x, -87.0f), 88.0f);
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float e = fmaf(p, r * r, r) + 1.0f;
+    int32_t bits = ((int32_t)n + 127) << 23;
+    float s; memcpy(&s, &bits, 4);
+    return e * s;
+}
+
+static float orc_act(float v, int act, float slope)
+{
+    switch (act) {
+        case CSM_ACT_RELU: return fmaxf(v, 0.0f);
+        case CSM_ACT_SILU: return v / (1.0f + orc_expf(-v));
+        case CSM_ACT_PRELU: return v >= 0.0f ? v : v * slope;
+        case CSM_ACT_HSIGMOID: return fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
+        case CSM_ACT_SIGMOID: return 1.0f / (1.0f + orc_expf(-v));
+        default: return v;
+    }
+}
+
+typedef struct { float *p; int n, h, w, c, ld; } view_t;
+
+static int get_view(const csm_tensor_desc *t, int id, float *ws, void *const *ext, view_t *v)
+{
+    if (id < 0) { memset(v, 0, sizeof(*v)); return 0; }
+    float *base = t[id].ext >= 0 ? (float *)ext[t[id].ext] : ws;
+    v->p = base + t[id].offset; v->n = t[id].n; v->h = t[id].h; v->w = t[id].w; v->c = t[id].c; v->ld = t[id].ld;
+    return 0;
+}
+
+/* conv: weights natural [groups*cout_g][cin_g][kh][kw]; op->groups = REAL groups */
+static void orc_conv(const csm_op *op, view_t in, view_t res, view_t out, const float *W, const float *bias,
+                     const float *slope)
+{
+    const int kh = op->kh, kw = op->kw, cin = op->cin_g, cout = op->cout_g, G = op->groups;
+    const int64_t M = (int64_t)out.n * out.h * out.w;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        int n = (int)(m / ((int64_t)out.h * out.w));
+        int rem = (int)(m - (int64_t)n * out.h * out.w);
+        int oy = rem / out.w, ox = rem - oy * out.w;
+        for (int g = 0; g < G; ++g)
+            for (int co = 0; co < cout; ++co) {
+                int oc = g * cout + co;
+                float acc = bias ? bias[oc] : 0.0f;
+                for (int ky = 0; ky < kh; ++ky) {
+                    int iy = oy * op->stride - op->pad + ky * op->dil;
+                    if (iy < 0 || iy >= in.h) continue;
+                    for (int kx = 0; kx < kw; ++kx) {
+                        int ix = ox * op->stride - op->pad + kx * op->dil;
+                        if (ix < 0 || ix >= in.w) continue;
+                        const float *x = in.p + ((int64_t)(n * in.h + iy) * in.w + ix) * in.ld + g * cin;
+                        const float *w = W + ((int64_t)oc * cin) * kh * kw + ky * kw + kx;
+                        for (int kb = 0; kb < cin; kb += 8)
+                            for (int t = 0; t < 4; ++t)
+                                for (int h = 0; h < 2; ++h) {
+                                    int c = kb + 4 * h + t;
+                                    if (c < cin) acc = fmaf(x[c], w[(int64_t)c * kh * kw], acc);
+                                }
+                    }
+                }
+                if (op->res_mode == 1 && res.p) acc += res.p[m * res.ld + oc];
+                acc = orc_act(acc, op->act, slope ? slope[oc] : 0.0f);
+                if (op->res_mode == 2 && res.p) acc += res.p[m * res.ld + oc];
+                out.p[m * out.ld + oc] = acc;
+            }
+    }
+}
+
+/* depthwise: weights natural [c][kh][kw] */
+static void orc_dwconv(const csm_op *op, view_t in, view_t out, const float *W, const float *bias, const float *slope)
+{
+    const int64_t M = (int64_t)out.n * out.h * out.w;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        int n = (int)(m / ((int64_t)out.h * out.w));
+        int rem = (int)(m - (int64_t)n * out.h * out.w);
+        int oy = rem / out.w, ox = rem - oy * out.w;
+        for (int c = 0; c < out.c; ++c) {
+            float acc = bias ? bias[c] : 0.0f;
+            for (int ky = 0; ky < op->kh; ++ky) {
+                int iy = oy * op->stride - op->pad + ky * op->dil;
+                if (iy < 0 || iy >= in.h) continue;
+                for (int kx = 0; kx < op->kw; ++kx) {
+                    int ix = ox * op->stride - op->pad + kx * op->dil;
+                    if (ix < 0 || ix >= in.w) continue;
+                    acc = fmaf(in.p[((int64_t)(n * in.h + iy) * in.w + ix) * in.ld + c],
+                               W[((int64_t)c * op->kh + ky) * op->kw + kx], acc);
+                }
+            }
+            out.p[m * out.ld + c] = orc_act(acc, op->act, slope ? slope[c] : 0.0f);
+        }
+    }
+}
+
+static void orc_maxpool(const csm_op *op, view_t in, view_t out)
+{
+    const int64_t M = (int64_t)out.n * out.h * out.w;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        int n = (int)(m / ((int64_t)out.h * out.w));
+        int rem = (int)(m - (int64_t)n * out.h * out.w);
+        int oy = rem / out.w, ox = rem - oy * out.w;
+        for (int c = 0; c < out.c; ++c) {
+            float mx = -INFINITY;
+            for (int ky = 0; ky < op->kh; ++ky) {
+                int iy = oy * op->stride - op->pad + ky;
+                if (iy < 0 || iy >= in.h) continue;
+                for (int kx = 0; kx < op->kh; ++kx) {
+                    int ix = ox * op->stride - op->pad + kx;
+                    if (ix < 0 || ix >= in.w) continue;
+                    mx = fmaxf(mx, in.p[((int64_t)(n * in.h + iy) * in.w + ix) * in.ld + c]);
+                }
+            }
+            out.p[m * out.ld + c] = mx;
+        }
+    }
+}
+
+/* aten/src/ATen/native/UpSample.h: area_pixel_compute_source_index + guard_index_and_lambda */
+static void src_index(int dst, int in_size, int out_size, float scale, int align, int *i0, int *i1, float *l0, float *l1)
+{
+    if (in_size == out_size) { *i0 = *i1 = dst; *l0 = 1.0f; *l1 = 0.0f; return; }
+    float real;
+    if (align) real = scale * (float)dst;
+    else { real = scale * ((float)dst + 0.5f) - 0.5f; if (real < 0.0f) real = 0.0f; }
+    *i0 = (int)real < in_size - 1 ? (int)real : in_size - 1;
+    *i1 = *i0 + (*i0 < in_size - 1 ? 1 : 0);
+    *l1 = fminf(fmaxf(real - (float)*i0, 0.0f), 1.0f);
+    *l0 = 1.0f - *l1;
+}
+
+static void orc_bilinear(const csm_op *op, view_t in, view_t out)
+{
+    int align = op->flags & 1;
+    float sh, sw;
+    if (align) { sh = out.h > 1 ? (float)(in.h - 1) / (float)(out.h - 1) : 0.0f; sw = out.w > 1 ? (float)(in.w - 1) / (float)(out.w - 1) : 0.0f; }
+    else { sh = (float)in.h / (float)out.h; sw = (float)in.w / (float)out.w; }
+    const int64_t M = (int64_t)out.n * out.h * out.w;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        int n = (int)(m / ((int64_t)out.h * out.w));
+        int rem = (int)(m - (int64_t)n * out.h * out.w);
+        int oy = rem / out.w, ox = rem - oy * out.w;
+        int y0, y1, x0, x1; float hl0, hl1, wl0, wl1;
+        src_index(oy, in.h, out.h, sh, align, &y0, &y1, &hl0, &hl1);
+        src_index(ox, in.w, out.w, sw, align, &x0, &x1, &wl0, &wl1);
+        const float *P = in.p + (int64_t)n * in.h * in.w * in.ld;
+        for (int c = 0; c < out.c; ++c) {
+            float p00 = P[((int64_t)y0 * in.w + x0) * in.ld + c], p01 = P[((int64_t)y0 * in.w + x1) * in.ld + c];
+            float p10 = P[((int64_t)y1 * in.w + x0) * in.ld + c], p11 = P[((int64_t)y1 * in.w + x1) * in.ld + c];
+            out.p[m * out.ld + c] = hl0 * (wl0 * p00 + wl1 * p01) + hl1 * (wl0 * p10 + wl1 * p11);
+        }
+    }
+}
+
+static void orc_nearest(view_t in, view_t out)
+{
+    int fy = out.h / in.h, fx = out.w / in.w;
+    const int64_t M = (int64_t)out.n * out.h * out.w;
+    for (int64_t m = 0; m < M; ++m) {
+        int n = (int)(m / ((int64_t)out.h * out.w));
+        int rem = (int)(m - (int64_t)n * out.h * out.w);
+        int oy = rem / out.w, ox = rem - oy * out.w;
+        memcpy(out.p + m * out.ld, in.p + ((int64_t)(n * in.h + oy / fy) * in.w + ox / fx) * in.ld, (size_t)out.c * 4);
+    }
+}
+
+static void orc_eltwise(view_t a, view_t b, view_t out, int act, int mode)
+{
+    const int64_t M = (int64_t)out.n * out.h * out.w;
+    for (int64_t m = 0; m < M; ++m) {
+        int64_t n = m / ((int64_t)out.h * out.w);
+        for (int c = 0; c < out.c; ++c) {
+            float v = a.p[m * a.ld + c];
+            if (mode == 1) v = v + b.p[m * b.ld + c];
+            else if (mode == 2) v = v * b.p[n * b.ld + c];
+            out.p[m * out.ld + c] = orc_act(v, act, 0.0f);
+        }
+    }
+}
+
+/* same fixed reduction tree as k_gavgpool: 256 strided sequential partials, then 128,64,..,1 */
+static void orc_gavgpool(view_t in, view_t out)
+{
+    int hw = in.h * in.w;
+    for (int n = 0; n < in.n; ++n)
+        for (int c = 0; c < in.c; ++c) {
+            float part[256];
+            const float *P = in.p + (int64_t)n * hw * in.ld + c;
+            for (int t = 0; t < 256; ++t) {
+                float s = 0.0f;
+                for (int i = t; i < hw; i += 256) s += P[(int64_t)i * in.ld];
+                part[t] = s;
+            }
+            for (int st = 128; st >= 1; st >>= 1)
+                for (int t = 0; t < st; ++t) part[t] += part[t + st];
+            out.p[(int64_t)n * out.ld + c] = part[0] / (float)hw;
+        }
+}
+
+int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors, const float *weights,
+                    float *workspace, void *const *ext, int n_ext)
+{
+    (void)n_tensors; (void)n_ext;
+    for (int i = 0; i < n_ops; ++i) {
+        const csm_op *op = &ops[i];
+        view_t in, in1, out;
+        get_view(tensors, op->in0, workspace, ext, &in);
+        get_view(tensors, op->in1, workspace, ext, &in1);
+        get_view(tensors, op->out, workspace, ext, &out);
+        const float *W = op->w_off >= 0 ? weights + op->w_off : NULL;
+        const float *B = op->b_off >= 0 ? weights + op->b_off : NULL;
+        const float *S = op->aux_off >= 0 ? weights + op->aux_off : NULL;
+        switch (op->kind) {
+            case CSM_OP_CONV: orc_conv(op, in, in1, out, W, B, S); break;
+            case CSM_OP_DWCONV: orc_dwconv(op, in, out, W, B, S); break;
+            case CSM_OP_MAXPOOL: orc_maxpool(op, in, out); break;
+            case CSM_OP_BILINEAR: orc_bilinear(op, in, out); break;
+            case CSM_OP_NEAREST: orc_nearest(in, out); break;
+            case CSM_OP_ADD: orc_eltwise(in, in1, out, op->act, 1); break;
+            case CSM_OP_SCALE: orc_eltwise(in, in1, out, op->act, 2); break;
+            case CSM_OP_ACT: orc_eltwise(in, in1, out, op->act, 0); break;
+            case CSM_OP_COPY: orc_eltwise(in, in1, out, 0, 0); break;
+            case CSM_OP_GAVGPOOL: orc_gavgpool(in, out); break;
+            case CSM_OP_NCHW_TO_NHWC: {
+                int64_t hw = (int64_t)out.h * out.w;
+                for (int64_t n = 0; n < out.n; ++n)
+                    for (int64_t p = 0; p < hw; ++p)
+                        for (int c = 0; c < out.c; ++c)
+                            out.p[(n * hw + p) * out.ld + c] = c < in.c ? in.p[(n * in.c + c) * hw + p] : 0.0f;
+                break;
+            }
+            case CSM_OP_NHWC_TO_NCHW: {
+                int64_t hw = (int64_t)in.h * in.w;
+                for (int64_t n = 0; n < in.n; ++n)
+                    for (int c = 0; c < in.c; ++c)
+                        for (int64_t p = 0; p < hw; ++p) out.p[(n * in.c + c) * hw + p] = in.p[(n * hw + p) * in.ld + c];
+                break;
+            }
+            default: fprintf(stderr, "orc_run_program: unknown op kind %d\n", op->kind); return 1;
+        }
+    }
+    return 0;
+}
+
+size_t orc_sizeof_op(void) { return sizeof(csm_op); }
+size_t orc_sizeof_tensor(void) { return sizeof(csm_tensor_desc); }
