@@ -36,6 +36,7 @@ def load():
         _lib.csm_build_info.restype = ctypes.c_char_p
         _lib.csm_warp_frame_scratch_floats.restype = ctypes.c_size_t
         _lib.csm_fill_disocclusion_scratch_bytes.restype = ctypes.c_size_t
+        _lib.csm_nms_scratch_bytes.restype = ctypes.c_size_t
     return _lib
 
 

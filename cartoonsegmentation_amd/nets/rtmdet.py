@@ -1,0 +1,194 @@
+"""RTMDet-Ins-L (CSPNeXt-L backbone + CSPNeXtPAFPN + RTMDetInsSepBNHead) -> layer program.
+
+The reference builds this model through the mmdet registry from the cfg string stored in the checkpoint
+(animeinsseg/__init__.py:196-210); mmdet 3.3.0 / mmcv 2.1.0 are NOT under /root/reference, so
+this file restates the mmdet 3.3.0 modules from their published definitions -- PARITY UNPINNED:
+  mmdet/models/backbones/cspnext.py (CSPNeXt, arch P5), backbones/csp_darknet.py (SPPBottleneck),
+  layers/csp_layer.py (CSPLayer, CSPNeXtBlock, ChannelAttention), necks/cspnext_pafpn.py,
+  dense_heads/rtmdet_ins_head.py (RTMDetInsSepBNHead, MaskFeatModule).
+The head consumed by the reference's own subclass is pinned where it is vendored:
+animeinsseg/models/rtmdet_inshead_custom.py:253-303 (dynamic-conv mask head, see maskhead.hip).
+
+The architecture is config-driven (RTMDetConfig); defaults = rtmdet-ins_l with num_classes=1.
+Parameter names follow mmdet's state_dict so a real rtmdetl_e60.ckpt imports unchanged.
+"""
+from dataclasses import dataclass, field
+from typing import Tuple
+
+from ..program import Program
+from ..weights import conv_bn, conv_plain
+
+
+@dataclass
+class RTMDetConfig:
+    deepen_factor: float = 1.0
+    widen_factor: float = 1.0
+    expand_ratio: float = 0.5
+    num_classes: int = 1
+    feat_channels: int = 256
+    stacked_convs: int = 2
+    num_prototypes: int = 8
+    dyconv_channels: int = 8
+    num_dyconvs: int = 3
+    strides: Tuple[int, ...] = (8, 16, 32)
+    share_conv: bool = True
+    bn_eps: float = 1e-5
+    # DetDataPreprocessor (BGR kept: bgr_to_rgb=False)
+    mean: Tuple[float, ...] = (103.53, 116.28, 123.675)
+    std: Tuple[float, ...] = (57.375, 57.12, 58.395)
+    pad_value: int = 114
+    # test_cfg
+    nms_pre: int = 1000
+    score_thr: float = 0.05
+    nms_iou: float = 0.6
+    max_per_img: int = 100
+    mask_thr_binary: float = 0.5
+    min_bbox_size: float = 0.0
+    arch: tuple = field(default_factory=lambda: ((64, 128, 3, True, False), (128, 256, 6, True, False),
+                                                 (256, 512, 6, True, False), (512, 1024, 3, False, True)))
+
+    @property
+    def num_gen_params(self):
+        d, p = self.dyconv_channels, self.num_prototypes
+        return (p + 2) * d + d * d * (self.num_dyconvs - 2) + d + d * (self.num_dyconvs - 1) + 1
+
+
+class _B:
+    def __init__(self, p, ws, cfg):
+        self.p, self.ws, self.cfg = p, ws, cfg
+
+    def cm(self, name, x, cout, k, stride=1, act='silu', out=None, res=None, res_mode=0, wname=None):
+        """mmcv ConvModule: conv(bias=False) + BN + act"""
+        w, b = conv_bn(_Alias(self.ws, name, wname), name + '.conv', name + '.bn', cout, x.c, k, eps=self.cfg.bn_eps)
+        return self.p.conv(x, w, b, stride=stride, pad=k // 2, act=act, out=out, res=res, res_mode=res_mode)
+
+    def dwcm(self, name, x, k, act='silu'):
+        from ..program import fold_bn
+        ws, c = self.ws, x.c
+        w = ws.get(name + '.conv.weight', (c, 1, k, k), 'conv_w')
+        g = ws.get(name + '.bn.weight', (c,), 'bn_gamma'); be = ws.get(name + '.bn.bias', (c,), 'bn_beta')
+        m = ws.get(name + '.bn.running_mean', (c,), 'bn_mean'); v = ws.get(name + '.bn.running_var', (c,), 'bn_var')
+        wf, bf = fold_bn(w, None, g, be, m, v, self.cfg.bn_eps)
+        return self.p.dwconv(x, wf, bf, pad=k // 2, act=act)
+
+    def cspnext_block(self, name, x, add_identity, out=None):
+        t = self.cm(name + '.conv1', x, x.c, 3)
+        t = self.dwcm(name + '.conv2.depthwise_conv', t, 5)
+        return self.cm(name + '.conv2.pointwise_conv', t, x.c, 1, out=out, res=x if add_identity else None, res_mode=2)
+
+    def csp_layer(self, name, x, cout, num_blocks, add_identity, channel_attention, out=None):
+        p, mid = self.p, int(cout * self.cfg.expand_ratio)
+        F = p.buffer(x.n, x.h, x.w, 2 * mid)                    # cat((x_main, x_short), 1)
+        self.cm(name + '.short_conv', x, mid, 1, out=F.slice(mid, 2 * mid))
+        t = self.cm(name + '.main_conv', x, mid, 1, out=F.slice(0, mid) if num_blocks == 0 else None)
+        for i in range(num_blocks):
+            t = self.cspnext_block('%s.blocks.%d' % (name, i), t, add_identity, out=F.slice(0, mid) if i == num_blocks - 1 else None)
+        if channel_attention:
+            wfc, bfc = conv_plain(self.ws, name + '.attention.fc', 2 * mid, 2 * mid, 1)
+            s = p.conv(p.gavgpool(F), wfc, bfc, act='hsigmoid')
+            F = p.scale(F, s, out=F)
+        return self.cm(name + '.final_conv', F, cout, 1, out=out)
+
+    def spp(self, name, x, cout):
+        p, mid = self.p, x.c // 2
+        S = p.buffer(x.n, x.h, x.w, 4 * mid)
+        t = self.cm(name + '.conv1', x, mid, 1, out=S.slice(0, mid))
+        for i in range(1, 4):                                   # maxpool 5, 9 (=5o5), 13 (=5o5o5): exact for max
+            t = p.maxpool(t, 5, 1, 2, out=S.slice(i * mid, (i + 1) * mid))
+        return self.cm(name + '.conv2', S, cout, 1)
+
+
+class _Alias:
+    """share_conv: conv weights of level n alias level 0; BN stays per level"""
+    def __init__(self, ws, name, wname):
+        self.ws, self.name, self.wname = ws, name, wname
+
+    def get(self, n, shape, kind):
+        if self.wname is not None and kind == 'conv_w':
+            n = self.wname + n[len(self.name):]
+        return self.ws.get(n, shape, kind)
+
+
+class RTMDetProgram:
+    def __init__(self, prog, cfg, n, h, w, outs):
+        self.prog, self.cfg, self.n, self.h, self.w = prog, cfg, n, h, w
+        self.cls, self.reg, self.kern, self.mask_feat = outs
+
+    def example_ext(self, dev):
+        import torch
+        return [torch.randn(self.n, 3, self.h, self.w, device=dev)]
+
+
+def build_rtmdet(ws, n, h, w, cfg=None):
+    """ext tensor [0]: normalised input NCHW [n,3,h,w] (BGR, (x-mean)/std).  Outputs stay in the workspace
+    (NHWC): per level cls [n,hl,wl,nc] (sigmoid applied), reg [n,hl,wl,4] (already relu'd, NOT yet x stride), kernels
+    [n,hl,wl,169]; mask_feat [n,h/8,w/8,8].  returns (RTMDetProgram, cfg)"""
+    cfg = cfg or RTMDetConfig()
+    assert h % 32 == 0 and w % 32 == 0
+    p = Program("rtmdet")
+    B = _B(p, ws, cfg)
+    x_ext = p.ext_nchw(n, 3, h, w)
+    x = p.to_nhwc(x_ext)
+    wf = cfg.widen_factor
+    arch = [(int(a * wf), int(b * wf), max(round(c * cfg.deepen_factor), 1), d, e) for a, b, c, d, e in cfg.arch]
+    c3, c4, c5 = arch[1][1], arch[2][1], arch[3][1]
+    # neck concat buffers first, so backbone outputs land in place (cat([upsample_feat, feat_low], 1))
+    TD1 = p.buffer(n, h // 16, w // 16, 2 * c4)
+    TD0 = p.buffer(n, h // 8, w // 8, 2 * c3)
+    BU0 = p.buffer(n, h // 16, w // 16, 2 * c3)                 # cat([downsample_feat, feat_height], 1)
+    BU1 = p.buffer(n, h // 32, w // 32, 2 * c4)
+    oc = cfg.feat_channels
+    MF = p.buffer(n, h // 8, w // 8, 3 * oc)                    # MaskFeatModule fusion input
+
+    t = B.cm('backbone.stem.0', x, arch[0][0] // 2, 3, stride=2)
+    t = B.cm('backbone.stem.1', t, arch[0][0] // 2, 3)
+    t = B.cm('backbone.stem.2', t, arch[0][0], 3)
+    outs_to = {1: TD0.slice(c3, 2 * c3), 2: TD1.slice(c4, 2 * c4)}
+    feats = []
+    for i, (cin, cout, nb, add_id, use_spp) in enumerate(arch):
+        s = 'backbone.stage%d' % (i + 1)
+        t = B.cm(s + '.0', t, cout, 3, stride=2)
+        k = 1
+        if use_spp:
+            t = B.spp(s + '.1', t, cout); k = 2
+        t = B.csp_layer('%s.%d' % (s, k), t, cout, nb, add_id, True, out=outs_to.get(i))
+        feats.append(t)
+    C3, C4, C5 = feats[1], feats[2], feats[3]
+    nb = max(round(3 * cfg.deepen_factor), 1)
+    fh5 = B.cm('neck.reduce_layers.0', C5, c4, 1, out=BU1.slice(c4, 2 * c4))
+    p.nearest(fh5, 2, out=TD1.slice(0, c4))
+    inner1 = B.csp_layer('neck.top_down_blocks.0', TD1, c4, nb, False, False)
+    fh4 = B.cm('neck.reduce_layers.1', inner1, c3, 1, out=BU0.slice(c3, 2 * c3))
+    p.nearest(fh4, 2, out=TD0.slice(0, c3))
+    o0 = B.csp_layer('neck.top_down_blocks.1', TD0, c3, nb, False, False)
+    B.cm('neck.downsamples.0', o0, c3, 3, stride=2, out=BU0.slice(0, c3))
+    o1 = B.csp_layer('neck.bottom_up_blocks.0', BU0, c4, nb, False, False)
+    B.cm('neck.downsamples.1', o1, c4, 3, stride=2, out=BU1.slice(0, c4))
+    o2 = B.csp_layer('neck.bottom_up_blocks.1', BU1, c5, nb, False, False)
+    P3 = B.cm('neck.out_convs.0', o0, oc, 3, out=MF.slice(0, oc))
+    P4 = B.cm('neck.out_convs.1', o1, oc, 3)
+    P5 = B.cm('neck.out_convs.2', o2, oc, 3)
+    # MaskFeatModule (rtmdet_ins_head.py): bilinear (align_corners=False) to P3 size, cat, 1x1 fuse, 4x conv, 1x1 proj
+    p.bilinear(P4, (P3.h, P3.w), out=MF.slice(oc, 2 * oc))
+    p.bilinear(P5, (P3.h, P3.w), out=MF.slice(2 * oc, 3 * oc))
+    H = 'bbox_head.'
+    wfu, bfu = conv_plain(ws, H + 'mask_head.fusion_conv', oc, 3 * oc, 1)
+    m = p.conv(MF, wfu, bfu)
+    for i in range(4):
+        m = B.cm('%smask_head.stacked_convs.%d' % (H, i), m, oc, 3)
+    wpj, bpj = conv_plain(ws, H + 'mask_head.projection', cfg.num_prototypes, oc, 1)
+    mask_feat = p.keep(p.conv(m, wpj, bpj))
+    cls, reg, kern = [], [], []
+    for lvl, f in enumerate((P3, P4, P5)):
+        def tower(kind, head, cout, act=None):
+            t_ = f
+            for i in range(cfg.stacked_convs):
+                nm = '%s%s.%d.%d' % (H, kind, lvl, i)
+                t_ = B.cm(nm, t_, oc, 3, wname=('%s%s.0.%d' % (H, kind, i)) if cfg.share_conv else None)
+            wh, bh = conv_plain(ws, '%s%s.%d' % (H, head, lvl), cout, oc, 1)
+            return p.keep(p.conv(t_, wh, bh, act=act))
+        cls.append(tower('cls_convs', 'rtm_cls', cfg.num_classes, act='sigmoid'))   # cls_score.sigmoid() fused
+        kern.append(tower('kernel_convs', 'rtm_kernel', cfg.num_gen_params))
+        reg.append(tower('reg_convs', 'rtm_reg', 4, act='relu'))          # F.relu(rtm_reg(.)) * stride  (x stride in decode)
+    p.plan()
+    return RTMDetProgram(p, cfg, n, h, w, (cls, reg, kern, mask_feat)), cfg

@@ -1,0 +1,296 @@
+"""AnimeInsSeg -- host-side mirror of animeinsseg/__init__.py::AnimeInsSeg (reference :185-708) on libcsm355.
+
+Same constructor / infer() signature and result type (AnimeInstances), so run_segmentation.ipynb drops in.
+Flow per image (reference :464-504, :447-462, :638-665), everything on the MI355X, masks never leave HBM:
+  uint8 image --csm_det_preprocess--> RTMDet-Ins layer program --decode (tiny torch index ops)--> csm_nms -->
+  csm_maskhead_logits --> csm_mask_resize_threshold --> [ISNet refine: csm_refine_prepare_batch --> ISNet layer
+  program --> csm_refine_threshold] --> AnimeInstances(masks bool [n,H,W], bboxes xywh int32, scores).
+The reference makes 5 host<->device crossings per image; here the only syncs are the data-dependent counts.
+
+Checkpoints: a real `rtmdetl_e60.ckpt` (mmdet state_dict + cfg text) and `refine_last.ckpt` import through
+StateDictWeights; `ckpt="synthetic"` uses closed-form weights (no checkpoint exists in this container).
+mmdet's pieces are restated from mmdet 3.3.0 (not vendored in the reference => parity unpinned).
+"""
+import ctypes
+import math
+import os
+from typing import List, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, f32, i32, ptr, stream_ptr
+from .anime_instances import AnimeInstances
+from .nets import RTMDetConfig, build_isnet, build_rtmdet
+from .runtime import CompiledProgram
+from .weights import StateDictWeights, SynthWeights
+
+VALID_REFINEMETHODS = {'refinenet_isnet', 'none'}
+
+
+def rescale_size(h, w, scale):
+    """mmcv.image.rescale_size for scale=(S,S): factor = min(long/max, short/min); int(x*f+0.5)"""
+    long_e, short_e = max(scale), min(scale)
+    f = min(long_e / max(h, w), short_e / min(h, w))
+    return int(h * float(f) + 0.5), int(w * float(f) + 0.5)
+
+
+def scaledown_size(h, w, max_size):
+    """utils/io_utils.py:254-274 scaledown_maxsize size rule (never upsamples)"""
+    r = max_size / max(h, w)
+    if r < 1:
+        if h > w:
+            h, w = max_size, max(1, int(round(w * r)))
+        else:
+            w, h = max_size, max(1, int(round(h * r)))
+    return h, w
+
+
+def _parse_mm_cfg(text):
+    """evaluate the mmengine config text stored in the checkpoint (animeinsseg/__init__.py:196-197) without
+    mmengine: it is plain Python made of literals and dict(...) calls."""
+    env = {'__builtins__': {}, 'dict': dict, 'list': list, 'tuple': tuple, 'True': True, 'False': False, 'None': None}
+    loc = {}
+    exec(text.replace('file_client_args', 'backend_args'), env, loc)   # noqa: S102 (checkpoint is as trusted as torch.load)
+    return loc
+
+
+def config_from_ckpt_cfg(cfg_text):
+    loc = _parse_mm_cfg(cfg_text)
+    m = loc['model']
+    c = RTMDetConfig()
+    bb, head = m.get('backbone', {}), m.get('bbox_head', {})
+    c.deepen_factor, c.widen_factor = bb.get('deepen_factor', 1.0), bb.get('widen_factor', 1.0)
+    c.num_classes = head.get('num_classes', 1)
+    c.feat_channels = head.get('feat_channels', 256)
+    c.stacked_convs = head.get('stacked_convs', 2)
+    dp = m.get('data_preprocessor', {})
+    c.mean, c.std = tuple(dp.get('mean', c.mean)), tuple(dp.get('std', c.std))
+    t = m.get('test_cfg', {})
+    c.nms_pre, c.score_thr = t.get('nms_pre', c.nms_pre), t.get('score_thr', c.score_thr)
+    c.nms_iou = t.get('nms', {}).get('iou_threshold', c.nms_iou)
+    c.max_per_img, c.mask_thr_binary = t.get('max_per_img', c.max_per_img), t.get('mask_thr_binary', c.mask_thr_binary)
+    c.min_bbox_size = t.get('min_bbox_size', c.min_bbox_size)
+    return c
+
+
+class AnimeInsSeg:
+    def __init__(self, ckpt: str, default_det_size: int = 640, device: str = None,
+                 refine_kwargs: dict = {'refine_method': 'refinenet_isnet'},
+                 tagger_path: str = 'models/wd-v1-4-swinv2-tagger-v2/model.onnx', mask_thr=0.3):
+        if device is None:
+            device = 'cuda'
+        if not torch.cuda.is_available():
+            raise _lib.CsmError("AnimeInsSeg needs an MI355X: libcsm355 has no CPU path")
+        _lib.load()
+        self.device = torch.device(device if device != 'cuda' else 'cuda:%d' % torch.cuda.current_device())
+        self.ckpt, self.default_det_size, self.mask_thr = ckpt, default_det_size, mask_thr
+        self.tagger, self.tagger_path = None, tagger_path
+        if ckpt is None or str(ckpt).startswith('synthetic'):
+            self.cfg, self._det_ws = RTMDetConfig(), SynthWeights('rtmdet.')
+        else:
+            blob = torch.load(ckpt, map_location='cpu', weights_only=False)
+            self.cfg = config_from_ckpt_cfg(blob['meta']['cfg'])
+            self._det_ws = StateDictWeights(blob['state_dict'])
+        self._det_programs, self._det_weights = {}, None
+        self._refine_programs, self._refine_weights, self._refine_ws = {}, None, None
+        self.refine_method = None
+        self.set_refine_method(**(refine_kwargs or {'refine_method': 'none'}))
+
+    # ---- configuration (reference :395-399, :623-636, :704-708) --------------------------------
+    def set_detect_size(self, det_size: Union[int, tuple]):
+        self.default_det_size = det_size if isinstance(det_size, int) else max(det_size)
+
+    def set_refine_method(self, refine_method: str = 'none', refine_size: int = 720, refinenet_ckpt: str = None, **kw):
+        if refine_method == 'animeseg':
+            raise NotImplementedError("refine_method 'animeseg' is out of the hot-path scope (SURVEY 2.1)")
+        if refine_method not in VALID_REFINEMETHODS:
+            raise NotImplementedError('Invalid refine method: %s' % refine_method)
+        self.refine_method, self.refine_size = refine_method, refine_size
+        if refine_method == 'refinenet_isnet' and self._refine_ws is None:
+            if refinenet_ckpt and os.path.exists(refinenet_ckpt):
+                sd = torch.load(refinenet_ckpt, map_location='cpu', weights_only=False)
+                sd = sd.get('state_dict', sd)
+                self._refine_ws = StateDictWeights({k.replace('net.', '', 1) if k.startswith('net.') else k: v for k, v in sd.items()})
+            else:
+                self._refine_ws = SynthWeights('isnet.')
+
+    def set_mask_threshold(self, mask_thr: float):
+        self.cfg.mask_thr_binary = mask_thr
+
+    def set_max_instance(self, num_ins):
+        self.cfg.max_per_img = num_ins
+
+    # ---- compiled programs ----------------------------------------------------------------------
+    def _detector(self, S):
+        if S not in self._det_programs:
+            rp, _ = build_rtmdet(self._det_ws, 1, S, S, self.cfg)
+            cp = CompiledProgram(rp.prog, self.device, weights=self._det_weights)
+            self._det_weights = cp.weights
+            self._det_programs[S] = (rp, cp)
+        return self._det_programs[S]
+
+    def _refiner(self, n, T):
+        if (n, T) not in self._refine_programs:
+            prog = build_isnet(self._refine_ws, n, T, T)
+            cp = CompiledProgram(prog, self.device, weights=self._refine_weights)
+            self._refine_weights = cp.weights
+            self._refine_programs[(n, T)] = cp
+        return self._refine_programs[(n, T)]
+
+    # ---- public entry (reference :401-445) --------------------------------------------------------
+    def infer(self, imgs, pred_score_thr: float = 0.3, refine_kwargs: dict = None, output_type: str = "tensor",
+              det_size: int = None, save_dir: str = '', save_visualization: bool = False, save_annotation: str = '',
+              infer_tags: bool = False, obj_id_start: int = -1, img_id_start: int = -1, verbose: bool = False,
+              infer_grey: bool = False, save_mask_only: bool = False, val_dir=None, max_instances: int = 100, **kw):
+        if det_size is not None:
+            self.set_detect_size(det_size)
+        if refine_kwargs is not None:
+            self.set_refine_method(**refine_kwargs)
+        self.set_max_instance(max_instances)
+        if save_annotation or save_visualization or infer_tags:
+            raise NotImplementedError("annotation export / tagging are outside the hot-path scope (SURVEY 2.1)")
+        assert output_type in {'tensor', 'numpy'}
+        return_list = isinstance(imgs, list)
+        if isinstance(imgs, str):
+            raise NotImplementedError("image decoding (mmcv.imread) is not part of the hot path: pass a uint8 BGR ndarray")
+        imgs = imgs if return_list else [imgs]
+        preds = []
+        for img in imgs:
+            inst = self._det_forward(img, pred_score_thr)
+            if self.refine_method == 'refinenet_isnet':
+                self._postprocess_refine(inst, img, refine_size=self.refine_size)
+            if output_type == 'numpy':
+                inst.to_numpy()
+            preds.append(inst)
+        return preds if return_list else preds[0]
+
+    # ---- detector forward + post-process (reference :447-462 + mmdet predict_by_feat) ---------------
+    def _upload(self, img):
+        if isinstance(img, torch.Tensor):
+            t = img.to(self.device)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
+        assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3, "expected uint8 HxWx3 (BGR)"
+        return t.contiguous()
+
+    def detect_raw(self, img):
+        """returns dict with kept boxes/scores/kernels/priors (score-sorted, after NMS) + scale info"""
+        L, cfg = _lib.load(), self.cfg
+        img_d = self._upload(img)
+        H, W = int(img_d.shape[0]), int(img_d.shape[1])
+        S = self.default_det_size
+        rh, rw = rescale_size(H, W, (S, S))
+        w_scale, h_scale = rw / W, rh / H
+        rp, cp = self._detector(S)
+        x = torch.empty((1, 3, S, S), dtype=torch.float32, device=self.device)
+        mean = (ctypes.c_float * 3)(*cfg.mean); std = (ctypes.c_float * 3)(*cfg.std)
+        check(L.csm_det_preprocess(ptr(img_d), i32(H), i32(W), i32(rh), i32(rw), i32(S), i32(S), mean, std,
+                                   f32(cfg.pad_value), ptr(x), stream_ptr()), "det_preprocess")
+        cp.run(x)
+        scores_l, boxes_l, priors_l, kern_l, labels_l = [], [], [], [], []
+        for lvl, stride in enumerate(cfg.strides):
+            cls = cp.read_view(rp.cls[lvl]).reshape(-1, cfg.num_classes)          # sigmoid fused in rtm_cls epilogue
+            reg = cp.read_view(rp.reg[lvl]).reshape(-1, 4) * float(stride)        # F.relu(rtm_reg) * stride
+            ker = cp.read_view(rp.kern[lvl]).reshape(-1, cfg.num_gen_params)
+            hl, wl = rp.cls[lvl].h, rp.cls[lvl].w
+            ys, xs = torch.meshgrid(torch.arange(hl, device=self.device), torch.arange(wl, device=self.device), indexing='ij')
+            pri = torch.stack([xs.reshape(-1) * stride, ys.reshape(-1) * stride, torch.full_like(xs.reshape(-1), stride),
+                               torch.full_like(xs.reshape(-1), stride)], 1).float()
+            valid = cls > cfg.score_thr                                          # filter_scores_and_topk
+            sc = cls[valid]
+            idx = valid.nonzero()
+            k = min(cfg.nms_pre, idx.shape[0])
+            sc, order = sc.sort(descending=True, stable=True)
+            sc, idx = sc[:k], idx[order[:k]]
+            keep, lab = idx[:, 0], idx[:, 1]
+            scores_l.append(sc); labels_l.append(lab); boxes_l.append(reg[keep]); priors_l.append(pri[keep]); kern_l.append(ker[keep])
+        scores, labels = torch.cat(scores_l), torch.cat(labels_l)
+        dist, priors, kernels = torch.cat(boxes_l), torch.cat(priors_l), torch.cat(kern_l)
+        x1 = (priors[:, 0] - dist[:, 0]).clamp(0, rw); y1 = (priors[:, 1] - dist[:, 1]).clamp(0, rh)   # distance2bbox(max_shape)
+        x2 = (priors[:, 0] + dist[:, 2]).clamp(0, rw); y2 = (priors[:, 1] + dist[:, 3]).clamp(0, rh)
+        sf = torch.tensor([1 / w_scale, 1 / h_scale] * 2, dtype=torch.float32, device=self.device)       # rescale=True
+        boxes = torch.stack([x1, y1, x2, y2], 1) * sf
+        if cfg.min_bbox_size >= 0:
+            ok = ((boxes[:, 2] - boxes[:, 0]) > cfg.min_bbox_size) & ((boxes[:, 3] - boxes[:, 1]) > cfg.min_bbox_size)
+            if not bool(ok.all()):
+                scores, labels, boxes, priors, kernels = scores[ok], labels[ok], boxes[ok], priors[ok], kernels[ok]
+        n = int(scores.shape[0])
+        out = dict(H=H, W=W, S=S, rh=rh, rw=rw, w_scale=w_scale, h_scale=h_scale, rp=rp, cp=cp)
+        if n == 0:
+            out.update(n=0)
+            return out
+        scores, order = scores.sort(descending=True, stable=True)
+        scores, order = scores[:4096], order[:4096]
+        boxes, priors, kernels, labels = boxes[order].contiguous(), priors[order], kernels[order], labels[order]
+        n = int(scores.shape[0])
+        offs = None
+        if cfg.num_classes > 1:                                                  # batched_nms coordinate trick
+            offs = (labels.float() * (boxes.max() + 1)).contiguous()
+        keep = torch.empty(cfg.max_per_img, dtype=torch.int32, device=self.device)
+        nk = torch.zeros(1, dtype=torch.int32, device=self.device)
+        scratch = torch.empty(L.csm_nms_scratch_bytes(i32(n)), dtype=torch.uint8, device=self.device)
+        check(L.csm_nms(ptr(boxes), ptr(offs), i32(n), f32(cfg.nms_iou), i32(cfg.max_per_img), ptr(keep), ptr(nk),
+                        ptr(scratch), stream_ptr()), "nms")
+        kidx = keep[:int(nk.item())].long()
+        out.update(n=int(kidx.shape[0]), boxes=boxes[kidx], scores=scores[kidx], priors=priors[kidx].contiguous(),
+                   kernels=kernels[kidx].contiguous(), labels=labels[kidx])
+        return out
+
+    def _masks_from(self, d, sel=None):
+        """dynamic-conv mask head + resize + sigmoid + threshold -> uint8 [n,H,W] on device"""
+        L, cfg = _lib.load(), self.cfg
+        pri, ker = (d['priors'], d['kernels']) if sel is None else (d['priors'][sel].contiguous(), d['kernels'][sel].contiguous())
+        n = int(pri.shape[0])
+        mf_view = d['rp'].mask_feat
+        b = mf_view.buf
+        mf = d['cp'].workspace[b.offset:]
+        h, w = mf_view.h, mf_view.w
+        logits = torch.empty((n, h, w), dtype=torch.float32, device=self.device)
+        check(L.csm_maskhead_logits(ptr(mf), i32(b.c), i32(h), i32(w), i32(cfg.num_prototypes), i32(cfg.dyconv_channels),
+                                    ptr(ker), ptr(pri), i32(n), i32(cfg.strides[0]), ptr(logits), stream_ptr()), "maskhead")
+        up = cfg.strides[0]
+        # mmdet quirk kept: scale_factor = [1/w_scale, 1/h_scale] is applied as (height, width)
+        rh2 = math.ceil(h * up * (1 / d['w_scale'])); rw2 = math.ceil(w * up * (1 / d['h_scale']))
+        masks = torch.empty((n, d['H'], d['W']), dtype=torch.uint8, device=self.device)
+        check(L.csm_mask_resize_threshold(ptr(logits), i32(n), i32(h), i32(w), i32(up), i32(rh2), i32(rw2), i32(d['H']),
+                                          i32(d['W']), f32(cfg.mask_thr_binary), ptr(masks), stream_ptr()), "mask_resize")
+        return masks
+
+    def _det_forward(self, img, pred_score_thr: float = 0.3) -> AnimeInstances:
+        d = self.detect_raw(img)
+        if d['n'] == 0:
+            return AnimeInstances()
+        sel = (d['scores'] > pred_score_thr).nonzero()[:, 0]                       # reference :452
+        if sel.numel() < 1:
+            return AnimeInstances()
+        masks = self._masks_from(d, sel).bool()
+        bboxes = d['boxes'][sel].to(torch.int32)                                   # :458-459 xyxy -> xywh (truncation)
+        bboxes[:, 2:] -= bboxes[:, :2]
+        return AnimeInstances(masks, bboxes, d['scores'][sel])
+
+    # ---- ISNet refine (reference :638-665, :37-55) ---------------------------------------------------
+    def _postprocess_refine(self, instances: AnimeInstances, img, refine_size: int = 720, max_refine_batch: int = 4, **kw):
+        if instances.is_empty:
+            return
+        L = _lib.load()
+        img_d = self._upload(img)
+        H, W = int(img_d.shape[0]), int(img_d.shape[1])
+        was_numpy = instances.is_numpy
+        segs = (torch.from_numpy(instances.masks) if was_numpy else instances.masks).to(self.device).to(torch.uint8).contiguous()
+        n, T = int(segs.shape[0]), refine_size
+        rh, rw = scaledown_size(H, W, T)
+        out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
+        for k0 in range(0, n, max_refine_batch):
+            b = min(max_refine_batch, n - k0)
+            cp = self._refiner(b, T)
+            batch = torch.empty((b, 4, T, T), dtype=torch.float32, device=self.device)
+            check(L.csm_refine_prepare_batch(ptr(img_d), ptr(segs[k0:k0 + b]), i32(b), i32(H), i32(W), i32(rh), i32(rw), i32(T),
+                                             ptr(batch), stream_ptr()), "refine_prepare")
+            logits = torch.empty((b, 1, T, T), dtype=torch.float32, device=self.device)
+            cp.run(batch, logits)
+            check(L.csm_refine_threshold(ptr(logits), i32(b), i32(T), i32(T), i32(rh), i32(rw), i32(H), i32(W),
+                                         f32(self.mask_thr), ptr(out[k0:k0 + b]), stream_ptr()), "refine_threshold")
+        masks = out.bool()
+        instances.masks = masks.cpu().numpy() if was_numpy else masks

@@ -151,6 +151,47 @@ typedef struct csm_op {
 int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
                     const float *weights, float *workspace, void *const *ext, int n_ext, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Instance-segmentation post-processing
+ * ---------------------------------------------------------------------------------- */
+
+/* Greedy NMS, replaces mmcv.ops.batched_nms -> nms (C++/CUDA ext; call site: mmdet head, imported at
+ * animeinsseg/models/rtmdet_inshead_custom.py:10).  boxes [n,4] xyxy sorted by descending score;
+ * class_offsets [n] (label * (max_coord+1)) or NULL for class-agnostic / single class;
+ * suppress iff inter > iou_thr * (Sa + Sb - inter).  keep[<=max_keep] = indices in score order.  n <= 4096. */
+size_t csm_nms_scratch_bytes(int n);
+int csm_nms(const float *boxes, const float *class_offsets, int n, float iou_thr, int max_keep, int *keep,
+            int *n_keep, void *scratch, void *stream);
+
+/* RTMDetInsSepBNHeadCustom._mask_predict_by_feat_single   animeinsseg/models/rtmdet_inshead_custom.py:253-303
+ * mask_feat NHWC [h,w,num_prototypes] with channel pitch ld; kernels [n,169]; priors [n,4] = (x,y,stride,stride);
+ * logits [n,h,w]. */
+int csm_maskhead_logits(const float *mask_feat, int ld, int h, int w, int num_prototypes, int dyconv_channels,
+                        const float *kernels, const float *priors, int n, int feat_stride, float *logits,
+                        void *stream);
+
+/* mmdet _bbox_mask_post_process tail (mirrored at animeinsseg/__init__.py:361-370), fused:
+ * interpolate(scale_factor=up) -> interpolate(size=(rh,rw)) -> [..., :oh, :ow] -> sigmoid() > thr.
+ * masks: uint8 [n,oh,ow] (0/1). */
+int csm_mask_resize_threshold(const float *logits, int n, int h, int w, int up, int rh, int rw, int oh, int ow,
+                              float thr, uint8_t *masks, void *stream);
+
+/* prepare_refine_batch   animeinsseg/__init__.py:37-55 (+ utils/io_utils.py:254-292 resize_pad):
+ * img u8 HWC [H,W,3], masks u8 [n,H,W] -> batch fp32 NCHW [n,4,T,T]; (rh,rw) = keep-ratio size inside T x T. */
+int csm_refine_prepare_batch(const uint8_t *img_hwc, const uint8_t *masks, int n, int H, int W, int rh, int rw, int T,
+                             float *batch, void *stream);
+
+/* _postprocess_refine tail   animeinsseg/__init__.py:653-662:
+ * sigmoid -> crop [:crop_h,:crop_w] -> bilinear(align_corners=True) to (oh,ow) -> > thr ; masks u8 [n,oh,ow]. */
+int csm_refine_threshold(const float *logits, int n, int S_h, int S_w, int crop_h, int crop_w, int oh, int ow, float thr,
+                         uint8_t *masks, void *stream);
+
+/* Detector input: mmdet test pipeline Resize(keep_ratio) + Pad(pad_value) + DetDataPreprocessor normalise
+ * (call sites animeinsseg/__init__.py:63-76, :212-215, :395-399).  img u8 HWC [H,W,3] (BGR) -> fp32 NCHW
+ * [1,3,S_h,S_w]; (rh,rw) resized extent (host computes mmcv rescale_size); mean3/std3 are HOST pointers. */
+int csm_det_preprocess(const uint8_t *img_hwc, int H, int W, int rh, int rw, int S_h, int S_w, const float *mean3,
+                       const float *std3, float pad_value, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
