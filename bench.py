@@ -28,8 +28,8 @@ MFMA_F32_PEAK_TF = 157.3  # same guide: fp32-input MFMA dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--workload", default="auto", help="auto | warp | frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,8 +150,90 @@ class WarpWorkload(Workload):
                 "sample": "%d warp frames %dx%d, oracle/warp_oracle.c single thread" % (n, self.W, self.H)}
 
 
+class FrameWorkload(Workload):
+    """BASELINE.json configs[2] with the shipped yaml's nets: one 1024x1024 frame =
+    AnimeInsSeg.infer (RTMDet-Ins-L @det 640 + mask head + ISNet refine @720 on `instances` masks)
+    + LeReS depth @640 + depth adjustment + disparity->points + ONE Ken Burns warp (+ crop/resize to uint8)."""
+    name = "seg+depth+warp"
+    INSTANCES = 2
+
+    def __init__(self, size, rank, device):
+        os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"          # no checkpoints exist offline: closed-form weights
+        from cartoonsegmentation_amd import ops, synth
+        from cartoonsegmentation_amd.kenburns import KenBurnsConfig, KenBurnsPipeline
+        self.ops, self.H, self.W, self.device = ops, size, size, device
+        cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', det_size=640, depth_est_size=640, max_size=size,
+                             refine_crf=False, depth_field=False, focal=size / 2.0,
+                             mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 720})
+        self.pipe = KenBurnsPipeline(cfg, device=str(device))
+        self.img = torch.from_numpy(synth.image_u8(size, size, 1234 + rank)).to(device)
+        self.wf = ops.WarpFrame(size, size, device)
+        self.out = torch.empty((size, size, 3), dtype=torch.uint8, device=device)
+        self.n_inst = None
+
+    def step(self):
+        from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, f32, check
+        pipe = self.pipe
+        inst = pipe.animeinsseg.infer(self.img, pred_score_thr=0.3, max_instances=self.INSTANCES, det_size=640)
+        self.n_inst = len(inst)
+        kc = pipe.generate_kenburns_config(self.img, instances=inst)
+        W, H = kc['intWidth'], kc['intHeight']
+        d_from = kc['objDepthrange'][0]
+        shift = self.ops.shift_vector({'fltShiftU': 30.0, 'fltShiftV': -20.0, 'fltDepthFrom': d_from, 'fltDepthTo': d_from / 1.25}, kc)
+        frame, _ = self.wf(kc['tenInpaPoints'], kc.inpainted_img, kc['tenInpaDepth'], kc['fltFocal'], kc['fltBaseline'], shift)
+        pw, ph = int(0.97 * W), int(0.97 * H)
+        check(load().csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0), ptr(self.out),
+                                        stream_ptr()))
+        return self.out
+
+    def _programs(self):
+        a = self.pipe.animeinsseg
+        (rp, det), = a._det_programs.values()
+        items = [("rtmdet-ins-l@640", det, [torch.randn(1, 3, 640, 640, device=self.device)])]
+        for (n, T), cp in a._refine_programs.items():
+            items.append(("isnet n=%d@%d" % (n, T), cp, [torch.rand(n, 4, T, T, device=self.device), torch.empty(n, 1, T, T, device=self.device)]))
+        for (h, w), cp in self.pipe._leres.items():
+            items.append(("leres@%dx%d" % (w, h), cp, [torch.randn(1, 3, h, w, device=self.device), torch.empty(1, 1, h, w, device=self.device)]))
+        return items
+
+    def config(self, world):
+        return {"workload": "seg(RTMDet-Ins-L det640 + maskhead + ISNet refine@720, %d instances) + LeReS depth@640 + 1 warp, "
+                            "frame %dx%d" % (self.n_inst or self.INSTANCES, self.W, self.H),
+                "frames_per_gpu_step": 1, "parallelism": "frames sharded x%d (no data-path collective; uint8 frame gather)" % world,
+                "weights": "closed-form synthetic (no checkpoints offline)", "precision": "fp32 exact (v_mfma_f32_32x32x2_f32)"}
+
+    def roofline(self):
+        """dominant kernel = k_conv_mfma: algorithmic conv FLOPs / summed launch durations (HIP events per op)"""
+        tot_ms, tot_fl, per_net = 0.0, 0.0, {}
+        for name, cp, ext in self._programs():
+            cp.run(*ext)
+            ms = None
+            for _ in range(3):
+                m = cp.profile(*ext)
+                ms = m if ms is None else [min(a, b) for a, b in zip(ms, m)]
+            cms = sum(t for t, o in zip(ms, cp.prog.ops) if o['kind'] == 1)
+            per_net[name] = {"conv_ms": round(cms, 3), "all_ops_ms": round(sum(ms), 3), "gflop": round(cp.prog.flops / 1e9, 1),
+                             "conv_launches": sum(1 for o in cp.prog.ops if o['kind'] == 1)}
+            tot_ms += cms; tot_fl += cp.prog.flops
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        n_launch = sum(v["conv_launches"] for v in per_net.values())
+        return {"bound": "mfma", "kernel": "k_conv_mfma (fp32 implicit GEMM, all conv launches of one frame)",
+                "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
+                "traffic": load_traffic("k_conv_mfma"), "algorithmic_flops_per_frame": tot_fl,
+                "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_frame": n_launch, "per_net": per_net}
+
+    def extra(self):
+        return {}
+
+    def cpu_baseline(self, seconds):
+        from oracle import frame as oframe
+        return oframe.cpu_baseline(seconds)
+
+
 def make_workload(kind, size, rank, device, world, dist):
-    if kind in ("auto", "warp"):
+    if kind in ("auto", "frame"):
+        wl = FrameWorkload(size, rank, device)
+    elif kind == "warp":
         wl = WarpWorkload(size, rank, device)
     else:
         raise SystemExit("unknown workload %r" % kind)

@@ -1,0 +1,146 @@
+// imageops.hip -- uint8 image plumbing around the nets, restated from OpenCV 4.10 semantics [EXT: cv2 is not under
+// /root/reference and not installed here => parity unpinned for these resamplers]:
+//   * LeReS input : scaledown_maxsize (cv2 INTER_LINEAR u8) -> /255 -> BGR->RGB -> ToTensor+Normalize
+//                   (kenburns_effect.py:563-571, depth_modules/leres/leres/depthmap.py:16-38)
+//   * LeReS output: min-max -> uint16 -> convertScaleAbs -> bitwise_not (depth_modules/leres/__init__.py:121-145),
+//                   then cv2.resize(INTER_AREA) back to the frame size and zero-fix (kenburns_effect.py:572-578)
+//   * frame tail  : cv2.getRectSubPix + cv2.resize(INTER_LINEAR) (kenburns_effect.py:1069-1070)
+#include "csm_common.h"
+
+namespace {
+
+__device__ __forceinline__ void cv_src(int d, int in_size, double scale, int &i0, int &i1, float &f) {
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.0f; sx = 0; }
+    if (sx >= in_size - 1) { fx = 0.0f; sx = in_size - 1; }
+    i0 = sx; i1 = min(sx + 1, in_size - 1); f = fx;
+}
+// INTER_AREA when up-sampling: linear taps with "area" fractions (resize.cpp, area_mode branch)
+__device__ __forceinline__ void cv_src_area(int d, int in_size, double scale, int &i0, int &i1, float &f) {
+    int sx = (int)floor(d * scale);
+    float fx = (float)((d + 1) - (sx + 1) * (1.0 / scale));
+    fx = fx <= 0.0f ? 0.0f : fx - floorf(fx);
+    if (sx < 0) { fx = 0.0f; sx = 0; }
+    if (sx >= in_size - 1) { fx = 0.0f; sx = in_size - 1; }
+    i0 = sx; i1 = min(sx + 1, in_size - 1); f = fx;
+}
+__device__ __forceinline__ int cv_lin_u8(int p00, int p01, int p10, int p11, float fx, float fy) {
+    const int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
+    const int b0 = (int)rintf((1.0f - fy) * 2048.0f), b1 = (int)rintf(fy * 2048.0f);
+    int r0 = p00 * a0 + p01 * a1, r1 = p10 * a0 + p11 * a1;
+    int q = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    return q < 0 ? 0 : (q > 255 ? 255 : q);
+}
+
+struct Norm3 { float mean[3], stdv[3]; };
+
+__global__ __launch_bounds__(256) void k_leres_input(const uint8_t *__restrict__ img, int H, int W, int h, int w, Norm3 nm,
+                                                      float *__restrict__ out) {
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const int64_t plane = (int64_t)h * w;
+    double sy = (double)H / h, sx = (double)W / w;
+    int y0 = y, y1 = y, x0 = x, x1 = x; float fy = 0.0f, fx = 0.0f;
+    const bool same = (h == H && w == W);
+    if (!same) { cv_src(y, H, sy, y0, y1, fy); cv_src(x, W, sx, x0, x1, fx); }
+    for (int c = 0; c < 3; ++c) {      // output channel c = RGB <- BGR channel 2-c
+        int sc = 2 - c;
+        int q = same ? img[((int64_t)y * W + x) * 3 + sc]
+                     : cv_lin_u8(img[((int64_t)y0 * W + x0) * 3 + sc], img[((int64_t)y0 * W + x1) * 3 + sc],
+                                 img[((int64_t)y1 * W + x0) * 3 + sc], img[((int64_t)y1 * W + x1) * 3 + sc], fx, fy);
+        float v = (float)q / 255.0f;
+        out[c * plane + (int64_t)y * w + x] = (v - nm.mean[c]) / nm.stdv[c];
+    }
+}
+
+// depth fp32 [h,w] -> u8: 65535*(d-min)/(max-min) -> uint16 (trunc) -> cvRound(x*255/65535) -> 255 - v
+__global__ __launch_bounds__(256) void k_leres_quantize(const float *__restrict__ d, int64_t n, const float *__restrict__ mnmx,
+                                                         uint8_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float mn = mnmx[0], mx = mnmx[1];
+    float o = 0.0f;
+    if ((double)(mx - mn) > 2.220446049250313e-16) o = 65535.0f * (d[i] - mn) / (mx - mn);
+    uint16_t u16 = (uint16_t)o;
+    float s = (float)u16 * (float)(255.0 / 65535.0);
+    int v = (int)rintf(fabsf(s));
+    v = v > 255 ? 255 : v;
+    out[i] = (uint8_t)(255 - v);
+}
+
+// u8 [h,w] -> fp32 [H,W] with cv2.resize: INTER_AREA when enlarging (linear taps, area fractions), identity if same size
+__global__ __launch_bounds__(256) void k_resize_u8_to_f32(const uint8_t *__restrict__ src, int h, int w, int H, int W,
+                                                           float *__restrict__ out) {
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    int q;
+    if (h == H && w == W) q = src[(int64_t)y * w + x];
+    else {
+        int y0, y1, x0, x1; float fy, fx;
+        cv_src_area(y, h, (double)h / H, y0, y1, fy); cv_src_area(x, w, (double)w / W, x0, x1, fx);
+        q = cv_lin_u8(src[(int64_t)y0 * w + x0], src[(int64_t)y0 * w + x1], src[(int64_t)y1 * w + x0], src[(int64_t)y1 * w + x1], fx, fy);
+    }
+    out[(int64_t)y * W + x] = (float)q;
+}
+
+// cv2.getRectSubPix(frame, (pw,ph), center) followed by cv2.resize(..., (W,H), INTER_LINEAR); u8 HWC 3 channels.
+// getRectSubPix (8u): bilinear at constant sub-pixel offset, float weights, cvRound (imgwarp: getRectSubPix_8u32f + convert)
+__device__ __forceinline__ int subpix(const uint8_t *__restrict__ f, int H, int W, int c, int px, int py, int ix, int iy, float a,
+                                      float b) {
+    int x0 = ix + px, y0 = iy + py;
+    auto at = [&](int yy, int xx) { yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                                    return (float)f[((int64_t)yy * W + xx) * 3 + c]; };
+    float a11 = (1.0f - a) * (1.0f - b), a12 = a * (1.0f - b), a21 = (1.0f - a) * b, a22 = a * b;
+    float v = at(y0, x0) * a11 + at(y0, x0 + 1) * a12 + at(y0 + 1, x0) * a21 + at(y0 + 1, x0 + 1) * a22;
+    int q = (int)rintf(v);
+    return q < 0 ? 0 : (q > 255 ? 255 : q);
+}
+__global__ __launch_bounds__(256) void k_crop_resize(const uint8_t *__restrict__ frame, int H, int W, int ph, int pw,
+                                                      float cx, float cy, uint8_t *__restrict__ out) {
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    // patch origin (sub-pixel): center - (patch-1)/2
+    float ox = cx - (float)(pw - 1) * 0.5f, oy = cy - (float)(ph - 1) * 0.5f;
+    int ix = (int)floorf(ox), iy = (int)floorf(oy);
+    float a = ox - (float)ix, b = oy - (float)iy;
+    int y0 = y, y1 = y, x0 = x, x1 = x; float fy = 0.0f, fx = 0.0f;
+    const bool same = (ph == H && pw == W);
+    if (!same) { cv_src(y, ph, (double)ph / H, y0, y1, fy); cv_src(x, pw, (double)pw / W, x0, x1, fx); }
+    for (int c = 0; c < 3; ++c) {
+        int q = same ? subpix(frame, H, W, c, x, y, ix, iy, a, b)
+                     : cv_lin_u8(subpix(frame, H, W, c, x0, y0, ix, iy, a, b), subpix(frame, H, W, c, x1, y0, ix, iy, a, b),
+                                 subpix(frame, H, W, c, x0, y1, ix, iy, a, b), subpix(frame, H, W, c, x1, y1, ix, iy, a, b), fx, fy);
+        out[((int64_t)y * W + x) * 3 + c] = (uint8_t)q;
+    }
+}
+
+}  // namespace
+
+extern "C" int csm_leres_input(const uint8_t *img_hwc, int H, int W, int h, int w, float *out, void *stream) {
+    CSM_REQUIRE(img_hwc && out && H > 0 && W > 0 && h > 0 && w > 0);
+    Norm3 nm{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}};
+    k_leres_input<<<dim3(csm::cdiv(w, 256), h), 256, 0, (hipStream_t)stream>>>(img_hwc, H, W, h, w, nm, out);
+    return csm::check_launch("k_leres_input");
+}
+
+extern "C" int csm_leres_quantize(const float *depth, int64_t n, const float *min_max_dev, uint8_t *out, void *stream) {
+    CSM_REQUIRE(depth && min_max_dev && out && n > 0);
+    k_leres_quantize<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(depth, n, min_max_dev, out);
+    return csm::check_launch("k_leres_quantize");
+}
+
+extern "C" int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream) {
+    CSM_REQUIRE(src && out && h > 0 && w > 0 && H >= h && W >= w);
+    k_resize_u8_to_f32<<<dim3(csm::cdiv(W, 256), H), 256, 0, (hipStream_t)stream>>>(src, h, w, H, W, out);
+    return csm::check_launch("k_resize_u8_to_f32");
+}
+
+extern "C" int csm_crop_resize_u8(const uint8_t *frame_hwc, int H, int W, int patch_h, int patch_w, float center_x,
+                                  float center_y, uint8_t *out_hwc, void *stream) {
+    CSM_REQUIRE(frame_hwc && out_hwc && frame_hwc != out_hwc && H > 0 && W > 0 && patch_h > 0 && patch_w > 0);
+    k_crop_resize<<<dim3(csm::cdiv(W, 256), H), 256, 0, (hipStream_t)stream>>>(frame_hwc, H, W, patch_h, patch_w, center_x,
+                                                                                 center_y, out_hwc);
+    return csm::check_launch("k_crop_resize");
+}

@@ -17,6 +17,7 @@
 //     that the 3x3 halo re-reads of neighbouring tiles hit the same 4 MiB L2.
 // Numerical contract: see include/csm355.h (one fmaf chain per output, fixed K order).
 #include "csm_common.h"
+#include <vector>
 
 namespace {
 
@@ -374,10 +375,9 @@ static int make_view(const csm_tensor_desc *tensors, int n_tensors, int id, floa
     return CSM_OK;
 }
 
-extern "C" int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
-                               const float *weights, float *workspace, void *const *ext, int n_ext, void *stream) {
-    CSM_REQUIRE(ops && tensors && n_ops >= 0 && n_tensors > 0);
-    hipStream_t st = (hipStream_t)stream;
+static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors, const float *weights,
+                   float *workspace, void *const *ext, int n_ext, hipStream_t st, hipEvent_t *ev) {
+    if (ev) CSM_HIP(hipEventRecord(ev[0], st));
     for (int i = 0; i < n_ops; ++i) {
         const csm_op &op = ops[i];
         View in{}, in1{}, out{};
@@ -454,6 +454,32 @@ extern "C" int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_de
         }
         rc = csm::check_launch("program op");
         if (rc) { csm::set_error("op %d (kind %d) launch failed", i, op.kind); return rc; }
+        if (ev) CSM_HIP(hipEventRecord(ev[i + 1], st));
     }
     return CSM_OK;
+}
+
+extern "C" int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
+                               const float *weights, float *workspace, void *const *ext, int n_ext, void *stream) {
+    CSM_REQUIRE(ops && tensors && n_ops >= 0 && n_tensors > 0);
+    return run_ops(ops, n_ops, tensors, n_tensors, weights, workspace, ext, n_ext, (hipStream_t)stream, nullptr);
+}
+
+// Same as csm_run_program, but brackets every op with HIP events on `stream`, synchronises the stream and returns
+// the per-op durations (ms) in op_ms[n_ops].  Measurement aid for bench.py's roofline (not graph-capturable).
+extern "C" int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
+                                       const float *weights, float *workspace, void *const *ext, int n_ext, void *stream,
+                                       float *op_ms) {
+    CSM_REQUIRE(ops && tensors && op_ms && n_ops >= 0 && n_tensors > 0);
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(n_ops + 1);
+    for (auto &e : ev) CSM_HIP(hipEventCreate(&e));
+    int rc = run_ops(ops, n_ops, tensors, n_tensors, weights, workspace, ext, n_ext, st, ev.data());
+    if (rc == CSM_OK) {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { csm::set_error("profile sync: %s", hipGetErrorString(e)); rc = CSM_ERR_HIP; }
+        else for (int i = 0; i < n_ops; ++i) (void)hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]);
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
 }

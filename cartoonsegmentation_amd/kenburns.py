@@ -1,0 +1,347 @@
+"""KenBurnsPipeline -- host-side mirror of anime_3dkenburns/kenburns_effect.py (reference :207-1090) on libcsm355.
+
+Call surface kept: KenBurnsConfig (dataclass + dict-style aliases), KenBurnsPipeline(cfg, device)
+.generate_kenburns_config / .autozoom / .process_kenburns, npyframes2video; module-level operators live in
+cartoonsegmentation_amd.ops (render_pointcloud, fill_disocclusion, process_shift, ...).
+
+MI355X-first differences (results unchanged):
+  * LeReS runs as one layer program; its uint8 pre/post-processing stays on the device (imageops.hip);
+  * process_autozoom (common.py:86-142) evaluates the <=256 candidate shifts without a host sync per candidate:
+    coverage counts are accumulated on the device and read back once;
+  * the 75-frame loop (kenburns_effect.py:1015-1072) is the fused csm_warp_frame + csm_crop_resize_u8; frames are
+    copied to the host once at the end (the reference does a 12 MB D2H per frame).
+Out of scope this round (SURVEY 8f "next"): Inpaint GridNet (inpaint=True), bokeh depth-of-field, zoe/marigold depth.
+"""
+import math
+import os
+from copy import deepcopy
+from dataclasses import dataclass, field, fields
+from typing import Union
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check, f32, i32, i64, ptr, stream_ptr
+from .anime_instances import AnimeInstances
+from .nets import build_leres
+from .runtime import CompiledProgram
+from .segmentation import AnimeInsSeg, scaledown_size
+from .weights import StateDictWeights, SynthWeights
+
+_ALIASES = {'fltFocal': 'focal', 'fltBaseline': 'baseline', 'intWidth': 'int_width', 'intHeight': 'int_height',
+            'fltDispmin': 'disparity_min', 'fltDispmax': 'disparity_max', 'objDepthrange': 'depth_range',
+            'tenRawImage': 'tensor_raw_image', 'tenRawDisparity': 'raw_disparity', 'tenRawDepth': 'raw_depth',
+            'tenRawPoints': 'raw_point', 'tenRawUnaltered': 'raw_unaltered', 'tenInpaImage': 'inpainted_img',
+            'tenInpaDisparity': 'inpainted_disparity', 'tenInpaDepth': 'inpainted_depth', 'tenInpaPoints': 'inpainted_points'}
+
+
+def _synthetic_ok():
+    return os.environ.get('CSM_SYNTHETIC_WEIGHTS', '0') == '1'
+
+
+@dataclass
+class KenBurnsConfig:
+    """field names / defaults of the reference dataclass (kenburns_effect.py:207-290); yaml keys map 1:1"""
+    detector: str = 'animeinsseg'
+    det_ckpt: str = 'models/AnimeInstanceSegmentation/rtmdetl_e60.ckpt'
+    det_size: int = 640
+    scale_depth: bool = False
+    depth_field: bool = False
+    mask_refine_kwargs: dict = field(default_factory=dict)
+    marigold_kwargs: dict = field(default_factory=dict)
+    pred_score_thr: float = 0.3
+    depth_est: str = 'zoe'
+    depth_est_device: str = ''
+    depth_refinement: str = 'default'
+    depthest_use_medium: bool = False
+    inpaint_type: str = 'default'
+    num_frame: int = 75
+    playback: bool = True
+    auto_zoom: bool = True
+    focal: float = 1024 / 2.0
+    baseline: float = 40.0
+    dof_speed: float = 50.
+    depth_factor: int = 1
+    lightness_factor: int = 13
+    max_size: int = 720
+    int_height: int = 1024
+    int_width: int = 1024
+    default_depth_refine: bool = False
+    refine_crf: bool = True
+    depth_est_size: int = 640
+    sd_img2img_url: str = 'http://127.0.0.1:7860/sdapi/v1/img2img'
+    ldm_inpaint_options: dict = field(default_factory=dict)
+    ldm_inpaint_size: int = 0
+    instances: AnimeInstances = None
+    # run-time state (not constructor fields in the reference either)
+    disparity_min = 0
+    disparity_max = 0
+    depth_range = None
+    tensor_raw_image = None
+    original_img_nparray = None
+    raw_disparity = None
+    raw_depth = None
+    raw_point = None
+    raw_unaltered = None
+    inpainted_img = None
+    inpainted_disparity = None
+    inpainted_depth = None
+    inpainted_points = None
+    save_path = r''
+
+    def __getitem__(self, item):
+        return getattr(self, _ALIASES.get(item, item))
+
+    def __setitem__(self, item, value):
+        setattr(self, _ALIASES.get(item, item), value)
+
+    def copy(self):
+        return deepcopy(self)
+
+
+def build_kenburns_cfg(tgt_cfg: Union[str, dict]):
+    """kenburns_effect.py:369-374 (OmegaConf replaced by PyYAML: same keys)"""
+    if isinstance(tgt_cfg, str):
+        import yaml
+        with open(tgt_cfg) as f:
+            tgt_cfg = yaml.safe_load(f)
+    names = {f.name for f in fields(KenBurnsConfig) if f.init}
+    return KenBurnsConfig(**{k: v for k, v in dict(tgt_cfg).items() if k in names})
+
+
+def depth_adjustment_animesseg(instances, tenDisparity, tenImage, use_medium=False):
+    """kenburns_effect.py:39-91: flatten every instance to the disparity at the bottom 3% of its rows"""
+    assert tenDisparity.shape[0] == 1
+    masks = [] if instances.is_empty else [instances.masks[i].float() for i in range(instances.masks.shape[0])]
+    resized = tenDisparity.shape[2:] != tenImage.shape[2:]
+    adj = torch.nn.functional.interpolate(tenDisparity, size=tuple(tenImage.shape[2:]), mode='bilinear', align_corners=False) \
+        if resized else tenDisparity
+    for m in masks:
+        plane = adj * m
+        if plane.sum().item() == 0:
+            continue
+        if not use_medium:
+            cols, rows = (plane.sum([2], True) > 0.0).flatten().nonzero(), (plane.sum([3], True) > 0.0).flatten().nonzero()
+            top, bottom = rows[0].item(), rows[-1].item()
+            _ = cols[0].item(), cols[-1].item()
+            adj = ((1.0 - m) * adj) + (m * plane[:, :, int(round(top + (0.97 * (bottom - top)))):, :].max())
+        else:
+            adj[plane > 0] = adj[plane > 0].median()
+    if resized:
+        return torch.nn.functional.interpolate(adj, size=tuple(tenDisparity.shape[2:]), mode='bilinear', align_corners=False)
+    return adj
+
+
+class KenBurnsPipeline:
+    def __init__(self, cfg: Union[KenBurnsConfig, str, dict] = None, device: str = None) -> None:
+        if cfg is None:
+            cfg = KenBurnsConfig()
+        elif isinstance(cfg, (str, dict)):
+            cfg = build_kenburns_cfg(cfg)
+        elif not isinstance(cfg, KenBurnsConfig):
+            raise NotImplementedError
+        self.cfg = cfg
+        if not torch.cuda.is_available():
+            raise _lib.CsmError("KenBurnsPipeline needs an MI355X: libcsm355 has no CPU path")
+        self.device = torch.device('cuda:%d' % torch.cuda.current_device()) if device in (None, 'cuda') else torch.device(device)
+        self.animeinsseg = None
+        self._leres, self._leres_weights, self._leres_ws = {}, None, None
+        self.set_detector(cfg.detector)
+        self.set_depth_estimation(cfg.depth_est)
+        self.set_inpainting(cfg.inpaint_type)
+
+    # ---- component selection (kenburns_effect.py:425-440, :514-546) ---------------------------------
+    def set_detector(self, detector: str):
+        if detector != 'animeinsseg':
+            raise NotImplementedError("detector %r: only 'animeinsseg' is on the hot path" % detector)
+        if self.animeinsseg is None:
+            ckpt = self.cfg.det_ckpt
+            if not os.path.exists(ckpt):
+                if not _synthetic_ok() and not str(ckpt).startswith('synthetic'):
+                    raise FileNotFoundError("%s (set det_ckpt='synthetic' or CSM_SYNTHETIC_WEIGHTS=1 for closed-form weights)" % ckpt)
+                ckpt = 'synthetic'
+            self.animeinsseg = AnimeInsSeg(ckpt, default_det_size=self.cfg.det_size, device=str(self.device),
+                                           refine_kwargs=self.cfg.mask_refine_kwargs or {'refine_method': 'refinenet_isnet'})
+
+    def set_depth_estimation(self, depth_est: str):
+        if depth_est != 'leres':
+            raise NotImplementedError("depth_est %r: LeReS is the shipped default (configs/3dkenburns.yaml:39); zoe/marigold "
+                                      "need un-vendored sources (SURVEY F3/F4)" % depth_est)
+        if self._leres_ws is None:
+            p = os.environ.get('CSM_LERES_CKPT', 'models/leres/res101.pth')
+            if not os.path.exists(p) and not _synthetic_ok():
+                raise FileNotFoundError("%s (set CSM_SYNTHETIC_WEIGHTS=1 for closed-form weights)" % p)
+            if os.path.exists(p):
+                sd = torch.load(p, map_location='cpu', weights_only=False)['depth_model']
+                self._leres_ws = StateDictWeights({'depth_model.' + k.replace('module.', '', 1): v for k, v in sd.items()})
+            else:
+                self._leres_ws = SynthWeights('leres.')
+        self._depth_est = self._depth_est_leres
+
+    def set_inpainting(self, inpainting: str):
+        self.inpaint_type = inpainting
+
+    # ---- depth (kenburns_effect.py:563-581) ------------------------------------------------------------
+    def _leres_prog(self, h, w):
+        if (h, w) not in self._leres:
+            cp = CompiledProgram(build_leres(self._leres_ws, 1, h, w), self.device, weights=self._leres_weights)
+            self._leres_weights = cp.weights
+            self._leres[(h, w)] = cp
+        return self._leres[(h, w)]
+
+    def _depth_est_leres(self, img_tensor, img_d):
+        """img_d: uint8 BGR HWC device tensor -> 'depth' (inverse-depth like, 1..255) fp32 [1,1,H,W]"""
+        L = _lib.load()
+        H, W = int(img_d.shape[0]), int(img_d.shape[1])
+        h, w = scaledown_size(H, W, self.cfg.depth_est_size)
+        h, w = int(math.ceil(h / 32) * 32), int(math.ceil(w / 32) * 32)
+        if h > H or w > W:
+            raise NotImplementedError("LeReS map larger than the frame needs cv2 INTER_LANCZOS4 (not restated)")
+        x = torch.empty((1, 3, h, w), dtype=torch.float32, device=self.device)
+        check(L.csm_leres_input(ptr(img_d), i32(H), i32(W), i32(h), i32(w), ptr(x), stream_ptr()), "leres_input")
+        y = torch.empty((1, 1, h, w), dtype=torch.float32, device=self.device)
+        self._leres_prog(h, w).run(x, y)
+        mnmx = torch.stack([y.min(), y.max()])
+        q = torch.empty((h, w), dtype=torch.uint8, device=self.device)
+        check(L.csm_leres_quantize(ptr(y), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
+        depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
+        check(L.csm_resize_u8_to_f32(ptr(q), i32(h), i32(w), i32(H), i32(W), ptr(depth), stream_ptr()), "resize_u8")
+        pos = depth[depth > 0]
+        if pos.numel():
+            depth[depth == 0] = pos.min()
+        return depth
+
+    def run_instance_segmentation(self, img, scale_down_to_maxsize=True):
+        inst = self.animeinsseg.infer(img, pred_score_thr=self.cfg.pred_score_thr, output_type='tensor',
+                                      det_size=self.cfg.det_size)
+        return inst, img
+
+    def infer_disparity(self, img, instances=None, img_tensor=None, kcfg=None, **kw):
+        img_d = self.animeinsseg._upload(img)
+        if instances is None:
+            instances, _ = self.run_instance_segmentation(img, scale_down_to_maxsize=False)
+        if img_tensor is None:
+            img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+        disparity = self._depth_est(img_tensor, img_d)
+        disparity = depth_adjustment_animesseg(instances, disparity, img_tensor, self.cfg.depthest_use_medium)
+        if self.cfg.default_depth_refine or self.cfg.refine_crf:
+            raise NotImplementedError("depth refinement (Refine net / CRF) is off in the shipped yaml and not built yet")
+        return disparity
+
+    # ---- generate_kenburns_config (kenburns_effect.py:898-951) -----------------------------------------------
+    def generate_kenburns_config(self, img, instances: AnimeInstances = None, verbose: bool = False, savep=None):
+        if isinstance(img, str):
+            raise NotImplementedError("pass a uint8 BGR ndarray (image decoding is not on the hot path)")
+        with torch.no_grad():
+            if instances is None:
+                instances, _ = self.run_instance_segmentation(img, scale_down_to_maxsize=False)
+            H, W = img.shape[:2]
+            if scaledown_size(H, W, self.cfg.max_size) != (H, W):
+                raise NotImplementedError("max_size smaller than the image needs cv2.resize of the frame (not restated); "
+                                          "use max_size >= max(H, W)")
+            instances.resize(H, W)
+            self.cfg.int_height, self.cfg.int_width = H, W
+            img_d = self.animeinsseg._upload(img)
+            img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+            cfg = self.cfg.copy()
+            disparity = self.infer_disparity(img, instances, img_tensor, kcfg=cfg)
+            disparity = disparity / disparity.max() * self.cfg.baseline
+            depth, valid, pts, unaltered = ops.disparity_to_points(disparity, cfg.focal, cfg.baseline)
+            cfg['fltDispmin'], cfg['fltDispmax'] = disparity.min().item(), disparity.max().item()
+            crop = depth[0, 0, 128:-128, 128:-128]                      # cv2.minMaxLoc(depth[128:-128,128:-128])
+            amin, amax = int(crop.argmin().item()), int(crop.argmax().item())
+            cw = crop.shape[1]
+            cfg['objDepthrange'] = (float(crop.min().item()), float(crop.max().item()), (amin % cw, amin // cw), (amax % cw, amax // cw))
+            cfg['tenRawImage'], cfg['tenRawDisparity'], cfg['tenRawDepth'] = img_tensor, disparity, depth
+            cfg['tenRawPoints'], cfg['tenRawUnaltered'] = pts.view(1, 3, -1), unaltered.view(1, 3, -1)
+            cfg.inpainted_img = img_tensor.view(1, 3, -1)
+            cfg['tenInpaDisparity'], cfg['tenInpaDepth'] = disparity.view(1, 1, -1), depth.view(1, 1, -1)
+            cfg['tenInpaPoints'] = cfg['tenRawPoints']
+            cfg.instances, cfg.original_img_nparray = instances, img
+            return cfg
+
+    # ---- autozoom (kenburns_effect.py:953-977, common.py:86-142) ------------------------------------------------
+    def process_autozoom(self, objSettings, objCommon):
+        shift = objSettings['fltShift']
+        lin = np.linspace(-shift, shift, 16)
+        cw = objSettings['objFrom']['intCropWidth'] / objSettings['fltZoom']
+        ch = objSettings['objFrom']['intCropHeight'] / objSettings['fltZoom']
+        d_from = objCommon['objDepthrange'][0]
+        d_to = d_from * (cw / objSettings['objFrom']['intCropWidth'])
+        cu, cv = objSettings['objFrom']['fltCenterU'], objSettings['objFrom']['fltCenterV']
+        W, H = objCommon['intWidth'], objCommon['intHeight']
+        cands = []
+        for iu in range(16):
+            for iv in range(16):
+                su, sv = float(lin[iv]), float(lin[iu])        # npyShiftU[intU,intV] = lin[intV]; npyShiftV[intU,intV] = lin[intU]
+                if cu + su < cw / 2.0 or cu + su > W - (cw / 2.0) or cv + sv < ch / 2.0 or cv + sv > H - (ch / 2.0):
+                    continue
+                cands.append((su, sv))
+        counts = torch.zeros(max(len(cands), 1), device=self.device)
+        rgb = objCommon['tenRawImage'].view(1, 3, -1)
+        for k, (su, sv) in enumerate(cands):                   # no host sync inside the loop
+            pts, _ = ops.process_shift({'tenPoints': objCommon['tenRawPoints'], 'fltShiftU': su, 'fltShiftV': sv,
+                                        'fltDepthFrom': d_from, 'fltDepthTo': d_to}, objCommon)
+            _, existing = ops.render_pointcloud(pts, rgb, W, H, objCommon['fltFocal'], objCommon['fltBaseline'])
+            counts[k] = (existing > 0.0).float().sum()
+        best, bu, bv = 0.0, None, None
+        for k, c in enumerate(counts.tolist()[:len(cands)]):   # first strictly-better candidate wins, like the reference
+            if best < c:
+                best, (bu, bv) = c, cands[k]
+        return {'fltCenterU': cu + bu, 'fltCenterV': cv + bv,
+                'intCropWidth': int(round(objSettings['objFrom']['intCropWidth'] / objSettings['fltZoom'])),
+                'intCropHeight': int(round(objSettings['objFrom']['intCropHeight'] / objSettings['fltZoom']))}
+
+    def autozoom(self, cfg: KenBurnsConfig, verbose: bool = False, inpaint: bool = True):
+        with torch.no_grad():
+            objFrom = {'fltCenterU': cfg.int_width / 2.0, 'fltCenterV': cfg.int_height / 2.0,
+                       'intCropWidth': int(math.floor(0.97 * cfg.int_width)), 'intCropHeight': int(math.floor(0.97 * cfg.int_height))}
+            objTo = self.process_autozoom({'fltShift': 100.0, 'fltZoom': 1.25, 'objFrom': objFrom}, cfg)
+            frames, _ = self.process_kenburns({'fltSteps': np.linspace(0.0, 1.0, cfg.num_frame).tolist(), 'objFrom': objFrom,
+                                               'objTo': objTo, 'boolInpaint': True}, cfg, inpaint, verbose)
+            return frames
+
+    # ---- frame loop (kenburns_effect.py:979-1081) -----------------------------------------------------------------
+    def process_kenburns(self, objSettings, objCommon: KenBurnsConfig, inpaint: bool = True, verbose: bool = False,
+                         to_numpy: bool = True):
+        if inpaint:
+            raise NotImplementedError("point-cloud inpainting (Inpaint GridNet, SURVEY 8f rank 1) is not built yet: call with "
+                                      "inpaint=False")
+        if objCommon.depth_field:
+            raise NotImplementedError("bokeh depth-of-field (SURVEY 8f rank 2) is not built yet: set depth_field=False")
+        L = _lib.load()
+        with torch.no_grad():
+            W, H = objCommon['intWidth'], objCommon['intHeight']
+            oF, oT = objSettings['objFrom'], objSettings['objTo']
+            wf = ops.WarpFrame(H, W, self.device)
+            steps = objSettings['fltSteps']
+            out = torch.empty((len(steps), H, W, 3), dtype=torch.uint8, device=self.device)
+            pw, ph = max(oF['intCropWidth'], oT['intCropWidth']), max(oF['intCropHeight'], oT['intCropHeight'])
+            pts, rgb, dep = objCommon['tenInpaPoints'], objCommon.inpainted_img, objCommon['tenInpaDepth']
+            for k, fltStep in enumerate(steps):
+                fltFrom = 1.0 - fltStep
+                fltTo = 1.0 - fltFrom
+                su = ((fltFrom * oF['fltCenterU']) + (fltTo * oT['fltCenterU'])) - (W / 2.0)
+                sv = ((fltFrom * oF['fltCenterV']) + (fltTo * oT['fltCenterV'])) - (H / 2.0)
+                cwid = (fltFrom * oF['intCropWidth']) + (fltTo * oT['intCropWidth'])
+                d_from = objCommon['objDepthrange'][0]
+                d_to = d_from * (cwid / max(oF['intCropWidth'], oT['intCropWidth']))
+                shift = ops.shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, objCommon)
+                frame, _ = wf(pts, rgb, dep, objCommon['fltFocal'], objCommon['fltBaseline'], shift)
+                check(L.csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0),
+                                           ptr(out[k]), stream_ptr()), "crop_resize")
+            frames = [f for f in out.cpu().numpy()] if to_numpy else out
+            return [frames, objCommon]
+
+
+def npyframes2video(npy_frame_list, video_save_path: str, playback: bool = False):
+    """kenburns_effect.py:1086-1090 (BGR->RGB, optional ping-pong, 25 fps mp4 through moviepy)"""
+    sequence = [f[:, :, ::-1] for f in npy_frame_list]
+    if playback:
+        sequence += sequence[::-1][1:-1]
+    try:
+        import moviepy.editor
+    except ImportError as e:
+        raise RuntimeError("npyframes2video needs moviepy/ffmpeg (video encoding is outside the hot path)") from e
+    moviepy.editor.ImageSequenceClip(sequence=sequence, fps=25).write_videofile(video_save_path, preset="veryslow")

@@ -31,6 +31,17 @@ class CompiledProgram:
                                           ctypes.c_void_p(self.workspace.data_ptr()), self._ext, ctypes.c_int(self.n_ext),
                                           stream_ptr()), "run_program(%s)" % self.prog.name)
 
+    def profile(self, *ext_tensors):
+        """per-op durations in ms (HIP events on the launch stream); returns list aligned with prog.ops"""
+        for i, t in enumerate(ext_tensors):
+            self._ext[i] = t.data_ptr()
+        ms = (ctypes.c_float * len(self.ops))()
+        check(_lib.load().csm_run_program_profile(self.ops, ctypes.c_int(len(self.ops)), self.tensors,
+                                                  ctypes.c_int(len(self.tensors)), ctypes.c_void_p(self.weights.data_ptr()),
+                                                  ctypes.c_void_p(self.workspace.data_ptr()), self._ext, ctypes.c_int(self.n_ext),
+                                                  stream_ptr(), ms), "run_program_profile(%s)" % self.prog.name)
+        return list(ms)
+
     def read_view(self, t):
         """debug: copy a planned NHWC view out of the workspace as [n,h,w,c]"""
         b = t.buf

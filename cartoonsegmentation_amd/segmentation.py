@@ -109,7 +109,11 @@ class AnimeInsSeg:
             raise NotImplementedError('Invalid refine method: %s' % refine_method)
         self.refine_method, self.refine_size = refine_method, refine_size
         if refine_method == 'refinenet_isnet' and self._refine_ws is None:
-            if refinenet_ckpt and os.path.exists(refinenet_ckpt):
+            refinenet_ckpt = refinenet_ckpt or 'models/AnimeInstanceSegmentation/refine_last.ckpt'   # utils/constants.py:80
+            synthetic = str(self.ckpt).startswith('synthetic') or os.environ.get('CSM_SYNTHETIC_WEIGHTS', '0') == '1'
+            if not os.path.exists(refinenet_ckpt) and not synthetic:
+                raise FileNotFoundError(refinenet_ckpt)
+            if os.path.exists(refinenet_ckpt):
                 sd = torch.load(refinenet_ckpt, map_location='cpu', weights_only=False)
                 sd = sd.get('state_dict', sd)
                 self._refine_ws = StateDictWeights({k.replace('net.', '', 1) if k.startswith('net.') else k: v for k, v in sd.items()})

@@ -150,6 +150,10 @@ typedef struct csm_op {
  * ext[i] are device pointers of external (caller-owned) tensors. */
 int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
                     const float *weights, float *workspace, void *const *ext, int n_ext, void *stream);
+/* Measurement aid: same execution, each op bracketed by HIP events on `stream`; synchronises and returns ms per op. */
+int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
+                            const float *weights, float *workspace, void *const *ext, int n_ext, void *stream,
+                            float *op_ms);
 
 /* ------------------------------------------------------------------------------------
  * Instance-segmentation post-processing
@@ -191,6 +195,22 @@ int csm_refine_threshold(const float *logits, int n, int S_h, int S_w, int crop_
  * [1,3,S_h,S_w]; (rh,rw) resized extent (host computes mmcv rescale_size); mean3/std3 are HOST pointers. */
 int csm_det_preprocess(const uint8_t *img_hwc, int H, int W, int rh, int rw, int S_h, int S_w, const float *mean3,
                        const float *std3, float pad_value, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * uint8 image plumbing around the depth net and the frame loop (OpenCV semantics restated, [EXT])
+ * ---------------------------------------------------------------------------------- */
+
+/* kenburns_effect.py:563-571 + depth_modules/leres/leres/depthmap.py:16-38: BGR u8 HWC [H,W,3] -> cv2 INTER_LINEAR to
+ * (h,w) -> /255 -> RGB -> (x-mean)/std (ImageNet) -> fp32 NCHW [1,3,h,w] */
+int csm_leres_input(const uint8_t *img_hwc, int H, int W, int h, int w, float *out, void *stream);
+/* depth_modules/leres/__init__.py:121-145: min-max -> uint16 -> convertScaleAbs(255/65535) -> bitwise_not.
+ * min_max_dev: DEVICE pointer to {min, max} of depth. */
+int csm_leres_quantize(const float *depth, int64_t n, const float *min_max_dev, uint8_t *out, void *stream);
+/* kenburns_effect.py:572-575: cv2.resize(u8 depth, (W,H), INTER_AREA) (enlarging) -> float32 */
+int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream);
+/* kenburns_effect.py:1069-1070: cv2.getRectSubPix(frame,(patch_w,patch_h),center) + cv2.resize(INTER_LINEAR) to (W,H) */
+int csm_crop_resize_u8(const uint8_t *frame_hwc, int H, int W, int patch_h, int patch_w, float center_x, float center_y,
+                       uint8_t *out_hwc, void *stream);
 
 #ifdef __cplusplus
 }
