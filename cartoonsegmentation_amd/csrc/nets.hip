@@ -64,22 +64,35 @@ struct ConvArgs {
     int M;                             // n*ho*wo
     int ncb;                           // ceil(cin_g / 32)
     int m_tiles;
+    int ksplit;                        // >1: blockIdx.z = g*ksplit + s, raw partial sums go to `partial`
+    float *partial;                    // [M][ksplit*cout] (groups == 1 only)
 };
 
 constexpr int kLdsLd = 36;  // floats per LDS row: 32 + 4 pad (conflict-free b128 reads, see MI355X LDS notes)
 
-// Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
-template <int WM, int WN, int TN>
-__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
-    constexpr int BM = 32 * WM, BN = 32 * WN * TN;
-    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
-    static_assert(WM * WN == 4, "4 waves per block");
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// Implicit-GEMM convolution on the exact-fp32 matrix pipe.
+//   MT = 32: v_mfma_f32_32x32x2_f32, wave tile 32 x (32*TN); LDS rows hold 32 channels in natural order, a lane
+//            (i, h) reads float4 at channel 4h of each 8-block: MFMA t multiplies channels (t, 4+t).
+//   MT = 16: v_mfma_f32_16x16x4_f32, wave tile 16 x (16*TN) -- 4x more tiles for small feature maps, so that all
+//            1024 SIMDs get work.  LDS 8-blocks are stored permuted [0,2,4,6,1,3,5,7]; lane (i, g) reads float2 at
+//            position 2g: MFMA 1 multiplies channels (0,4,1,5), MFMA 2 (2,6,3,7).
+// Both give the contract's chain order 0,4,1,5,2,6,3,7 per 8-block, so they are bit-identical to each other.
+template <int MT, int WM, int WN, int TN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_mfma(ConvArgs a) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = MT * WM, BN = MT * WN * TN;
+    constexpr int A_IT = (BM * 8 + NT - 1) / NT, B_IT = (BN * 8 + NT - 1) / NT;
+    constexpr bool A_FULL = A_IT * NT == BM * 8, B_FULL = B_IT * NT == BN * 8;
+    constexpr int NACC = MT == 32 ? 16 : 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int kStage = (BM + BN) * kLdsLd;   // floats per pipeline stage: A rows then B rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lh = lane >> 5;
+    const int li = MT == 32 ? (lane & 31) : (lane & 15);
+    const int lh = MT == 32 ? (lane >> 5) : (lane >> 4);
 
     // XCD-aware M-tile remap (speed only): block b runs on XCD b%8; give each XCD a contiguous tile range.
     int mt;
@@ -88,117 +101,183 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
         const int q = nt >> 3, r = nt & 7, xcd = b & 7, loc = b >> 3;
         mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int m0 = mt * BM, n0 = blockIdx.y * BN, g = blockIdx.z;
+    const int m0 = mt * BM, n0 = blockIdx.y * BN;
+    const int g = blockIdx.z / a.ksplit, ks = blockIdx.z - g * a.ksplit;
     const int ho = a.out.h, wo = a.out.w;
     const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
 
-    // per-thread A rows (output pixels) -> input origin
-    int rn[A_IT], riy[A_IT], rix[A_IT]; bool rvalid[A_IT];
+    // Per-thread A rows (output pixels): base pointer of the receptive-field origin and a per-tap validity mask,
+    // computed once; the K loop then only adds block-uniform offsets (no integer divisions, ~2 VALU per load).
+    const float *rowp[A_IT]; unsigned long long vmask[A_IT];
+    const int c4 = (tid & 7) * 4;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        int row = (tid + 256 * it) >> 3;
+        int row = (tid + NT * it) >> 3;
         int m = m0 + row;
-        rvalid[it] = m < a.M;
-        int mm = rvalid[it] ? m : 0;
+        bool rv = m < a.M && (A_FULL || row < BM);
+        int mm = rv ? m : 0;
         int n = mm / (ho * wo), rem = mm - n * ho * wo;
         int oy = rem / wo, ox = rem - oy * wo;
-        rn[it] = n; riy[it] = oy * a.stride - a.pad; rix[it] = ox * a.stride - a.pad;
+        int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        rowp[it] = a.in.p + ((int64_t)(n * a.in.h + iy0) * a.in.w + ix0) * a.in.ld + cin_off + c4;
+        unsigned long long vm = 0ull;
+        if (rv)
+            for (int kh = 0; kh < a.kh; ++kh)
+                for (int kw = 0; kw < a.kw; ++kw) {
+                    int iy = iy0 + kh * a.dil, ix = ix0 + kw * a.dil;
+                    if (iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w) vm |= 1ull << (kh * a.kw + kw);
+                }
+        vmask[it] = vm;
     }
-    const int c4 = (tid & 7) * 4;
-    const int T = a.kh * a.kw * a.ncb;
-    const float *wbase = a.w + (int64_t)g * T * a.npad * 32;
+    const int Tall = a.kh * a.kw * a.ncb;
+    const int c_begin = (int)(((int64_t)ks * Tall) / a.ksplit), T = (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
+    // loader state = the NEXT chunk to fetch (block-uniform -> SGPRs)
+    int l_tap = c_begin / a.ncb, l_cb = c_begin - l_tap * a.ncb;
+    int l_kh = l_tap / a.kw, l_kw = l_tap - l_kh * a.kw;
+    const float *wp[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+        wp[it] = a.w + ((int64_t)g * Tall + c_begin) * a.npad * 32 + (int64_t)(n0 + ((tid + NT * it) >> 3)) * 32 + c4;
 
     float4 ra[A_IT], rb[B_IT];
-    auto gload = [&](int chunk) {
-        int tap = chunk / a.ncb, cb = chunk - tap * a.ncb;
-        int kh = tap / a.kw, kw = tap - kh * a.kw;
-        int c = cb * 32 + c4;
-        bool cv = c < a.cin_g;
+    auto gload = [&]() {
+        const int64_t toff = ((int64_t)l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32;
+        const bool cv = l_cb * 32 + c4 < a.cin_g;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int iy = riy[it] + kh * a.dil, ix = rix[it] + kw * a.dil;
-            bool v = rvalid[it] && cv && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
-            const float *p = a.in.p + ((int64_t)(rn[it] * a.in.h + iy) * a.in.w + ix) * a.in.ld + cin_off + c;
-            ra[it] = v ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bool v = cv && ((vmask[it] >> l_tap) & 1ull);
+            ra[it] = v ? *reinterpret_cast<const float4 *>(rowp[it] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            int row = (tid + 256 * it) >> 3;
-            bool v = n0 + row < a.npad;
-            const float *p = wbase + ((int64_t)chunk * a.npad + n0 + row) * 32 + c4;
-            rb[it] = v ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+            int row = (tid + NT * it) >> 3;
+            bool v = n0 + row < a.npad && (B_FULL || row < BN);
+            rb[it] = v ? *reinterpret_cast<const float4 *>(wp[it]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wp[it] += (int64_t)a.npad * 32;
+        }
+        if (++l_cb == a.ncb) { l_cb = 0; ++l_tap; if (++l_kw == a.kw) { l_kw = 0; ++l_kh; } }
+    };
+    auto put = [&](float *dst, float4 v) {
+        if (MT == 32) *reinterpret_cast<float4 *>(dst + c4) = v;
+        else {  // permuted 8-block [0,2,4,6,1,3,5,7]
+            float *b8 = dst + (c4 & ~7) + 2 * ((c4 >> 2) & 1);
+            *reinterpret_cast<float2 *>(b8) = make_float2(v.x, v.z);
+            *reinterpret_cast<float2 *>(b8 + 4) = make_float2(v.y, v.w);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            int row = (tid + 256 * it) >> 3;
-            *reinterpret_cast<float4 *>(lds + buf * kStage + row * kLdsLd + c4) = ra[it];
-        }
+        for (int it = 0; it < A_IT; ++it)
+            if (A_FULL || ((tid + NT * it) >> 3) < BM) put(lds + buf * kStage + ((tid + NT * it) >> 3) * kLdsLd, ra[it]);
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            int row = (tid + 256 * it) >> 3;
-            *reinterpret_cast<float4 *>(lds + buf * kStage + (BM + row) * kLdsLd + c4) = rb[it];
-        }
+        for (int it = 0; it < B_IT; ++it)
+            if (B_FULL || ((tid + NT * it) >> 3) < BN) put(lds + buf * kStage + (BM + ((tid + NT * it) >> 3)) * kLdsLd, rb[it]);
     };
 
     // accumulators start at the (folded-BN) bias
-    f32x16 acc[TN];
+    float acc[TN][NACC];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        int n = n0 + 32 * (TN * wn + tn) + li;
-        float b = (a.bias && n < a.cout_g) ? a.bias[cout_off + n] : 0.0f;
+        int n = n0 + MT * (TN * wn + tn) + li;
+        float b = (a.bias && ks == 0 && n < a.cout_g) ? a.bias[cout_off + n] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tn][r] = b;
+        for (int r = 0; r < NACC; ++r) acc[tn][r] = b;
     }
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int chunk = 0; chunk < T; ++chunk) {
-        const int buf = chunk & 1;
-        if (chunk + 1 < T) gload(chunk + 1);
-        int cb = chunk % a.ncb;
-        int rem = a.cin_g - cb * 32;
-        int nkb = rem >= 32 ? 4 : (rem + 7) >> 3;
-        const float *A = lds + buf * kStage + (32 * wm + li) * kLdsLd + 4 * lh;
-        const float *B = lds + buf * kStage + (BM + 32 * TN * wn + li) * kLdsLd + 4 * lh;
-        for (int kb = 0; kb < nkb; ++kb) {
+    auto kblock = [&](const float *A, const float *B, int kb) {
+        if (MT == 32) {
             float4 af = *reinterpret_cast<const float4 *>(A + kb * 8);
             float4 bf[TN];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<const float4 *>(B + tn * 32 * kLdsLd + kb * 8);
+            const float av[4] = {af.x, af.y, af.z, af.w};
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[tn].x, acc[tn], 0, 0, 0);
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[tn].y, acc[tn], 0, 0, 0);
+                for (int tn = 0; tn < TN; ++tn) {
+                    const float bv = t == 0 ? bf[tn].x : (t == 1 ? bf[tn].y : (t == 2 ? bf[tn].z : bf[tn].w));
+                    f32x16 c;
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[tn].z, acc[tn], 0, 0, 0);
+                    for (int r = 0; r < 16; ++r) c[r] = acc[tn][r];
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, c, 0, 0, 0);
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[tn].w, acc[tn], 0, 0, 0);
+                    for (int r = 0; r < 16; ++r) acc[tn][r] = c[r];
+                }
+        } else {
+            float2 af = *reinterpret_cast<const float2 *>(A + kb * 8);
+            float2 bf[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<const float2 *>(B + tn * 16 * kLdsLd + kb * 8);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    f32x4v c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[r] = acc[tn][r];
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(t == 0 ? af.x : af.y, t == 0 ? bf[tn].x : bf[tn].y, c, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tn][r] = c[r];
+                }
+        }
+    };
+
+    gload();
+    lstore(c_begin & 1);
+    __syncthreads();
+    int cb = c_begin % a.ncb;
+    for (int chunk = c_begin; chunk < T; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < T) gload();
+        int rem = a.cin_g - cb * 32;
+        if (++cb == a.ncb) cb = 0;
+        const float *A = lds + buf * kStage + (MT * wm + li) * kLdsLd + (MT == 32 ? 4 : 2) * lh;
+        const float *B = lds + buf * kStage + (BM + MT * TN * wn + li) * kLdsLd + (MT == 32 ? 4 : 2) * lh;
+        if (rem >= 32) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) kblock(A, B, kb);
+        } else {
+            int nkb = (rem + 7) >> 3;
+            for (int kb = 0; kb < nkb; ++kb) kblock(A, B, kb);
         }
         if (chunk + 1 < T) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue: lane holds column li (channel), rows (r&3)+8*(r>>2)+4*lh of the 32x32 tile
+    // epilogue.  MT=32: lane holds column li, rows (r&3)+8*(r>>2)+4*lh.  MT=16: column li, rows 4*lh + r.
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        int n = n0 + 32 * (TN * wn + tn) + li;
+        int n = n0 + MT * (TN * wn + tn) + li;
         if (n >= a.cout_g) continue;
         float slope = a.slope ? a.slope[cout_off + n] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            int m = m0 + 32 * wm + row;
+        for (int r = 0; r < NACC; ++r) {
+            int row = MT == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : 4 * lh + r;
+            int m = m0 + MT * wm + row;
             if (m >= a.M) continue;
             float v = acc[tn][r];
+            if (a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
             if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
             v = apply_act(v, a.act, slope);
             if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
             a.out.p[(int64_t)m * a.out.ld + cout_off + n] = v;
         }
     }
+}
+
+// split-K tail: v = ((p0 + p1) + p2) + ... in run order, then the usual epilogue
+__global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs a) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.M * a.cout_g) return;
+    int n = (int)(idx % a.cout_g); int64_t m = idx / a.cout_g;
+    const float *P = a.partial + m * a.ksplit * a.cout_g + n;
+    float v = P[0];
+    for (int s = 1; s < a.ksplit; ++s) v += P[(int64_t)s * a.cout_g];
+    float slope = a.slope ? a.slope[n] : 0.0f;
+    if (a.res_mode == 1) v += a.res.p[m * a.res.ld + n];
+    v = apply_act(v, a.act, slope);
+    if (a.res_mode == 2) v += a.res.p[m * a.res.ld + n];
+    a.out.p[m * a.out.ld + n] = v;
 }
 
 // depthwise conv (RTMDet CSPNeXt 5x5): lane = (pixel, 4 channels); weights [tap][C]; fmaf chain over taps
@@ -341,21 +420,53 @@ __global__ __launch_bounds__(256) void k_nhwc_to_nchw(View in, float *__restrict
     dst[idx] = in.p[(n * hw + p) * in.ld + c];
 }
 
-template <int WM, int WN, int TN>
+template <int MT, int WM, int WN, int TN>
 int launch_conv(const ConvArgs &a0, hipStream_t st) {
-    constexpr int BM = 32 * WM, BN = 32 * WN * TN;
+    constexpr int BM = MT * WM, BN = MT * WN * TN;
     ConvArgs a = a0;
     a.m_tiles = (a.M + BM - 1) / BM;
     size_t lds = (size_t)2 * (BM + BN) * kLdsLd * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_mfma<WM, WN, TN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_mfma<MT, WM, WN, TN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups);
-    k_conv_mfma<WM, WN, TN><<<grid, 256, lds, st>>>(a);
-    return csm::check_launch("k_conv_mfma");
+    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * a.ksplit);
+    k_conv_mfma<MT, WM, WN, TN><<<grid, 64 * WM * WN, lds, st>>>(a);
+    int rc = csm::check_launch("k_conv_mfma");
+    if (rc || a.ksplit <= 1) return rc;
+    k_splitk_reduce<<<(unsigned)(((int64_t)a.M * a.cout_g + 255) / 256), 256, 0, st>>>(a);
+    return csm::check_launch("k_splitk_reduce");
+}
+
+// ---- tile selection ---------------------------------------------------------------------------------------
+// cost model: a tile occupies WM*WN SIMD slots for (K/2)*TN*64 cycles (MT=32) or (K/4)*TN*32 cycles (MT=16),
+// divided by an empirical per-config efficiency; the chip has 256 CUs x 4 SIMDs.  Pick the cheapest config.
+// Measured on the three nets (tools/conv_bench.py --sweep, profiles/): occupancy beats register-tile reuse in this
+// two-stage pipeline, so the default is the 64x64 tile (4 blocks = 16 waves per CU); narrow outputs get narrow tiles.
+enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CFG_128x32 = 4, CFG_64x16 = 5, CFG_COUNT = 6 };
+static int g_force_cfg = -1;
+
+static int choose_cfg(int M, int N, int groups) {
+    (void)M; (void)groups;
+    if (g_force_cfg >= 0 && g_force_cfg < CFG_COUNT) return g_force_cfg;
+    if (N <= 16) return CFG_64x16;
+    if (N <= 32) return CFG_128x32;
+    // enough 128x128 tiles for >= 1 block of 8 waves per CU, twice over: the higher arithmetic intensity wins
+    if (N >= 128 && (int64_t)((M + 127) / 128) * ((N + 127) / 128) * groups >= 384) return CFG_128x128_8w;
+    return CFG_64x64;
+}
+
+static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
+    switch (cfg) {
+        case CFG_128x128_4w: return launch_conv<32, 4, 1, 4>(a, st);
+        case CFG_128x64: return launch_conv<32, 4, 1, 2>(a, st);
+        case CFG_128x128_8w: return launch_conv<32, 4, 2, 2>(a, st);
+        case CFG_128x32: return launch_conv<32, 4, 1, 1>(a, st);
+        case CFG_64x16: return launch_conv<16, 4, 1, 1>(a, st);
+        default: return launch_conv<32, 2, 2, 1>(a, st);
+    }
 }
 
 inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
@@ -394,15 +505,17 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 a.groups = op.groups; a.cin_g = op.cin_g; a.cout_g = op.cout_g; a.npad = (op.cout_g + 31) / 32 * 32;
                 a.act = op.act; a.res_mode = op.in1 >= 0 ? op.res_mode : 0;
                 a.M = out.n * out.h * out.w; a.ncb = (op.cin_g + 31) / 32;
+                a.ksplit = op.ksplit > 1 ? op.ksplit : 1; a.partial = nullptr;
+                if (a.ksplit > 1) {
+                    View sc{};
+                    if (op.groups != 1) { csm::set_error("op %d: ksplit needs groups == 1", i); return CSM_ERR_ARG; }
+                    rc = make_view(tensors, n_tensors, op.scratch, workspace, ext, n_ext, sc); if (rc) return rc;
+                    a.partial = sc.p;
+                }
                 if ((in.ld & 3) || (op.cin_g & 3) || (((uintptr_t)in.p) & 15)) {
                     csm::set_error("op %d: conv input must be 16-byte aligned with channels %% 4 == 0", i); return CSM_ERR_ARG;
                 }
-                // tile choice: wide N when there are many output channels, narrow M when the map is small
-                int64_t blocks128 = (int64_t)((a.M + 127) / 128) * ((op.cout_g + 63) / 64) * op.groups;
-                if (op.cout_g <= 32) rc = a.M >= 64 * 256 ? launch_conv<4, 1, 1>(a, st) : launch_conv<2, 2, 1>(a, st);
-                else if (blocks128 >= 256) rc = launch_conv<4, 1, 2>(a, st);
-                else if (a.M > 64) rc = launch_conv<2, 2, 1>(a, st);
-                else rc = launch_conv<1, 4, 1>(a, st);
+                rc = launch_conv_cfg(choose_cfg(a.M, op.cout_g, op.groups), a, st);
                 if (rc) return rc;
                 break;
             }
@@ -483,3 +596,6 @@ extern "C" int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_t
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
 }
+
+// debug / tuning knob: force a conv tile configuration (-1 = cost model).  Not part of the stable ABI.
+extern "C" int csm_debug_force_conv_cfg(int cfg) { g_force_cfg = cfg; return CSM_OK; }

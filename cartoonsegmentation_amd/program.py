@@ -27,7 +27,8 @@ class CsmOp(ctypes.Structure):
                 ("dil", ctypes.c_int32), ("groups", ctypes.c_int32), ("cin_g", ctypes.c_int32),
                 ("cout_g", ctypes.c_int32), ("act", ctypes.c_int32), ("res_mode", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64), ("aux_off", ctypes.c_int64),
-                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("ksplit", ctypes.c_int32), ("scratch", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 def fold_bn(w, b, gamma, beta, mean, var, eps):
@@ -131,10 +132,12 @@ class Program:
     def _emit(self, kind, in0, in1, out, **kw):
         op = dict(kind=kind, in0=in0.id, in1=-1 if in1 is None else in1.id, out=out.id, kh=0, kw=0, stride=1, pad=0,
                   dil=1, groups=1, cin_g=0, cout_g=0, act=0, res_mode=0, w_off=-1, b_off=-1, aux_off=-1, flags=0,
-                  nat=None)
+                  ksplit=1, scratch=-1, nat=None)
         op.update(kw)
         i = len(self.ops)
-        for t in (in0, in1, out):
+        scr = kw.get('scratch_view')
+        op.pop('scratch_view', None)
+        for t in (in0, in1, out, scr):
             if t is None:
                 continue
             b = t.buf
@@ -175,10 +178,25 @@ class Program:
             a_h, a_n = self._w(slope, slope)
         self.flops += 2 * x.n * ho * wo * cout * cin_g * kh * kw
         self.conv_bytes += 4 * (x.n * x.h * x.w * x.c + x.n * ho * wo * cout + w.size)
+        ksplit, scr = self.choose_ksplit(x.n * ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups), None
+        if ksplit > 1:
+            scr = self.buffer(x.n, ho, wo, ksplit * cout)
         return self._emit(OP_CONV, x, res, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, groups=sg, cin_g=cin_sg,
                           cout_g=cout_sg, act=ACT[act], res_mode=res_mode if res is not None else 0, w_off=w_h, b_off=b_h,
-                          aux_off=a_h, nat=dict(groups=groups, cin_g=cin_g, cout_g=cout // groups, w_off=w_n, b_off=b_n,
-                                                aux_off=a_n))
+                          aux_off=a_h, ksplit=ksplit, scratch=-1 if scr is None else scr.id, scratch_view=scr,
+                          nat=dict(groups=groups, cin_g=cin_g, cout_g=cout // groups, w_off=w_n, b_off=b_n, aux_off=a_n))
+
+    split_k = True
+
+    def choose_ksplit(self, M, N, T, groups):
+        """small feature maps: not enough 64x64 output tiles to fill 256 CUs -> cut K (part of the numerical contract)"""
+        if not self.split_k or groups != 1:
+            return 1
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        if tiles >= 768 or T < 8:
+            return 1
+        s = min(-(-1024 // tiles), T // 4, 16)
+        return s if s >= 2 else 1
 
     def dwconv(self, x, w, b=None, stride=1, pad=0, dil=1, act=None, out=None):
         """depthwise: w [c,1,kh,kw]"""
