@@ -1,0 +1,124 @@
+"""CPU oracle of the Ken Burns glue (TEST INFRASTRUCTURE ONLY): LeReS depth path, depth adjustment, point cloud
+set-up, autozoom search and the frame loop, restated in numpy over oracle/*.c -- independent of
+cartoonsegmentation_amd/kenburns.py.  References: anime_3dkenburns/kenburns_effect.py:39-91, :563-633, :898-1081,
+anime_3dkenburns/common.py:59-142, depth_modules/leres/__init__.py:69-147."""
+import ctypes
+import math
+
+import numpy as np
+
+from . import nets as onets, segment as oseg, warp as owarp
+
+ci, cf = ctypes.c_int, ctypes.c_float
+_p = oseg._p
+
+
+def leres_depth(img, leres_prog_for, depth_est_size):
+    """-> 'depth' (inverse-depth like) float32 [1,1,H,W]"""
+    L = oseg.lib()
+    H, W = img.shape[:2]
+    r = depth_est_size / max(H, W)
+    h, w = H, W
+    if r < 1:
+        if H > W:
+            h, w = depth_est_size, max(1, int(round(W * r)))
+        else:
+            w, h = depth_est_size, max(1, int(round(H * r)))
+    h, w = int(math.ceil(h / 32) * 32), int(math.ceil(w / 32) * 32)
+    x = np.empty((1, 3, h, w), np.float32)
+    L.orc_leres_input(_p(np.ascontiguousarray(img)), ci(H), ci(W), ci(h), ci(w), _p(x))
+    y = np.zeros((1, 1, h, w), np.float32)
+    onets.run_program(leres_prog_for(h, w), [x, y])
+    q = np.empty((h, w), np.uint8)
+    L.orc_leres_quantize(_p(y), ctypes.c_int64(h * w), cf(float(y.min())), cf(float(y.max())), _p(q))
+    depth = np.empty((1, 1, H, W), np.float32)
+    L.orc_resize_u8_to_f32(_p(q), ci(h), ci(w), ci(H), ci(W), _p(depth))
+    pos = depth[depth > 0]
+    if pos.size:
+        depth[depth == 0] = pos.min()
+    return depth, y, q
+
+
+def depth_adjustment(masks_bool, disparity):
+    adj = disparity.copy()
+    for m in masks_bool:
+        mf = m.astype(np.float32)[None, None]
+        plane = adj * mf
+        if float(plane.sum()) == 0:
+            continue
+        rows = np.nonzero(plane.sum(axis=3).reshape(-1) > 0.0)[0]
+        top, bottom = int(rows[0]), int(rows[-1])
+        r0 = int(round(top + (0.97 * (bottom - top))))
+        adj = ((np.float32(1.0) - mf) * adj) + (mf * plane[:, :, r0:, :].max())
+    return adj
+
+
+def kenburns_config(img, masks_bool, leres_prog_for, depth_est_size, focal, baseline):
+    disparity, _, _ = leres_depth(img, leres_prog_for, depth_est_size)
+    disparity = depth_adjustment(masks_bool, disparity)
+    disparity = (disparity / disparity.max() * np.float32(baseline)).astype(np.float32)
+    _, depth, valid, pts, unaltered = _points_from_normalised(disparity, focal, baseline)
+    crop = depth[0, 0, 128:-128, 128:-128]
+    amin = int(crop.argmin()); cw = crop.shape[1]
+    return dict(disparity=disparity, depth=depth, valid=valid, pts=pts.reshape(1, 3, -1), unaltered=unaltered.reshape(1, 3, -1),
+                depthrange=(float(crop.min()), float(crop.max()), (amin % cw, amin // cw)))
+
+
+def _points_from_normalised(disparity, focal, baseline):
+    """kenburns_effect.py:929-933 on an already normalised disparity (oracle C works on the raw map; redo in numpy/C parts)"""
+    H, W = disparity.shape[-2:]
+    fb = np.float32(focal * baseline)
+    depth = ((np.float32(1.0) / (disparity + np.float32(0.00001))) * fb).astype(np.float32)
+    nd = (disparity / disparity.max()).astype(np.float32)
+    lap = owarp.spatial_filter_laplacian(nd)
+    valid = (np.abs(lap) < np.float32(0.03)).astype(np.float32)
+    pts = owarp.depth_to_points((depth * valid).astype(np.float32), focal)
+    un = owarp.depth_to_points(depth, focal)
+    return None, depth, valid, pts, un
+
+
+def autozoom_target(kc, rgb, W, H, focal, baseline, shift=100.0, zoom=1.25):
+    """common.py:86-142"""
+    lin = np.linspace(-shift, shift, 16)
+    icw, ich = int(math.floor(0.97 * W)), int(math.floor(0.97 * H))
+    cw, ch = icw / zoom, ich / zoom
+    cu, cv = W / 2.0, H / 2.0
+    d_from = kc['depthrange'][0]
+    d_to = d_from * (cw / icw)
+    common = {'objDepthrange': kc['depthrange'], 'intWidth': W, 'intHeight': H, 'fltFocal': focal, 'fltBaseline': baseline}
+    best, bu, bv = 0.0, None, None
+    for iu in range(16):
+        for iv in range(16):
+            su, sv = float(lin[iv]), float(lin[iu])
+            if cu + su < cw / 2.0 or cu + su > W - (cw / 2.0) or cv + sv < ch / 2.0 or cv + sv > H - (ch / 2.0):
+                continue
+            s = owarp.shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, common)
+            ps = owarp.process_shift(kc['pts'], s)
+            _, existing = owarp.render_pointcloud(ps, rgb, W, H, focal, baseline, degrid_mode=1)
+            c = float((existing > 0.0).astype(np.float32).sum())
+            if best < c:
+                best, bu, bv = c, su, sv
+    return {'fltCenterU': cu + bu, 'fltCenterV': cv + bv, 'intCropWidth': int(round(icw / zoom)), 'intCropHeight': int(round(ich / zoom))}, \
+           {'fltCenterU': cu, 'fltCenterV': cv, 'intCropWidth': icw, 'intCropHeight': ich}
+
+
+def frames(kc, rgb, W, H, focal, baseline, objFrom, objTo, steps):
+    """kenburns_effect.py:1015-1072 without inpainting / bokeh"""
+    L = oseg.lib()
+    common = {'objDepthrange': kc['depthrange'], 'intWidth': W, 'intHeight': H, 'fltFocal': focal, 'fltBaseline': baseline}
+    rgbd = np.concatenate([rgb, kc['depth'].reshape(1, 1, -1)], 1)
+    pw, ph = max(objFrom['intCropWidth'], objTo['intCropWidth']), max(objFrom['intCropHeight'], objTo['intCropHeight'])
+    out = []
+    for st in steps:
+        f, t = 1.0 - st, 1.0 - (1.0 - st)
+        su = ((f * objFrom['fltCenterU']) + (t * objTo['fltCenterU'])) - (W / 2.0)
+        sv = ((f * objFrom['fltCenterV']) + (t * objTo['fltCenterV'])) - (H / 2.0)
+        cwid = (f * objFrom['intCropWidth']) + (t * objTo['intCropWidth'])
+        d_from = kc['depthrange'][0]
+        d_to = d_from * (cwid / max(objFrom['intCropWidth'], objTo['intCropWidth']))
+        s = owarp.shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, common)
+        _, _, fr = owarp.warp_frame(kc['pts'], rgbd, H, W, focal, baseline, s, degrid_mode=1)
+        o = np.empty_like(fr)
+        L.orc_crop_resize_u8(_p(np.ascontiguousarray(fr)), ci(H), ci(W), ci(ph), ci(pw), cf(W / 2.0), cf(H / 2.0), _p(o))
+        out.append(o)
+    return out

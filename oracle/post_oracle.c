@@ -212,3 +212,109 @@ void orc_det_preprocess(const uint8_t *img, int H, int W, int rh, int rw, int S_
             for (int c = 0; c < 3; ++c) out[c * plane + (int64_t)y * S_w + x] = (v[c] - mean[c]) / stdv[c];
         }
 }
+
+/* ---- image plumbing around LeReS and the frame tail (mirrors imageops.hip; OpenCV semantics restated [EXT]) ---- */
+static void cv_src_area(int d, int in_size, double scale, int *i0, int *i1, float *f)
+{
+    int sx = (int)floor(d * scale);
+    float fx = (float)((d + 1) - (sx + 1) * (1.0 / scale));
+    fx = fx <= 0.0f ? 0.0f : fx - floorf(fx);
+    if (sx < 0) { fx = 0.0f; sx = 0; }
+    if (sx >= in_size - 1) { fx = 0.0f; sx = in_size - 1; }
+    *i0 = sx; *i1 = sx + 1 < in_size - 1 ? sx + 1 : in_size - 1; *f = fx;
+}
+static int cv_lin_u8(int p00, int p01, int p10, int p11, float fx, float fy)
+{
+    int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
+    int b0 = (int)rintf((1.0f - fy) * 2048.0f), b1 = (int)rintf(fy * 2048.0f);
+    int r0 = p00 * a0 + p01 * a1, r1 = p10 * a0 + p11 * a1;
+    int q = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    return q < 0 ? 0 : (q > 255 ? 255 : q);
+}
+
+/* kenburns_effect.py:563-571 + leres/depthmap.py:16-38 */
+void orc_leres_input(const uint8_t *img, int H, int W, int h, int w, float *out)
+{
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    int64_t plane = (int64_t)h * w;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int y0 = y, y1 = y, x0 = x, x1 = x; float fy = 0.0f, fx = 0.0f;
+            int same = (h == H && w == W);
+            if (!same) { cv_src(y, H, (double)H / h, &y0, &y1, &fy); cv_src(x, W, (double)W / w, &x0, &x1, &fx); }
+            for (int c = 0; c < 3; ++c) {
+                int sc = 2 - c;
+                int q = same ? img[((int64_t)y * W + x) * 3 + sc]
+                             : cv_lin_u8(img[((int64_t)y0 * W + x0) * 3 + sc], img[((int64_t)y0 * W + x1) * 3 + sc],
+                                         img[((int64_t)y1 * W + x0) * 3 + sc], img[((int64_t)y1 * W + x1) * 3 + sc], fx, fy);
+                float v = (float)q / 255.0f;
+                out[c * plane + (int64_t)y * w + x] = (v - mean[c]) / stdv[c];
+            }
+        }
+}
+
+/* depth_modules/leres/__init__.py:121-145 */
+void orc_leres_quantize(const float *d, int64_t n, float mn, float mx, uint8_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float o = 0.0f;
+        if ((double)(mx - mn) > 2.220446049250313e-16) o = 65535.0f * (d[i] - mn) / (mx - mn);
+        uint16_t u16 = (uint16_t)o;
+        float s = (float)u16 * (float)(255.0 / 65535.0);
+        int v = (int)rintf(fabsf(s));
+        v = v > 255 ? 255 : v;
+        out[i] = (uint8_t)(255 - v);
+    }
+}
+
+/* kenburns_effect.py:572-575 (cv2.resize INTER_AREA, enlarging) */
+void orc_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out)
+{
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int q;
+            if (h == H && w == W) q = src[(int64_t)y * w + x];
+            else {
+                int y0, y1, x0, x1; float fy, fx;
+                cv_src_area(y, h, (double)h / H, &y0, &y1, &fy); cv_src_area(x, w, (double)w / W, &x0, &x1, &fx);
+                q = cv_lin_u8(src[(int64_t)y0 * w + x0], src[(int64_t)y0 * w + x1], src[(int64_t)y1 * w + x0], src[(int64_t)y1 * w + x1], fx, fy);
+            }
+            out[(int64_t)y * W + x] = (float)q;
+        }
+}
+
+static int subpix(const uint8_t *f, int H, int W, int c, int px, int py, int ix, int iy, float a, float b)
+{
+    int x0 = ix + px, y0 = iy + py;
+    float v[4]; int k = 0;
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            int yy = y0 + dy, xx = x0 + dx;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            v[k++] = (float)f[((int64_t)yy * W + xx) * 3 + c];
+        }
+    float a11 = (1.0f - a) * (1.0f - b), a12 = a * (1.0f - b), a21 = (1.0f - a) * b, a22 = a * b;
+    float r = v[0] * a11 + v[1] * a12 + v[2] * a21 + v[3] * a22;
+    int q = (int)rintf(r);
+    return q < 0 ? 0 : (q > 255 ? 255 : q);
+}
+
+/* kenburns_effect.py:1069-1070 */
+void orc_crop_resize_u8(const uint8_t *frame, int H, int W, int ph, int pw, float cx, float cy, uint8_t *out)
+{
+    float ox = cx - (float)(pw - 1) * 0.5f, oy = cy - (float)(ph - 1) * 0.5f;
+    int ix = (int)floorf(ox), iy = (int)floorf(oy);
+    float a = ox - (float)ix, b = oy - (float)iy;
+    int same = (ph == H && pw == W);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int y0 = y, y1 = y, x0 = x, x1 = x; float fy = 0.0f, fx = 0.0f;
+            if (!same) { cv_src(y, ph, (double)ph / H, &y0, &y1, &fy); cv_src(x, pw, (double)pw / W, &x0, &x1, &fx); }
+            for (int c = 0; c < 3; ++c) {
+                int q = same ? subpix(frame, H, W, c, x, y, ix, iy, a, b)
+                             : cv_lin_u8(subpix(frame, H, W, c, x0, y0, ix, iy, a, b), subpix(frame, H, W, c, x1, y0, ix, iy, a, b),
+                                         subpix(frame, H, W, c, x0, y1, ix, iy, a, b), subpix(frame, H, W, c, x1, y1, ix, iy, a, b), fx, fy);
+                out[((int64_t)y * W + x) * 3 + c] = (uint8_t)q;
+            }
+        }
+}

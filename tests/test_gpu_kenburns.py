@@ -1,0 +1,94 @@
+"""GPU parity of the KenBurnsPipeline glue (through the drop-in import surface) vs the numpy/C oracle."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pipe_and_cfg():
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd import synth
+    H, W = 320, 384
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', det_size=96, depth_est_size=96, max_size=512, refine_crf=False,
+                         depth_field=False, focal=W / 2.0, num_frame=3,
+                         mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 64})
+    pipe = KenBurnsPipeline(cfg)
+    img = synth.image_u8(H, W, 11)
+    inst = pipe.animeinsseg.infer(img, pred_score_thr=0.3, max_instances=2, det_size=96)
+    kc = pipe.generate_kenburns_config(img, instances=inst)
+    return pipe, kc, img, inst
+
+
+def test_image_ops_bit_exact():
+    import ctypes
+    from cartoonsegmentation_amd import _lib, synth
+    from cartoonsegmentation_amd._lib import check, f32, i32, i64, ptr, stream_ptr
+    from oracle import segment as oseg
+    L, O = _lib.load(), oseg.lib()
+    ci, cf = ctypes.c_int, ctypes.c_float
+    img = synth.image_u8(150, 200, 3)
+    d_img = torch.from_numpy(img).cuda()
+    x = torch.empty((1, 3, 96, 128), device='cuda'); xo = np.empty((1, 3, 96, 128), np.float32)
+    check(L.csm_leres_input(ptr(d_img), i32(150), i32(200), i32(96), i32(128), ptr(x), stream_ptr()))
+    O.orc_leres_input(oseg._p(img), ci(150), ci(200), ci(96), ci(128), oseg._p(xo))
+    assert np.array_equal(x.cpu().numpy(), xo)
+    d = np.random.default_rng(0).normal(0, 3, (96, 128)).astype(np.float32)
+    dd = torch.from_numpy(d).cuda(); mm = torch.stack([dd.min(), dd.max()])
+    q = torch.empty((96, 128), dtype=torch.uint8, device='cuda'); qo = np.empty((96, 128), np.uint8)
+    check(L.csm_leres_quantize(ptr(dd), i64(96 * 128), ptr(mm), ptr(q), stream_ptr()))
+    O.orc_leres_quantize(oseg._p(d), ctypes.c_int64(96 * 128), cf(float(d.min())), cf(float(d.max())), oseg._p(qo))
+    assert np.array_equal(q.cpu().numpy(), qo)
+    up = torch.empty((150, 200), device='cuda'); upo = np.empty((150, 200), np.float32)
+    check(L.csm_resize_u8_to_f32(ptr(q), i32(96), i32(128), i32(150), i32(200), ptr(up), stream_ptr()))
+    O.orc_resize_u8_to_f32(oseg._p(qo), ci(96), ci(128), ci(150), ci(200), oseg._p(upo))
+    assert np.array_equal(up.cpu().numpy(), upo)
+    cr = torch.empty((150, 200, 3), dtype=torch.uint8, device='cuda'); cro = np.empty((150, 200, 3), np.uint8)
+    check(L.csm_crop_resize_u8(ptr(d_img), i32(150), i32(200), i32(145), i32(194), f32(100.0), f32(75.0), ptr(cr), stream_ptr()))
+    O.orc_crop_resize_u8(oseg._p(img), ci(150), ci(200), ci(145), ci(194), cf(100.0), cf(75.0), oseg._p(cro))
+    assert np.array_equal(cr.cpu().numpy(), cro)
+
+
+def test_generate_kenburns_config_vs_oracle(pipe_and_cfg):
+    from cartoonsegmentation_amd.nets import build_leres
+    from cartoonsegmentation_amd.weights import SynthWeights
+    from oracle import kenburns as okb
+    pipe, kc, img, inst = pipe_and_cfg
+    assert kc['intWidth'] == 384 and kc['intHeight'] == 320 and kc['tenRawPoints'].shape == (1, 3, 320 * 384)
+    progs = {}
+
+    def leres_for(h, w):
+        if (h, w) not in progs:
+            progs[(h, w)] = build_leres(SynthWeights('leres.'), 1, h, w)
+        return progs[(h, w)]
+    masks = inst.masks.cpu().numpy()
+    o = okb.kenburns_config(img, masks, leres_for, 96, kc['fltFocal'], kc['fltBaseline'])
+    assert np.array_equal(kc['tenRawDisparity'].cpu().numpy(), o['disparity'])
+    assert np.array_equal(kc['tenRawDepth'].cpu().numpy(), o['depth'])
+    assert np.array_equal(kc['tenRawPoints'].cpu().numpy(), o['pts'])
+    assert np.array_equal(kc['tenRawUnaltered'].cpu().numpy(), o['unaltered'])
+    assert kc['objDepthrange'][0] == o['depthrange'][0] and tuple(kc['objDepthrange'][2]) == tuple(o['depthrange'][2])
+
+
+def test_autozoom_and_frames_vs_oracle(pipe_and_cfg):
+    from oracle import kenburns as okb
+    pipe, kc, img, inst = pipe_and_cfg
+    W, H = kc['intWidth'], kc['intHeight']
+    o = dict(depth=kc['tenRawDepth'].cpu().numpy(), pts=kc['tenRawPoints'].cpu().numpy(), depthrange=kc['objDepthrange'])
+    rgb = kc['tenRawImage'].view(1, 3, -1).cpu().numpy()
+    objTo_o, objFrom = okb.autozoom_target(o, rgb, W, H, kc['fltFocal'], kc['fltBaseline'])
+    objTo = pipe.process_autozoom({'fltShift': 100.0, 'fltZoom': 1.25, 'objFrom': objFrom}, kc)
+    assert objTo == objTo_o
+    steps = [0.0, 0.5, 1.0]
+    frames, _ = pipe.process_kenburns({'fltSteps': steps, 'objFrom': objFrom, 'objTo': objTo, 'boolInpaint': False}, kc, inpaint=False)
+    frames_o = okb.frames(o, rgb, W, H, kc['fltFocal'], kc['fltBaseline'], objFrom, objTo, steps)
+    assert len(frames) == 3 and frames[0].shape == (H, W, 3) and frames[0].dtype == np.uint8
+    for a, b in zip(frames, frames_o):
+        diff = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        assert (diff <= 1).mean() >= 0.999 and (diff == 0).mean() >= 0.99      # fp32 atomicAdd order only
+    with pytest.raises(NotImplementedError):
+        pipe.autozoom(kc)            # inpaint=True is SURVEY 8f rank 1 (not built yet) -- must fail loudly, not silently skip

@@ -1,27 +1,39 @@
 #!/bin/bash
-# usage: tools_profile.sh <tag> -- runs tests, bench, rocprofv3 stats + pmc passes; writes gpurun_out/<tag>/
+# usage: tools_profile.sh <tag> [quick] -- GPU validation + measurement pass; writes gpurun_out/<tag>/
 TAG=${1:-run}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
-python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log
-python bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > $OUT/bench.json; cat $OUT/bench.json
+python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $OUT/smoke.log
+python bench.py 2>/dev/null | tail -1 > $OUT/bench.json; cat $OUT/bench.json
+python bench.py --workload warp --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_warp.json; cat $OUT/bench_warp.json
+python tools/conv_bench.py --sweep 2>/dev/null > $OUT/conv_sweep.txt; tail -1 $OUT/conv_sweep.txt
+python tools/layer_profile.py 2>/dev/null > $OUT/layer_profile.txt; grep "^==" $OUT/layer_profile.txt
+[ "$2" = "quick" ] && exit 0
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o warp -- python /root/repo/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o warp -- python /root/repo/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o warp -- python /root/repo/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-find $OUT -name "*.csv" | head; 
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o frame -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_warp -o warp -- python /root/repo/bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_warp.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o frame -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmcw_$C -o warp -- python /root/repo/bench.py --workload warp --steps 20 --warmup 2 --no-cpu-baseline > $OUT/pmcw_$C.log 2>&1
+done
 python - <<PY
-import csv,glob,collections
-for f in glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True):
-    print(open(f).read()[:3000])
-for kind in ("fetch","write"):
-    agg=collections.defaultdict(lambda:[0,0.0])
-    for f in glob.glob("$OUT/pmc_%s/**/*counter_collection.csv"%kind, recursive=True):
-        for r in csv.DictReader(open(f)):
-            k=r["Kernel_Name"][:60]; agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
-    for k,(n,v) in sorted(agg.items(), key=lambda kv:-kv[1][1])[:12]:
-        print(kind, k, n, "avg_KB=%.1f"%(v/n))
+import csv,glob,collections,json
+out={}
+for f in glob.glob("$OUT/stats*/**/*kernel_stats.csv", recursive=True):
+    print(f); print("".join(open(f).readlines()[:14]))
+tr={}
+for kind,key in (("FETCH_SIZE","fetch_KB"),("WRITE_SIZE","write_KB")):
+    for pre in ("pmc_","pmcw_"):
+        agg=collections.defaultdict(lambda:[0,0.0])
+        for f in glob.glob("$OUT/%s%s/**/*counter_collection.csv"%(pre,kind), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k=r["Kernel_Name"]; k=k[k.find("k_"):][:24] if "k_" in k else k[:24]
+                agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
+        for k,(n,v) in agg.items():
+            tr.setdefault(k,{})[key]=round(v/n,1); tr[k]["launches_"+key]=n
+json.dump(tr, open("$OUT/pmc_summary.json","w"), indent=1)
+for k,v in sorted(tr.items(), key=lambda kv:-kv[1].get("fetch_KB",0))[:14]: print(k, v)
 PY
-# drop the big raw traces, keep summaries
-find $OUT -name "*kernel_trace.csv" -size +2M -delete
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +1M -delete
