@@ -100,7 +100,10 @@ class AnimeInstances:
         bboxes[:, ::2] *= hs
         bboxes[:, 1::2] *= ws
         self.bboxes = torch.round(bboxes).int()
-        self.masks = torch.nn.functional.interpolate(masks, (h, w), mode=mode).squeeze(1) > 0.3
+        if (oh, ow) == (h, w):        # identity resize: interpolate(area) of a 0/1 mask then > 0.3 returns the mask itself
+            self.masks = masks.squeeze(1) > 0.3
+        else:
+            self.masks = torch.nn.functional.interpolate(masks, (h, w), mode=mode).squeeze(1) > 0.3
 
     def compose_masks(self, output_type=None):
         if self.is_empty:

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void k_nms_scan(const unsigned long long *__res
                                                   int *__restrict__ keep, int *__restrict__ n_keep, int max_keep) {
     unsigned long long removed = 0ull;
     int lane = threadIdx.x, cnt = 0;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n && cnt < max_keep; ++i) {   // results[:max_per_img]: later boxes cannot change earlier keeps
         unsigned long long wv = __shfl(removed, i >> 6);
         bool dead = (wv >> (i & 63)) & 1ull;
         if (!dead) {

@@ -193,9 +193,9 @@ class Program:
         if not self.split_k or groups != 1:
             return 1
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        if tiles >= 768 or T < 8:
+        if tiles >= 256 or T < 8:      # >= 1 block per CU: the extra reduce launch (~6 us) costs more than it buys
             return 1
-        s = min(-(-1024 // tiles), T // 4, 16)
+        s = min(-(-768 // tiles), T // 4, 16)
         return s if s >= 2 else 1
 
     def dwconv(self, x, w, b=None, stride=1, pad=0, dil=1, act=None, out=None):
