@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_nearest(View in, View out) {
 }
 
 // out = act(a + b), or unary act / copy when b.p == nullptr
-__global__ __launch_bounds__(256) void k_eltwise(View a, View b, View out, int act, int mode) {
+__global__ __launch_bounds__(256) void k_eltwise(View a, View b, View out, int act, int mode, const float *__restrict__ slope) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = (int64_t)out.n * out.h * out.w * out.c;
     if (idx >= total) return;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_eltwise(View a, View b, View out, int a
     float v = a.p[pix * a.ld + c];
     if (mode == 1) v = v + b.p[pix * b.ld + c];
     else if (mode == 2) { int64_t n = pix / ((int64_t)out.h * out.w); v = v * b.p[n * b.ld + c]; }
-    out.p[pix * out.ld + c] = apply_act(v, act, 0.0f);
+    out.p[pix * out.ld + c] = apply_act(v, act, slope ? slope[c] : 0.0f);
 }
 
 // global average pool with a fixed, oracle-reproducible reduction tree:
@@ -543,14 +543,15 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 k_nearest<<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, out);
                 break;
             case CSM_OP_ADD:
-                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act, 1);
+                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act, 1, nullptr);
                 break;
             case CSM_OP_SCALE:
-                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act, 2);
+                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act, 2, nullptr);
                 break;
             case CSM_OP_ACT:
             case CSM_OP_COPY:
-                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.kind == CSM_OP_ACT ? op.act : 0, 0);
+                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.kind == CSM_OP_ACT ? op.act : 0, 0,
+                                                                                              op.aux_off >= 0 ? weights + op.aux_off : nullptr);
                 break;
             case CSM_OP_GAVGPOOL:
                 k_gavgpool<<<dim3(in.c, in.n), 256, 0, st>>>(in, out);

@@ -371,6 +371,35 @@ __global__ __launch_bounds__(kBlock) void k_laplacian(const float *__restrict__ 
     out[((int64_t)blockIdx.z * H + y) * W + x] = laplacian_at(I, x, y, H, W, 0.0f);
 }
 
+
+// spatial_filter 'median-5' (models/utils.py:32-36): reflect pad 2, 5x5 window, torch.median = lower median (13th of 25)
+__global__ __launch_bounds__(kBlock) void k_median5(const float *__restrict__ in, float *__restrict__ out, int H, int W) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float *I = in + (int64_t)blockIdx.z * H * W;
+    float v[25];
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy) {
+        int yy = y + dy; yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            int xx = x + dx; xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+            v[(dy + 2) * 5 + (dx + 2)] = I[(int64_t)yy * W + xx];
+        }
+    }
+    // rank of each element (ties broken by index) -> the element of rank 12 is the lower median
+    float med = v[0];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 25; ++j) rank += (v[j] < v[i] || (v[j] == v[i] && j < i)) ? 1 : 0;
+        if (rank == 12) med = v[i];
+    }
+    out[((int64_t)blockIdx.z * H + y) * W + x] = med;
+}
+
 // depth_to_points (models/utils.py:43-50)
 __global__ __launch_bounds__(kBlock) void k_depth_to_points(const float *__restrict__ depth, float *__restrict__ pts,
                                                              int H, int W, float invf, float x_start, float y_start) {
@@ -387,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_to_points(const float *__restr
 
 // kenburns_effect.py:928-933 fused into one pass over the disparity map
 __global__ __launch_bounds__(kBlock) void k_disparity_to_points(const float *__restrict__ disp, float disp_max, int H,
-                                                                 int W, float fb, float invf, float x_start,
+                                                                 int W, float fb, float eps, float invf, float x_start,
                                                                  float y_start, float *__restrict__ depth,
                                                                  float *__restrict__ valid, float *__restrict__ pts,
                                                                  float *__restrict__ unaltered) {
@@ -395,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_disparity_to_points(const float *__r
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const int64_t plane = (int64_t)H * W, o = (int64_t)y * W + x;
-    float d = (1.0f / (disp[o] + 0.00001f)) * fb;  // float / Tensor == reciprocal()*float in torch
+    float d = (1.0f / (disp[o] + eps)) * fb;  // float / Tensor == reciprocal()*float in torch
     float lap = laplacian_at(disp, x, y, H, W, disp_max);
     float v = fabsf(lap) < 0.03f ? 1.0f : 0.0f;
     float hx = (x_start + (float)x) * invf, vy = (y_start + (float)y) * invf;
@@ -528,6 +557,12 @@ extern "C" int csm_spatial_filter_laplacian(const float *in, float *out, int BC,
     return csm::check_launch("k_laplacian");
 }
 
+extern "C" int csm_spatial_filter_median5(const float *in, float *out, int BC, int H, int W, void *stream) {
+    CSM_REQUIRE(in && out && in != out && BC > 0 && H > 2 && W > 2);
+    k_median5<<<grid2d(W, H, BC, 64, 4), kBlock, 0, (hipStream_t)stream>>>(in, out, H, W);
+    return csm::check_launch("k_median5");
+}
+
 extern "C" int csm_depth_to_points(const float *depth, float *pts, int B, int H, int W, double focal, void *stream) {
     CSM_REQUIRE(depth && pts && B > 0 && H > 0 && W > 0 && focal != 0.0);
     k_depth_to_points<<<grid2d(W, H, B, 64, 4), kBlock, 0, (hipStream_t)stream>>>(
@@ -536,10 +571,10 @@ extern "C" int csm_depth_to_points(const float *depth, float *pts, int B, int H,
 }
 
 extern "C" int csm_disparity_to_points(const float *disp, float disp_max, int H, int W, double focal, double baseline,
-                                       float *depth, float *valid, float *pts, float *unaltered, void *stream) {
+                                       float eps, float *depth, float *valid, float *pts, float *unaltered, void *stream) {
     CSM_REQUIRE(disp && depth && valid && pts && unaltered && H > 0 && W > 0 && focal != 0.0);
     k_disparity_to_points<<<grid2d(W, H, 1, 64, 4), kBlock, 0, (hipStream_t)stream>>>(
-        disp, disp_max, H, W, (float)(focal * baseline), (float)(1.0 / focal), (float)(-0.5 * W + 0.5),
+        disp, disp_max, H, W, (float)(focal * baseline), eps, (float)(1.0 / focal), (float)(-0.5 * W + 0.5),
         (float)(-0.5 * H + 0.5), depth, valid, pts, unaltered);
     return csm::check_launch("k_disparity_to_points");
 }

@@ -10,7 +10,8 @@ MI355X-first differences (results unchanged):
     coverage counts are accumulated on the device and read back once;
   * the 75-frame loop (kenburns_effect.py:1015-1072) is the fused csm_warp_frame + csm_crop_resize_u8; frames are
     copied to the host once at the end (the reference does a 12 MB D2H per frame).
-Out of scope this round (SURVEY 8f "next"): Inpaint GridNet (inpaint=True), bokeh depth-of-field, zoe/marigold depth.
+Point-cloud inpainting (Inpaint GridNet, :441-512) is built; out of scope this round: bokeh depth-of-field (depth_field=True),
+ldm/patchmatch inpainting, zoe/marigold depth, Refine/CRF depth refinement inside infer_disparity.
 """
 import math
 import os
@@ -24,7 +25,7 @@ import torch
 from . import _lib, ops
 from ._lib import check, f32, i32, i64, ptr, stream_ptr
 from .anime_instances import AnimeInstances
-from .nets import build_leres
+from .nets import build_inpaint_context, build_inpaint_grid, build_leres
 from .runtime import CompiledProgram
 from .segmentation import AnimeInsSeg, scaledown_size
 from .weights import StateDictWeights, SynthWeights
@@ -180,7 +181,85 @@ class KenBurnsPipeline:
         self._depth_est = self._depth_est_leres
 
     def set_inpainting(self, inpainting: str):
+        """kenburns_effect.py:425-440: 'default' = the Inpaint GridNet; 'ldm'/'patchmatch' call external services"""
+        if inpainting != 'default':
+            raise NotImplementedError("inpaint_type %r needs stable-diffusion-webui / libpatchmatch (out of scope, SURVEY 2.1)" % inpainting)
         self.inpaint_type = inpainting
+        if getattr(self, '_inpaint_ws', None) is None:
+            p = 'models/AnimeInstanceSegmentation/kenburns_inpaintnet.ckpt'          # utils/constants.py:82
+            if os.path.exists(p):
+                self._inpaint_ws = StateDictWeights(torch.load(p, map_location='cpu', weights_only=False))
+            elif _synthetic_ok() or str(self.cfg.det_ckpt).startswith('synthetic'):
+                self._inpaint_ws = SynthWeights('inpaint.')
+            else:
+                self._inpaint_ws = None         # raised lazily: inpainting is only needed by process_kenburns(inpaint=True)
+            self._inpaint_progs = {}
+
+    def _inpaint_programs(self, H, W):
+        if self._inpaint_ws is None:
+            raise FileNotFoundError('models/AnimeInstanceSegmentation/kenburns_inpaintnet.ckpt')
+        if (H, W) not in self._inpaint_progs:
+            self._inpaint_progs[(H, W)] = (CompiledProgram(build_inpaint_context(self._inpaint_ws, H, W), self.device),
+                                           CompiledProgram(build_inpaint_grid(self._inpaint_ws, H, W), self.device))
+        return self._inpaint_progs[(H, W)]
+
+    def _inpaint(self, tenImage, tenDisparity, tenShift, objCommon, segmasks=None):
+        """Inpaint.forward (anime_3dkenburns/models/pointcloud_inpainting.py:116-203): context convs -> forward splat of
+        68 channels -> median-5 clean-up -> GridNet -> colour + disparity.  mean/std are scalar torch reductions."""
+        W, H, f, b = objCommon['intWidth'], objCommon['intHeight'], objCommon['fltFocal'], objCommon['fltBaseline']
+        ctx_p, grid_p = self._inpaint_programs(H, W)
+        _, _, pts, _ = ops.disparity_to_points(tenDisparity, f, b, eps=0.0000001)
+        pts = pts.view(1, 3, -1)
+        tenMean = [tenImage.mean([1, 2, 3], True), tenDisparity.mean([1, 2, 3], True)]
+        tenStd = [tenImage.std([1, 2, 3], False, True), tenDisparity.std([1, 2, 3], False, True)]
+        ni = (tenImage - tenMean[0]) / (tenStd[0] + 0.0000001)
+        nd = (tenDisparity - tenMean[1]) / (tenStd[1] + 0.0000001)
+        x = torch.cat([ni, nd], 1).contiguous()
+        ctx = torch.empty((1, 64, H, W), dtype=torch.float32, device=self.device)
+        ctx_p.run(x, ctx)
+        ps = (pts + tenShift).contiguous()
+        render, existing = ops.render_pointcloud(ps, torch.cat([ni, nd, ctx], 1).view(1, 68, -1), W, H, f, b)
+        if segmasks is not None:
+            s = torch.cat([segmasks, nd], 1).view(1, segmasks.shape[1] + 1, -1)
+            segmasks, _ = ops.render_pointcloud(ps, s, W, H, f, b)
+        existing = (existing > 0.0).float()
+        existing = existing * ops.spatial_filter(existing, 'median-5')
+        render = render * existing
+        gin = torch.cat([render, existing], 1).contiguous()
+        img = torch.empty((1, 3, H, W), dtype=torch.float32, device=self.device)
+        dsp = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
+        grid_p.run(gin, img, dsp)
+        img = img * (tenStd[0] + 0.0000001) + tenMean[0]
+        dsp = dsp * (tenStd[1] + 0.0000001) + tenMean[1]
+        return {'tenExisting': existing, 'tenImage': img.clip(0.0, 1.0),
+                'tenDisparity': torch.nn.functional.threshold(dsp, threshold=0.0, value=0.0), 'segmasks': segmasks}
+
+    def inpaint(self, tenShift, tenPoints, objCommon: KenBurnsConfig, verbose: bool = False):
+        """kenburns_effect.py:441-512 (inpaint_type 'default'): inpaint the view at `tenShift` and append the points that
+        fill its holes to the cloud (N grows, data dependent)."""
+        ins = objCommon.instances
+        mask_with_ins = None
+        if ins is not None and not ins.is_empty:
+            m = ins.masks[0]
+            for k in ins.masks[1:]:
+                m = torch.logical_or(m, k)
+            mask_with_ins = m.to(torch.float32).repeat(3, 1, 1).unsqueeze(0)
+        f, b = objCommon['fltFocal'], objCommon['fltBaseline']
+        o = self._inpaint(objCommon['tenRawImage'], objCommon['tenRawDisparity'], tenShift, objCommon, mask_with_ins)
+        depth_t, _, pts, _ = ops.disparity_to_points(o['tenDisparity'], f, b, eps=0.0000001)      # :457-460
+        pts = pts.view(1, 3, -1) - tenShift
+        tenMask = (o['tenExisting'] == 0.0).view(1, 1, -1)
+        m1, m3 = tenMask[0, 0], tenMask.repeat(1, 3, 1)
+        objCommon.inpainted_img = torch.cat([objCommon.inpainted_img, o['tenImage'].view(1, 3, -1)[m3].view(1, 3, -1)], 2)
+        objCommon['tenInpaDisparity'] = torch.cat([objCommon['tenInpaDisparity'], o['tenDisparity'].view(1, 1, -1)[:, :, m1]], 2)
+        objCommon['tenInpaDepth'] = torch.cat([objCommon['tenInpaDepth'], depth_t.view(1, 1, -1)[:, :, m1]], 2)
+        objCommon['tenInpaPoints'] = torch.cat([objCommon['tenInpaPoints'], pts[m3].view(1, 3, -1)], 2)
+        if not hasattr(objCommon, 'stage_inpainted_imgs') or objCommon.stage_inpainted_imgs is None:
+            objCommon.stage_inpainted_imgs, objCommon.stage_inpainted_masks = [], []
+        if verbose:
+            objCommon.stage_inpainted_imgs.append((o['tenImage'][0] * 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy())
+            objCommon.stage_inpainted_masks.append((tenMask.view(objCommon.int_height, objCommon.int_width).to(torch.uint8) * 255).cpu().numpy())
+        return o
 
     # ---- depth (kenburns_effect.py:563-581) ------------------------------------------------------------
     def _leres_prog(self, h, w):
@@ -305,9 +384,6 @@ class KenBurnsPipeline:
     # ---- frame loop (kenburns_effect.py:979-1081) -----------------------------------------------------------------
     def process_kenburns(self, objSettings, objCommon: KenBurnsConfig, inpaint: bool = True, verbose: bool = False,
                          to_numpy: bool = True):
-        if inpaint:
-            raise NotImplementedError("point-cloud inpainting (Inpaint GridNet, SURVEY 8f rank 1) is not built yet: call with "
-                                      "inpaint=False")
         if objCommon.depth_field:
             raise NotImplementedError("bokeh depth-of-field (SURVEY 8f rank 2) is not built yet: set depth_field=False")
         L = _lib.load()
@@ -318,7 +394,23 @@ class KenBurnsPipeline:
             steps = objSettings['fltSteps']
             out = torch.empty((len(steps), H, W, 3), dtype=torch.uint8, device=self.device)
             pw, ph = max(oF['intCropWidth'], oT['intCropWidth']), max(oF['intCropHeight'], oT['intCropHeight'])
-            pts, rgb, dep = objCommon['tenInpaPoints'], objCommon.inpainted_img, objCommon['tenInpaDepth']
+            if inpaint:                                                   # kenburns_effect.py:984-1012
+                objCommon.inpainted_img = objCommon['tenRawImage'].view(1, 3, -1)
+                objCommon['tenInpaDisparity'] = objCommon['tenRawDisparity'].view(1, 1, -1)
+                objCommon['tenInpaDepth'] = objCommon['tenRawDepth'].view(1, 1, -1)
+                objCommon['tenInpaPoints'] = objCommon['tenRawPoints'].view(1, 3, -1)
+                for fltStep in [0.0, 1.0]:
+                    fltFrom = 1.0 - fltStep
+                    fltTo = 1.0 - fltFrom
+                    su = ((fltFrom * oF['fltCenterU']) + (fltTo * oT['fltCenterU'])) - (W / 2.0)
+                    sv = ((fltFrom * oF['fltCenterV']) + (fltTo * oT['fltCenterV'])) - (H / 2.0)
+                    cwid = (fltFrom * oF['intCropWidth']) + (fltTo * oT['intCropWidth'])
+                    d_from = objCommon['objDepthrange'][0]
+                    d_to = d_from * (cwid / max(oF['intCropWidth'], oT['intCropWidth']))
+                    shift = ops.shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, objCommon)
+                    tenShift = torch.tensor(shift, dtype=torch.float32).view(1, 3, 1).to(self.device)
+                    self.inpaint(1.1 * tenShift, None, objCommon, verbose)
+            pts, rgb, dep = objCommon['tenInpaPoints'].contiguous(), objCommon.inpainted_img.contiguous(), objCommon['tenInpaDepth'].contiguous()
             for k, fltStep in enumerate(steps):
                 fltFrom = 1.0 - fltStep
                 fltTo = 1.0 - fltFrom

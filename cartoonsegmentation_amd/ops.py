@@ -82,13 +82,13 @@ def fill_disocclusion(tenInput, tenDepth):
 
 def spatial_filter(tenInput, strType):
     """spatial_filter -- anime_3dkenburns/models/utils.py:9-40 ('laplacian' is the hot-path mode)"""
-    if strType != 'laplacian':
-        raise NotImplementedError("spatial_filter(%r): only 'laplacian' is on the hot path" % strType)
+    if strType not in ('laplacian', 'median-5'):
+        raise NotImplementedError("spatial_filter(%r): 'laplacian' and 'median-5' are the modes the hot path uses" % strType)
     tenInput = _dev(tenInput, "tenInput")
     B, C, H, W = tenInput.shape
     out = torch.empty_like(tenInput)
-    check(_lib.load().csm_spatial_filter_laplacian(ptr(tenInput), ptr(out), i32(B * C), i32(H), i32(W), stream_ptr()),
-          "spatial_filter")
+    fn = _lib.load().csm_spatial_filter_laplacian if strType == 'laplacian' else _lib.load().csm_spatial_filter_median5
+    check(fn(ptr(tenInput), ptr(out), i32(B * C), i32(H), i32(W), stream_ptr()), "spatial_filter")
     return out
 
 
@@ -102,14 +102,14 @@ def depth_to_points(tenDepth, fltFocal):
     return pts
 
 
-def disparity_to_points(tenDisparity, fltFocal, fltBaseline):
+def disparity_to_points(tenDisparity, fltFocal, fltBaseline, eps=0.00001):
     """kenburns_effect.py:929-933 fused: normalised disparity -> depth, valid, points, unaltered"""
     d = _dev(tenDisparity, "tenDisparity")
     H, W = d.shape[-2:]
     depth, valid = torch.empty_like(d), torch.empty_like(d)
     pts, un = d.new_empty([1, 3, H, W]), d.new_empty([1, 3, H, W])
     check(_lib.load().csm_disparity_to_points(ptr(d), f32(float(d.max().item())), i32(H), i32(W), f64(fltFocal),
-                                              f64(fltBaseline), ptr(depth), ptr(valid), ptr(pts), ptr(un), stream_ptr()),
+                                              f64(fltBaseline), f32(eps), ptr(depth), ptr(valid), ptr(pts), ptr(un), stream_ptr()),
           "disparity_to_points")
     return depth, valid, pts, un
 

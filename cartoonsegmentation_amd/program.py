@@ -242,10 +242,16 @@ class Program:
             out = self.buffer(a.n, a.h, a.w, a.c)
         return self._emit(OP_ADD, a, b, out, act=ACT[act])
 
-    def act(self, x, act, out=None):
+    def act(self, x, act, out=None, slope=None):
         if out is None:
             out = self.buffer(x.n, x.h, x.w, x.c)
-        return self._emit(OP_ACT, x, None, out, act=ACT[act])
+        a_h = a_n = -1
+        if slope is not None:
+            slope = np.asarray(slope, np.float32)
+            if slope.size < x.c:                       # zero-padded channels keep slope 0
+                slope = np.concatenate([slope, np.zeros(x.c - slope.size, np.float32)])
+            a_h, a_n = self._w(slope, slope)
+        return self._emit(OP_ACT, x, None, out, act=ACT[act], aux_off=a_h, nat=dict(aux_off=a_n))
 
     def copy(self, x, out):
         return self._emit(OP_COPY, x, None, out)

@@ -71,12 +71,16 @@ int csm_fill_disocclusion(const float *in, const float *depth, float *out, int B
 /* spatial_filter(x,'laplacian')   models/utils.py:12-24 ; x,out [BC,H,W] */
 int csm_spatial_filter_laplacian(const float *in, float *out, int BC, int H, int W, void *stream);
 
+/* spatial_filter(x,'median-5')   models/utils.py:32-36 (reflect pad, lower median of 25) ; x,out [BC,H,W] */
+int csm_spatial_filter_median5(const float *in, float *out, int BC, int H, int W, void *stream);
+
 /* depth_to_points   models/utils.py:43-50 ; depth [B,1,H,W] -> pts [B,3,H,W] */
 int csm_depth_to_points(const float *depth, float *pts, int B, int H, int W, double focal, void *stream);
 
 /* kenburns_effect.py:928-933 fused: normalised disparity [1,1,H,W] (already /max*baseline) ->
- * depth, valid, points (depth*valid), unaltered points.  disp_max = max(disparity). */
-int csm_disparity_to_points(const float *disp, float disp_max, int H, int W, double focal, double baseline,
+ * depth = (1/(disp+eps))*focal*baseline, valid, points (depth*valid), unaltered points.  disp_max = max(disparity);
+ * eps = 1e-5 at kenburns_effect.py:929, 1e-7 at :458 and pointcloud_inpainting.py:117. */
+int csm_disparity_to_points(const float *disp, float disp_max, int H, int W, double focal, double baseline, float eps,
                             float *depth, float *valid, float *pts, float *unaltered, void *stream);
 
 /* tensor part of process_shift   common.py:74-81 ; shift = float32(sx,sy,sz) */

@@ -122,3 +122,35 @@ def frames(kc, rgb, W, H, focal, baseline, objFrom, objTo, steps):
         L.orc_crop_resize_u8(_p(np.ascontiguousarray(fr)), ci(H), ci(W), ci(ph), ci(pw), cf(W / 2.0), cf(H / 2.0), _p(o))
         out.append(o)
     return out
+
+
+def inpaint_forward(img, disp, shift, segmasks, W, H, focal, baseline, ctx_prog, grid_prog, degrid_mode=1):
+    """Inpaint.forward (anime_3dkenburns/models/pointcloud_inpainting.py:116-203) restated over the oracle programs.
+    img [1,3,H,W], disp [1,1,H,W], shift [1,3,1]; returns dict like the reference."""
+    f32 = np.float32
+    depth = ((f32(1.0) / (disp + f32(0.0000001))) * f32(focal * baseline)).astype(f32)           # float / Tensor
+    valid = (np.abs(owarp.spatial_filter_laplacian((disp / disp.max()).astype(f32))) < f32(0.03)).astype(f32)
+    pts = owarp.depth_to_points((depth * valid).astype(f32), focal).reshape(1, 3, -1)
+    mi, md = f32(img.mean(dtype=np.float64)), f32(disp.mean(dtype=np.float64))
+    si, sd = f32(img.std(dtype=np.float64)), f32(disp.std(dtype=np.float64))
+    ni = ((img - mi) / (si + f32(0.0000001))).astype(f32)
+    nd = ((disp - md) / (sd + f32(0.0000001))).astype(f32)
+    x = np.ascontiguousarray(np.concatenate([ni, nd], 1))
+    ctx = np.zeros((1, 64, H, W), f32)
+    onets.run_program(ctx_prog, [x, ctx])
+    data = np.concatenate([ni, nd, ctx], 1).reshape(1, 68, -1)
+    ps = (pts + shift.reshape(1, 3, 1)).astype(f32)
+    render, existing = owarp.render_pointcloud(ps, data, W, H, focal, baseline, degrid_mode=degrid_mode)
+    seg_r = None
+    if segmasks is not None:
+        s = np.concatenate([segmasks, nd], 1).reshape(1, segmasks.shape[1] + 1, -1)
+        seg_r, _ = owarp.render_pointcloud(ps, s, W, H, focal, baseline, degrid_mode=degrid_mode)
+    existing = (existing > 0.0).astype(f32)
+    existing = (existing * owarp.spatial_filter_median5(existing)).astype(f32)
+    render = (render * existing).astype(f32)
+    gin = np.ascontiguousarray(np.concatenate([render, existing], 1))
+    oi, od = np.zeros((1, 3, H, W), f32), np.zeros((1, 1, H, W), f32)
+    onets.run_program(grid_prog, [gin, oi, od])
+    image = (oi * (si + f32(0.0000001)) + mi).astype(f32)
+    dsp = (od * (sd + f32(0.0000001)) + md).astype(f32)
+    return dict(existing=existing, image=np.clip(image, 0.0, 1.0), disparity=np.where(dsp > 0, dsp, 0).astype(f32), segmasks=seg_r)

@@ -216,7 +216,7 @@ static void orc_nearest(view_t in, view_t out)
     }
 }
 
-static void orc_eltwise(view_t a, view_t b, view_t out, int act, int mode)
+static void orc_eltwise(view_t a, view_t b, view_t out, int act, int mode, const float *slope)
 {
     const int64_t M = (int64_t)out.n * out.h * out.w;
     for (int64_t m = 0; m < M; ++m) {
@@ -225,7 +225,7 @@ static void orc_eltwise(view_t a, view_t b, view_t out, int act, int mode)
             float v = a.p[m * a.ld + c];
             if (mode == 1) v = v + b.p[m * b.ld + c];
             else if (mode == 2) v = v * b.p[n * b.ld + c];
-            out.p[m * out.ld + c] = orc_act(v, act, 0.0f);
+            out.p[m * out.ld + c] = orc_act(v, act, slope ? slope[c] : 0.0f);
         }
     }
 }
@@ -268,10 +268,10 @@ int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
             case CSM_OP_MAXPOOL: orc_maxpool(op, in, out); break;
             case CSM_OP_BILINEAR: orc_bilinear(op, in, out); break;
             case CSM_OP_NEAREST: orc_nearest(in, out); break;
-            case CSM_OP_ADD: orc_eltwise(in, in1, out, op->act, 1); break;
-            case CSM_OP_SCALE: orc_eltwise(in, in1, out, op->act, 2); break;
-            case CSM_OP_ACT: orc_eltwise(in, in1, out, op->act, 0); break;
-            case CSM_OP_COPY: orc_eltwise(in, in1, out, 0, 0); break;
+            case CSM_OP_ADD: orc_eltwise(in, in1, out, op->act, 1, NULL); break;
+            case CSM_OP_SCALE: orc_eltwise(in, in1, out, op->act, 2, NULL); break;
+            case CSM_OP_ACT: orc_eltwise(in, in1, out, op->act, 0, S); break;
+            case CSM_OP_COPY: orc_eltwise(in, in1, out, 0, 0, NULL); break;
             case CSM_OP_GAVGPOOL: orc_gavgpool(in, out); break;
             case CSM_OP_NCHW_TO_NHWC: {
                 int64_t hw = (int64_t)out.h * out.w;

@@ -74,9 +74,34 @@ def leres_cases():
         print('leres', tag, float(y.mean()), float(y.std()))
 
 
+def inpaint_case():
+    """whole Inpaint.forward of the reference (incl. its render_pointcloud CUDA text through cuda_on_cpu.h)"""
+    mu, co, cu = ref_loader.load_warp_modules()
+    m = ref_loader.load_by_path("anime_3dkenburns.models.pointcloud_inpainting", "anime_3dkenburns/models/pointcloud_inpainting.py")
+    net = fill_synthetic(m.Inpaint(), 'inpaint.')
+    H, W = 32, 40
+    g = np.random.default_rng(77)
+    img = g.uniform(0, 1, (1, 3, H, W)).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    disp = (10 + 8 * yy / H + 14.0 / (1.0 + np.exp(np.clip((np.hypot(xx - 18, yy - 14) - 8) / 0.75, -60, 60)))).astype(np.float32)[None, None]
+    disp = disp / disp.max() * 40.0
+    seg = (np.hypot(xx - 18, yy - 14) < 8).astype(np.float32)[None, None].repeat(3, 1)
+    shift = np.array([2.5, -1.5, -3.0], np.float32).reshape(1, 3, 1)
+    common = {'fltFocal': W / 2.0, 'fltBaseline': 40.0, 'intWidth': W, 'intHeight': H}
+    with torch.no_grad():
+        out = net(torch.from_numpy(img), torch.from_numpy(disp.astype(np.float32)), torch.from_numpy(shift), common, torch.from_numpy(seg))
+    np.savez_compressed(os.path.join(HERE, 'net_inpaint_32x40.npz'), img=img, disp=disp.astype(np.float32), shift=shift, seg=seg,
+                        existing=out['tenExisting'].numpy(), image=out['tenImage'].numpy(), disparity=out['tenDisparity'].numpy(),
+                        segmasks=out['segmasks'].numpy())
+    print('inpaint', float(out['tenExisting'].mean()), float(out['tenImage'].mean()), float(out['tenDisparity'].mean()))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['isnet', 'leres']
     if 'isnet' in which:
         isnet_cases()
     if 'leres' in which:
         leres_cases()
+    if 'inpaint' in which:
+        inpaint_case()
+

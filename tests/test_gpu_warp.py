@@ -108,6 +108,10 @@ def test_pointwise(ops):
     assert np.abs(lap - g['lap']).max() < 2e-6
     p2 = ops.depth_to_points(dev(g['depth']), focal).cpu().numpy()
     assert np.array_equal(p2, g['unaltered'])
+    m = (np.random.default_rng(3).uniform(0, 1, (2, 1, 37, 41)) > 0.4).astype(np.float32)
+    assert np.array_equal(ops.spatial_filter(dev(m), 'median-5').cpu().numpy(), orc.spatial_filter_median5(m))
+    f = np.random.default_rng(4).normal(0, 1, (1, 2, 19, 23)).astype(np.float32)
+    assert np.array_equal(ops.spatial_filter(dev(f), 'median-5').cpu().numpy(), orc.spatial_filter_median5(f))
 
 
 def _frame_case(ops, H, W, seed, extra=0):

@@ -95,3 +95,12 @@ def test_pointwise():
     assert (valid != g['valid']).mean() < 1e-3
     same = valid == g['valid']
     assert np.array_equal(pts[:, :, same[0, 0]], g['pts'].reshape(1, 3, *valid.shape[2:])[:, :, same[0, 0]])
+
+
+def test_median5_matches_torch_restatement():
+    """spatial_filter(x,'median-5') of the reference (models/utils.py:32-36) is pure torch: reflect pad + unfold + median"""
+    import torch
+    x = torch.from_numpy(np.random.default_rng(9).normal(0, 1, (1, 2, 17, 21)).astype(np.float32))
+    t = torch.nn.functional.pad(x, [2, 2, 2, 2], mode='reflect').unfold(2, 5, 1).unfold(3, 5, 1)
+    t = t.contiguous().view(1, 2, 17, 21, 25).median(-1, False)[0]
+    assert np.array_equal(orc.spatial_filter_median5(x.numpy()), t.numpy())
