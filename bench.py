@@ -162,7 +162,7 @@ class FrameWorkload(Workload):
         from cartoonsegmentation_amd import ops, synth
         from cartoonsegmentation_amd.kenburns import KenBurnsConfig, KenBurnsPipeline
         self.ops, self.H, self.W, self.device = ops, size, size, device
-        cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', det_size=640, depth_est_size=640, max_size=size,
+        cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=640, max_size=size,
                              refine_crf=False, depth_field=False, focal=size / 2.0,
                              mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 720})
         self.pipe = KenBurnsPipeline(cfg, device=str(device))
@@ -174,7 +174,7 @@ class FrameWorkload(Workload):
     def step(self):
         from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, f32, check
         pipe = self.pipe
-        inst = pipe.animeinsseg.infer(self.img, pred_score_thr=0.3, max_instances=self.INSTANCES, det_size=640)
+        inst = pipe.animeinsseg.infer(self.img, 0.3, pipe.cfg.mask_refine_kwargs, max_instances=self.INSTANCES, det_size=640)
         self.n_inst = len(inst)
         kc = pipe.generate_kenburns_config(self.img, instances=inst)
         W, H = kc['intWidth'], kc['intHeight']

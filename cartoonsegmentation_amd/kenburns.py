@@ -25,7 +25,7 @@ import torch
 from . import _lib, ops
 from ._lib import check, f32, i32, i64, ptr, stream_ptr
 from .anime_instances import AnimeInstances
-from .nets import build_inpaint_context, build_inpaint_grid, build_leres
+from .nets import build_inpaint_context, build_inpaint_grid, build_leres, build_refine
 from .runtime import CompiledProgram
 from .segmentation import AnimeInsSeg, scaledown_size
 from .weights import StateDictWeights, SynthWeights
@@ -148,8 +148,11 @@ class KenBurnsPipeline:
         self.device = torch.device('cuda:%d' % torch.cuda.current_device()) if device in (None, 'cuda') else torch.device(device)
         self.animeinsseg = None
         self._leres, self._leres_weights, self._leres_ws = {}, None, None
+        self._refine_ws, self._refine_progs = None, {}
         self.set_detector(cfg.detector)
         self.set_depth_estimation(cfg.depth_est)
+        if self.cfg.default_depth_refine:
+            self.set_depth_refinement(cfg.depth_refinement)
         self.set_inpainting(cfg.inpaint_type)
 
     # ---- component selection (kenburns_effect.py:425-440, :514-546) ---------------------------------
@@ -162,8 +165,9 @@ class KenBurnsPipeline:
                 if not _synthetic_ok() and not str(ckpt).startswith('synthetic'):
                     raise FileNotFoundError("%s (set det_ckpt='synthetic' or CSM_SYNTHETIC_WEIGHTS=1 for closed-form weights)" % ckpt)
                 ckpt = 'synthetic'
-            self.animeinsseg = AnimeInsSeg(ckpt, default_det_size=self.cfg.det_size, device=str(self.device),
-                                           refine_kwargs=self.cfg.mask_refine_kwargs or {'refine_method': 'refinenet_isnet'})
+            # kenburns_effect.py:832-837: AnimeInsSeg(cfg.det_ckpt, device) -- the reference never applies cfg.det_size
+            # (SURVEY F8); callers that want another detector size use animeinsseg.set_detect_size / infer(det_size=)
+            self.animeinsseg = AnimeInsSeg(ckpt, device=str(self.device))
 
     def set_depth_estimation(self, depth_est: str):
         if depth_est != 'leres':
@@ -179,6 +183,35 @@ class KenBurnsPipeline:
             else:
                 self._leres_ws = SynthWeights('leres.')
         self._depth_est = self._depth_est_leres
+
+    def set_depth_refinement(self, depth_refinement: str):
+        """kenburns_effect.py:820-829: 'default' = the Ken Burns `Refine` net"""
+        if depth_refinement != 'default':
+            raise NotImplementedError('Invalid depth refinement: %s' % depth_refinement)
+        if self._refine_ws is None:
+            p = 'models/AnimeInstanceSegmentation/kenburns_depth_refinenet.ckpt'     # utils/constants.py:81
+            if os.path.exists(p):
+                self._refine_ws = StateDictWeights(torch.load(p, map_location='cpu', weights_only=False))
+            elif _synthetic_ok() or str(self.cfg.det_ckpt).startswith('synthetic'):
+                self._refine_ws = SynthWeights('refine.')
+            else:
+                raise FileNotFoundError(p)
+
+    def refine_depth(self, img: torch.Tensor, disparity: torch.Tensor):
+        """Refine.forward (anime_3dkenburns/models/disparity_refinement.py:97-126): normalise, net, de-normalise, threshold(0)"""
+        if self._refine_ws is None:
+            self.set_depth_refinement('default')
+        H, W, h, w = img.shape[2], img.shape[3], disparity.shape[2], disparity.shape[3]
+        if (H, W, h, w) not in self._refine_progs:
+            self._refine_progs[(H, W, h, w)] = CompiledProgram(build_refine(self._refine_ws, H, W, h, w), self.device)
+        tenMean = [img.mean([1, 2, 3], True), disparity.mean([1, 2, 3], True)]
+        tenStd = [img.std([1, 2, 3], False, True), disparity.std([1, 2, 3], False, True)]
+        ni = ((img - tenMean[0]) / (tenStd[0] + 0.0000001)).contiguous()
+        nd = ((disparity - tenMean[1]) / (tenStd[1] + 0.0000001)).contiguous()
+        out = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
+        self._refine_progs[(H, W, h, w)].run(ni, nd, out)
+        out = out * (tenStd[1] + 0.0000001) + tenMean[1]
+        return torch.nn.functional.threshold(out, threshold=0.0, value=0.0)
 
     def set_inpainting(self, inpainting: str):
         """kenburns_effect.py:425-440: 'default' = the Inpaint GridNet; 'ldm'/'patchmatch' call external services"""
@@ -292,8 +325,7 @@ class KenBurnsPipeline:
         return depth
 
     def run_instance_segmentation(self, img, scale_down_to_maxsize=True):
-        inst = self.animeinsseg.infer(img, pred_score_thr=self.cfg.pred_score_thr, output_type='tensor',
-                                      det_size=self.cfg.det_size)
+        inst = self.animeinsseg.infer(img, self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None, output_type='tensor')   # :869-872
         return inst, img
 
     def infer_disparity(self, img, instances=None, img_tensor=None, kcfg=None, **kw):
@@ -304,8 +336,10 @@ class KenBurnsPipeline:
             img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
         disparity = self._depth_est(img_tensor, img_d)
         disparity = depth_adjustment_animesseg(instances, disparity, img_tensor, self.cfg.depthest_use_medium)
-        if self.cfg.default_depth_refine or self.cfg.refine_crf:
-            raise NotImplementedError("depth refinement (Refine net / CRF) is off in the shipped yaml and not built yet")
+        if self.cfg.default_depth_refine:                                        # kenburns_effect.py:619-622
+            disparity = self.refine_depth(img_tensor, disparity)
+        elif self.cfg.refine_crf:
+            raise NotImplementedError("refine_crf=True needs cv2 / pydensecrf CPU heuristics (out of scope, SURVEY 2.1; off in the shipped yaml)")
         return disparity
 
     # ---- generate_kenburns_config (kenburns_effect.py:898-951) -----------------------------------------------

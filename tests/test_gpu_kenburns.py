@@ -14,12 +14,12 @@ def pipe_and_cfg():
     from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
     from cartoonsegmentation_amd import synth
     H, W = 320, 384
-    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', det_size=96, depth_est_size=96, max_size=512, refine_crf=False,
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=96, max_size=512, refine_crf=False,
                          depth_field=False, focal=W / 2.0, num_frame=3,
                          mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 64})
     pipe = KenBurnsPipeline(cfg)
     img = synth.image_u8(H, W, 11)
-    inst = pipe.animeinsseg.infer(img, pred_score_thr=0.3, max_instances=2, det_size=96)
+    inst = pipe.animeinsseg.infer(img, pred_score_thr=0.3, max_instances=2, det_size=96, refine_kwargs=cfg.mask_refine_kwargs)
     kc = pipe.generate_kenburns_config(img, instances=inst)
     return pipe, kc, img, inst
 
@@ -126,3 +126,12 @@ def test_autozoom_end_to_end_with_inpainting(pipe_and_cfg):
     assert kc['tenInpaPoints'].shape[2] >= n0 and kc.inpainted_img.shape[2] == kc['tenInpaPoints'].shape[2]
     assert kc['tenInpaDepth'].shape[2] == kc['tenInpaPoints'].shape[2]
     assert np.isfinite(kc['tenInpaPoints'].cpu().numpy()).all()
+
+
+def test_refine_depth_vs_reference_fixture():
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "net_refine_48x64.npz")))
+    pipe = KenBurnsPipeline(KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', refine_crf=False, default_depth_refine=True))
+    y = pipe.refine_depth(torch.from_numpy(g['img']).to(pipe.device), torch.from_numpy(g['dsp']).to(pipe.device)).cpu().numpy()
+    assert np.abs(y - g['y']).max() / np.abs(g['y']).max() < 1e-4          # reference Refine module, fp32 tolerance
