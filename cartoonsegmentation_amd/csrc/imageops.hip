@@ -144,3 +144,100 @@ extern "C" int csm_crop_resize_u8(const uint8_t *frame_hwc, int H, int W, int pa
                                                                                  center_y, out_hwc);
     return csm::check_launch("k_crop_resize");
 }
+
+// ---- bokeh depth-of-field (utils/effects.py:12-181) --------------------------------------------------------------
+namespace {
+
+// kernel_bokeh (utils/effects.py:16-74): one (pixel, channel) per lane, HWC-interleaved fp32 image (the reference kernel
+// indexes raw memory as (y*W+x)*3+c), 32 depth-weighted samples along (dx, dy).
+__global__ __launch_bounds__(256) void k_bokeh_pass(const float *__restrict__ img, const float *__restrict__ depth,
+                                                     float *__restrict__ out, int H, int W, int nsamples, float dx, float dy) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)H * W * 3) return;
+    const int c = (int)(idx % 3); const int64_t pix = idx / 3;
+    const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
+    const int im_size = min(H, W), off = nsamples / 2;
+    const float d = depth[pix];
+    const float ddx = dx * d, ddy = dy * d;
+    float weight = 0.0f, color = 0.0f;
+    for (int s = 0; s < nsamples; ++s) {
+        const int sp = (s - off) * im_size;
+        const int x_ = x + (int)roundf(ddx * (float)sp), y_ = y + (int)roundf(ddy * (float)sp);
+        if (x_ >= W || y_ >= H || x_ < 0 || y_ < 0) continue;
+        const float w_ = depth[(int64_t)y_ * W + x_];
+        weight += w_;
+        color += img[((int64_t)y_ * W + x_) * 3 + c] * w_;
+    }
+    out[idx] = weight != 0.0f ? color / weight : img[idx];
+}
+
+// img u8 HWC -> (img/255)^lightness  (utils/effects.py:155-156)
+__global__ __launch_bounds__(256) void k_bokeh_highlight(const uint8_t *__restrict__ img, float *__restrict__ out, int64_t n, float lf) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = powf((float)img[i] / 255.0f, lf);
+}
+// ((diag + rhom)/2)^(1/lightness) * 255 -> u8  (utils/effects.py:172, :179-180)
+__global__ __launch_bounds__(256) void k_bokeh_finish(const float *__restrict__ a, const float *__restrict__ b, uint8_t *__restrict__ out,
+                                                       int64_t n, float inv_lf) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = powf((a[i] + b[i]) / 2.0f, inv_lf) * 255.0f;
+    out[i] = (uint8_t)v;
+}
+// depth u8 -> bokeh depth map (utils/effects.py:146-153, :162-163): mx - |d - focal|, minus min, / max, 1 - x, * 0.0005
+// stats = {max(d), min(mx-|d-f|), max(after minus min)} are computed by the caller (scalar reductions)
+__global__ __launch_bounds__(256) void k_bokeh_depth(const uint8_t *__restrict__ d8, float *__restrict__ out, int64_t n, float dmax,
+                                                      float focal, float mn, float mx2) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = dmax - fabsf((float)d8[i] - focal);
+    v = v - mn;
+    v = v / mx2;
+    v = 1.0f - v;
+    out[i] = v * 0.0005f;
+}
+// colorize(depth, cmap='gray_r')[...,0] (zoedepth/utils/misc.py:97-135): (v - vmin)/(vmax - vmin) -> matplotlib LUT index
+__global__ __launch_bounds__(256) void k_colorize_gray_r(const float *__restrict__ v, uint8_t *__restrict__ out, int64_t n, float vmin,
+                                                          float vmax) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float x = vmin != vmax ? (v[i] - vmin) / (vmax - vmin) : 0.0f;
+    // matplotlib Colormap.__call__: xa = x*256; xa==256 -> 255; clip to [-1, 256]; int(); <0 -> under (lut[0]), >255 -> over (lut[255])
+    float xa = x * 256.0f;
+    if (xa == 256.0f) xa = 255.0f;
+    xa = fminf(fmaxf(xa, -1.0f), 256.0f);
+    int k = (int)xa;
+    k = k < 0 ? 0 : (k > 255 ? 255 : k);
+    out[i] = (uint8_t)(255 - k);          // gray_r LUT: uint8((1 - k/255) * 255) == 255 - k  (checked against matplotlib in tests)
+}
+
+}  // namespace
+
+extern "C" int csm_bokeh_pass(const float *img_hwc, const float *depth, float *out_hwc, int H, int W, int nsamples, float dx, float dy,
+                              void *stream) {
+    CSM_REQUIRE(img_hwc && depth && out_hwc && img_hwc != out_hwc && H > 0 && W > 0 && nsamples > 0);
+    k_bokeh_pass<<<csm::cdiv((int64_t)H * W * 3, 256), 256, 0, (hipStream_t)stream>>>(img_hwc, depth, out_hwc, H, W, nsamples, dx, dy);
+    return csm::check_launch("k_bokeh_pass");
+}
+extern "C" int csm_bokeh_highlight(const uint8_t *img_hwc, float *out_hwc, int64_t n, float lightness, void *stream) {
+    CSM_REQUIRE(img_hwc && out_hwc && n > 0);
+    k_bokeh_highlight<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(img_hwc, out_hwc, n, lightness);
+    return csm::check_launch("k_bokeh_highlight");
+}
+extern "C" int csm_bokeh_finish(const float *diag_hwc, const float *rhom_hwc, uint8_t *out_hwc, int64_t n, float lightness, void *stream) {
+    CSM_REQUIRE(diag_hwc && rhom_hwc && out_hwc && n > 0 && lightness != 0.0f);
+    k_bokeh_finish<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(diag_hwc, rhom_hwc, out_hwc, n, (float)(1.0 / (double)lightness));
+    return csm::check_launch("k_bokeh_finish");
+}
+extern "C" int csm_bokeh_depth(const uint8_t *depth_u8, float *out, int64_t n, float dmax, float focal_plane, float mn, float mx2,
+                               void *stream) {
+    CSM_REQUIRE(depth_u8 && out && n > 0);
+    k_bokeh_depth<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(depth_u8, out, n, dmax, focal_plane, mn, mx2);
+    return csm::check_launch("k_bokeh_depth");
+}
+extern "C" int csm_colorize_gray_r(const float *value, uint8_t *out, int64_t n, float vmin, float vmax, void *stream) {
+    CSM_REQUIRE(value && out && n > 0);
+    k_colorize_gray_r<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(value, out, n, vmin, vmax);
+    return csm::check_launch("k_colorize_gray_r");
+}

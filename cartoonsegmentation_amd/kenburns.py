@@ -10,8 +10,8 @@ MI355X-first differences (results unchanged):
     coverage counts are accumulated on the device and read back once;
   * the 75-frame loop (kenburns_effect.py:1015-1072) is the fused csm_warp_frame + csm_crop_resize_u8; frames are
     copied to the host once at the end (the reference does a 12 MB D2H per frame).
-Point-cloud inpainting (Inpaint GridNet, :441-512) is built; out of scope this round: bokeh depth-of-field (depth_field=True),
-ldm/patchmatch inpainting, zoe/marigold depth, Refine/CRF depth refinement inside infer_disparity.
+Point-cloud inpainting (Inpaint GridNet, :441-512) is built; bokeh depth-of-field (depth_field=True, :1042-1067) is built;
+out of scope this round: ldm/patchmatch inpainting, zoe/marigold depth, Refine/CRF depth refinement inside infer_disparity.
 """
 import math
 import os
@@ -418,13 +418,12 @@ class KenBurnsPipeline:
     # ---- frame loop (kenburns_effect.py:979-1081) -----------------------------------------------------------------
     def process_kenburns(self, objSettings, objCommon: KenBurnsConfig, inpaint: bool = True, verbose: bool = False,
                          to_numpy: bool = True):
-        if objCommon.depth_field:
-            raise NotImplementedError("bokeh depth-of-field (SURVEY 8f rank 2) is not built yet: set depth_field=False")
         L = _lib.load()
         with torch.no_grad():
             W, H = objCommon['intWidth'], objCommon['intHeight']
             oF, oT = objSettings['objFrom'], objSettings['objTo']
-            wf = ops.WarpFrame(H, W, self.device)
+            wf = ops.WarpFrame(H, W, self.device, keep_render=bool(objCommon.depth_field))
+            focal_start, focal_end = 0, 255
             steps = objSettings['fltSteps']
             out = torch.empty((len(steps), H, W, 3), dtype=torch.uint8, device=self.device)
             pw, ph = max(oF['intCropWidth'], oT['intCropWidth']), max(oF['intCropHeight'], oT['intCropHeight'])
@@ -454,7 +453,27 @@ class KenBurnsPipeline:
                 d_from = objCommon['objDepthrange'][0]
                 d_to = d_from * (cwid / max(oF['intCropWidth'], oT['intCropWidth']))
                 shift = ops.shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, objCommon)
-                frame, _ = wf(pts, rgb, dep, objCommon['fltFocal'], objCommon['fltBaseline'], shift)
+                frame, render = wf(pts, rgb, dep, objCommon['fltFocal'], objCommon['fltBaseline'], shift)
+                if objCommon.depth_field:                                         # kenburns_effect.py:1042-1067
+                    depth_u8 = ops.colorize_gray_r(render[0, 3])
+                    if k == 0:
+                        ins = objCommon.instances
+                        if ins is not None and not ins.is_empty:
+                            focal_end = -1
+                            for m in ins.masks:
+                                vals = depth_u8[m.to(self.device)]
+                                if vals.numel() == 0:
+                                    continue
+                                sv_, _ = torch.sort(vals)
+                                nn_ = sv_.numel()
+                                dm = float(sv_[nn_ // 2].item()) if nn_ % 2 else (float(sv_[nn_ // 2 - 1].item()) + float(sv_[nn_ // 2].item())) / 2.0
+                                if dm > focal_end:
+                                    focal_end = dm
+                            focal_start = 255 if abs(255 - focal_end) > abs(0 - focal_end) else 0
+                    focal_int = 1 / (1 + np.exp((0.5 - fltStep) * objCommon.dof_speed))
+                    focal_plane = focal_int * focal_end + (1 - focal_int) * focal_start
+                    frame = ops.bokeh_blur(frame, depth_u8, 32, objCommon.lightness_factor, focal_plane=focal_plane, use_cuda=True,
+                                           depth_factor=objCommon.depth_factor)
                 check(L.csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0),
                                            ptr(out[k]), stream_ptr()), "crop_resize")
             frames = [f for f in out.cpu().numpy()] if to_numpy else out

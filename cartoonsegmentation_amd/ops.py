@@ -168,3 +168,72 @@ class WarpFrame:
                                          f64(fltFocal), f64(fltBaseline), sx, sy, sz, ptr(self.scratch),
                                          ptr(self.render), ptr(self.frame), st), "warp_frame")
         return self.frame, self.render
+
+
+# ---- bokeh depth-of-field (utils/effects.py:143-181, depth_modules/zoedepth/utils/misc.py:97-135) ---------------------
+import math as _math
+
+import numpy as _np
+
+_GRAY_R_LUT = None
+
+
+def _percentile_linear(sorted_vals, q):
+    """np.percentile(..., method='linear') on an ascending device tensor (two element reads)"""
+    n = sorted_vals.numel()
+    vi = (n - 1) * (q / 100.0)
+    lo = int(_math.floor(vi)); hi = min(lo + 1, n - 1)
+    a, b = float(sorted_vals[lo].item()), float(sorted_vals[hi].item())
+    t = vi - lo
+    r = a + (b - a) * t if t < 0.5 else b - (b - a) * (1 - t)          # numpy _lerp
+    return float(_np.float32(r))
+
+
+def colorize_gray_r(tenValue):
+    """colorize(value, cmap='gray_r')[..., 0] -> uint8 tensor (same shape, squeezed); vmin/vmax = 2nd / 85th percentile"""
+    global _GRAY_R_LUT
+    v = _dev(tenValue.reshape(-1), "tenValue")
+    s, _ = torch.sort(v)
+    vmin, vmax = _percentile_linear(s, 2), _percentile_linear(s, 85)
+    if _GRAY_R_LUT is None or _GRAY_R_LUT.device != v.device:
+        # matplotlib: lut = 1 - linspace(0,1,256) (float64); bytes=True -> (lut*255).astype(uint8)  [truncation, not 255-k]
+        _GRAY_R_LUT = torch.from_numpy(((1.0 - _np.linspace(0.0, 1.0, 256)) * 255).astype(_np.uint8)).to(v.device)
+    idx = torch.empty(v.numel(), dtype=torch.uint8, device=v.device)
+    check(_lib.load().csm_colorize_gray_r(ptr(v), ptr(idx), i64(v.numel()), f32(vmin), f32(vmax), stream_ptr()), "colorize")
+    # kernel returns 255 - k; map k through the exact matplotlib byte LUT
+    return _GRAY_R_LUT[(255 - idx.long())].reshape(tenValue.squeeze().shape)
+
+
+def bokeh_blur(img, depth, num_samples=32, lightness_factor=10, depth_factor=2, use_cuda=False, focal_plane=None):
+    """bokeh_blur -- utils/effects.py:143-181.  img uint8 HxWx3 and depth uint8/float HxW as device tensors (numpy inputs are
+    uploaded); returns a uint8 HxWx3 DEVICE tensor.  `use_cuda` is accepted for signature compatibility (always device)."""
+    L = _lib.load()
+    dev = img.device if isinstance(img, torch.Tensor) else torch.device('cuda', torch.cuda.current_device())
+    img_d = (img if isinstance(img, torch.Tensor) else torch.from_numpy(_np.ascontiguousarray(img))).to(dev).contiguous()
+    H, W = int(img_d.shape[0]), int(img_d.shape[1])
+    n = H * W
+    d8 = (depth if isinstance(depth, torch.Tensor) else torch.from_numpy(_np.ascontiguousarray(depth))).to(dev)
+    if depth_factor != 1 or d8.dtype != torch.uint8:
+        raise NotImplementedError("bokeh_blur: the hot path calls it with the uint8 colorized depth and depth_factor=1 "
+                                  "(configs/3dkenburns.yaml:47)")
+    d8 = d8.contiguous()
+    df = d8.float()
+    if focal_plane is None:
+        raise NotImplementedError("bokeh_blur without focal_plane is not used by the pipeline")
+    fp = float(_np.float32(focal_plane))
+    dmax = float(df.max().item())
+    t = dmax - (df - fp).abs()
+    mn = float(t.min().item())
+    mx2 = float((t - mn).max().item())
+    dm = torch.empty((H, W), dtype=torch.float32, device=dev)
+    check(L.csm_bokeh_depth(ptr(d8), ptr(dm), i64(n), f32(dmax), f32(fp), f32(mn), f32(mx2), stream_ptr()), "bokeh_depth")
+    hi = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    check(L.csm_bokeh_highlight(ptr(img_d), ptr(hi), i64(n * 3), f32(lightness_factor), stream_ptr()), "bokeh_highlight")
+    a, b, c = torch.empty_like(hi), torch.empty_like(hi), torch.empty_like(hi)
+    PI = _math.pi
+    for src, dst, (dx, dy) in ((hi, a, (0, 1)), (a, b, (_math.cos(-PI / 6), _math.sin(-PI / 6))),
+                               (b, c, (_math.cos(-PI * 5 / 6), _math.sin(-PI * 5 / 6)))):
+        check(L.csm_bokeh_pass(ptr(src), ptr(dm), ptr(dst), i32(H), i32(W), i32(num_samples), f32(dx), f32(dy), stream_ptr()), "bokeh_pass")
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    check(L.csm_bokeh_finish(ptr(b), ptr(c), ptr(out), i64(n * 3), f32(lightness_factor), stream_ptr()), "bokeh_finish")
+    return out

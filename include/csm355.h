@@ -225,6 +225,23 @@ int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *
 int csm_crop_resize_u8(const uint8_t *frame_hwc, int H, int W, int patch_h, int patch_w, float center_x, float center_y,
                        uint8_t *out_hwc, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Bokeh depth-of-field (utils/effects.py:12-181; kenburns_effect.py:1042-1067)
+ * ---------------------------------------------------------------------------------- */
+/* kernel_bokeh   utils/effects.py:16-74 : one depth-weighted `nsamples`-tap line blur along (dx,dy); img/out fp32 HWC
+ * [H,W,3] (the reference kernel indexes raw HWC memory), depth fp32 [H,W] (already x 0.0005). */
+int csm_bokeh_pass(const float *img_hwc, const float *depth, float *out_hwc, int H, int W, int nsamples, float dx, float dy,
+                   void *stream);
+/* (img/255)^lightness  utils/effects.py:155-156 ; n = H*W*3 */
+int csm_bokeh_highlight(const uint8_t *img_hwc, float *out_hwc, int64_t n, float lightness, void *stream);
+/* ((diag+rhom)/2)^(1/lightness)*255 -> uint8  utils/effects.py:172,179-180 */
+int csm_bokeh_finish(const float *diag_hwc, const float *rhom_hwc, uint8_t *out_hwc, int64_t n, float lightness, void *stream);
+/* depth map of bokeh_blur  utils/effects.py:146-153,162-163: out = (1 - ((dmax - |d - focal|) - mn) / mx2) * 0.0005 ;
+ * dmax = max(d), mn = min(dmax - |d-focal|), mx2 = max(that - mn) are scalar reductions supplied by the caller. */
+int csm_bokeh_depth(const uint8_t *depth_u8, float *out, int64_t n, float dmax, float focal_plane, float mn, float mx2, void *stream);
+/* colorize(value, cmap='gray_r')[...,0]  depth_modules/zoedepth/utils/misc.py:97-135 (vmin/vmax = 2nd/85th percentile) */
+int csm_colorize_gray_r(const float *value, uint8_t *out, int64_t n, float vmin, float vmax, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,3 +154,38 @@ def inpaint_forward(img, disp, shift, segmasks, W, H, focal, baseline, ctx_prog,
     image = (oi * (si + f32(0.0000001)) + mi).astype(f32)
     dsp = (od * (sd + f32(0.0000001)) + md).astype(f32)
     return dict(existing=existing, image=np.clip(image, 0.0, 1.0), disparity=np.where(dsp > 0, dsp, 0).astype(f32), segmasks=seg_r)
+
+
+def gray_r_lut():
+    return ((1.0 - np.linspace(0.0, 1.0, 256)) * 255).astype(np.uint8)
+
+
+def colorize_gray_r(value):
+    """depth_modules/zoedepth/utils/misc.py:97-135 with cmap='gray_r', channel 0"""
+    v = value.astype(np.float32).squeeze()
+    vmin, vmax = np.float32(np.percentile(v, 2)), np.float32(np.percentile(v, 85))
+    x = ((v - vmin) / (vmax - vmin)).astype(np.float32) if vmin != vmax else v * np.float32(0)
+    xa = (x * np.float32(256)).astype(np.float32)
+    xa[xa == 256] = 255
+    under, over = xa < 0, xa >= 256
+    k = xa.astype(np.int64)
+    k[under] = 0; k[over] = 255
+    return gray_r_lut()[np.clip(k, 0, 255)]
+
+
+def bokeh_blur(img, depth_u8, num_samples, lightness_factor, focal_plane):
+    """utils/effects.py:143-181 (use_cuda branch, depth_factor == 1)"""
+    L = oseg.lib()
+    H, W = img.shape[:2]
+    d = depth_u8.astype(np.float32)
+    d = d.max() - np.abs(d - np.float32(focal_plane))
+    d = d - d.min()
+    d = d.astype(np.float32) / d.max()
+    d = ((np.float32(1) - d) * np.float32(0.0005)).astype(np.float32)
+    hi = np.power(img.astype(np.float32) / np.float32(255), np.float32(lightness_factor)).astype(np.float32)
+    a, b, c = np.empty_like(hi), np.empty_like(hi), np.empty_like(hi)
+    PI = math.pi
+    for src, dst, (dx, dy) in ((hi, a, (0, 1)), (a, b, (math.cos(-PI / 6), math.sin(-PI / 6))), (b, c, (math.cos(-PI * 5 / 6), math.sin(-PI * 5 / 6)))):
+        L.orc_bokeh_pass(_p(np.ascontiguousarray(src)), _p(np.ascontiguousarray(d)), _p(dst), ci(H), ci(W), ci(num_samples), cf(dx), cf(dy))
+    bl = np.power((b + c) / np.float32(2), np.float32(1 / lightness_factor))
+    return (bl * np.float32(255)).astype(np.uint8)

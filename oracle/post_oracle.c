@@ -318,3 +318,25 @@ void orc_crop_resize_u8(const uint8_t *frame, int H, int W, int ph, int pw, floa
             }
         }
 }
+
+/* kernel_bokeh  (utils/effects.py:16-74), sequential */
+void orc_bokeh_pass(const float *img, const float *depth, float *out, int H, int W, int nsamples, float dx, float dy)
+{
+    int im_size = H < W ? H : W, off = nsamples / 2;
+    for (int64_t pix = 0; pix < (int64_t)H * W; ++pix) {
+        int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
+        float d = depth[pix], ddx = dx * d, ddy = dy * d;
+        for (int c = 0; c < 3; ++c) {
+            float weight = 0.0f, color = 0.0f;
+            for (int s = 0; s < nsamples; ++s) {
+                int sp = (s - off) * im_size;
+                int x_ = x + (int)roundf(ddx * (float)sp), y_ = y + (int)roundf(ddy * (float)sp);
+                if (x_ >= W || y_ >= H || x_ < 0 || y_ < 0) continue;
+                float w_ = depth[(int64_t)y_ * W + x_];
+                weight += w_;
+                color += img[((int64_t)y_ * W + x_) * 3 + c] * w_;
+            }
+            out[pix * 3 + c] = weight != 0.0f ? color / weight : img[pix * 3 + c];
+        }
+    }
+}

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/bokeh_*.npz from the REFERENCE's utils/effects.py::bokeh_blur (its kernel_bokeh CUDA text runs
+through cuda_on_cpu.h) and depth_modules/zoedepth/utils/misc.py::colorize (matplotlib is available in the build
+container).  Build container only."""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_loader  # noqa: E402
+
+ref_loader.install_stubs()
+nb = types.ModuleType('numba'); nb.jit = lambda *a, **k: (lambda f: f); nb.njit = lambda f=None, **k: (f if f else (lambda g: g))
+sys.modules['numba'] = nb
+sys.modules['cv2'] = types.ModuleType('cv2')
+sys.modules['requests'] = types.ModuleType('requests')
+tvt = sys.modules['torchvision.transforms']; tvt.ToTensor = object
+ref_loader._bare('utils')
+ref_loader.load_by_path('utils.cupy_utils', 'utils/cupy_utils.py')
+fx = ref_loader.load_by_path('utils.effects', 'utils/effects.py')
+for n in ('depth_modules', 'depth_modules.zoedepth', 'depth_modules.zoedepth.utils'):
+    ref_loader._bare(n)
+misc = ref_loader.load_by_path('depth_modules.zoedepth.utils.misc', 'depth_modules/zoedepth/utils/misc.py')
+
+g = np.random.default_rng(42)
+H, W = 240, 320
+from cartoonsegmentation_amd import synth  # noqa: E402
+img = synth.image_u8(H, W, 9)
+yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+depth_f = (300.0 + 4.0 * yy + 150.0 / (1.0 + np.exp((np.hypot(xx - 130, yy - 110) - 60) / 1.5))).astype(np.float32)
+col = misc.colorize(depth_f.copy(), cmap='gray_r')
+depth_u8 = col[..., 0]
+out = {}
+for tag, fp in (('fp100', 100.0), ('fp17', 17.25)):
+    out['blur_' + tag] = fx.bokeh_blur(img, depth_u8, 32, 13, focal_plane=fp, use_cuda=True, depth_factor=1)
+# raw single pass of kernel_bokeh on float data
+imf = (img.astype(np.float32) / 255)
+dn = (g.uniform(0, 1, (H, W)).astype(np.float32) * 0.0005).astype(np.float32)
+t_img, t_d = fx.np2flatten_tensor(imf, True), fx.np2flatten_tensor(dn, True)
+one = fx.ftensor2img(fx.bokeh_filter_cupy(t_img, t_d, np.cos(-np.pi / 6), np.sin(-np.pi / 6), H, W, 32), H, W)
+np.savez_compressed(os.path.join(HERE, 'bokeh_240x320.npz'), img=img, depth_f=depth_f, depth_u8=depth_u8, dn=dn,
+                    one_pass=one, **out)
+print('ok', depth_u8.min(), depth_u8.max(), out['blur_fp100'].shape, out['blur_fp100'].dtype, np.abs(out['blur_fp100'].astype(int) - img).mean())

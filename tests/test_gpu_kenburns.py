@@ -135,3 +135,35 @@ def test_refine_depth_vs_reference_fixture():
     pipe = KenBurnsPipeline(KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', refine_crf=False, default_depth_refine=True))
     y = pipe.refine_depth(torch.from_numpy(g['img']).to(pipe.device), torch.from_numpy(g['dsp']).to(pipe.device)).cpu().numpy()
     assert np.abs(y - g['y']).max() / np.abs(g['y']).max() < 1e-4          # reference Refine module, fp32 tolerance
+
+
+def test_bokeh_and_colorize_vs_oracle_and_reference():
+    from cartoonsegmentation_amd import ops
+    from oracle import kenburns as okb
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "bokeh_240x320.npz")))
+    d8 = ops.colorize_gray_r(torch.from_numpy(g['depth_f']).cuda()).cpu().numpy()
+    assert np.array_equal(d8, g['depth_u8'])                                     # == reference colorize (matplotlib)
+    from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, f32, check
+    imf = torch.from_numpy((g['img'].astype(np.float32) / 255)).cuda().contiguous()
+    dn = torch.from_numpy(g['dn']).cuda()
+    one = torch.empty_like(imf)
+    check(load().csm_bokeh_pass(ptr(imf), ptr(dn), ptr(one), i32(240), i32(320), i32(32), f32(np.cos(-np.pi / 6)), f32(np.sin(-np.pi / 6)),
+                                stream_ptr()))
+    assert np.array_equal(one.cpu().numpy(), g['one_pass'])                      # kernel_bokeh: bit-exact vs the reference text
+    for tag, fp in (("fp100", 100.0), ("fp17", 17.25)):
+        out = ops.bokeh_blur(torch.from_numpy(g['img']).cuda(), torch.from_numpy(g['depth_u8']).cuda(), 32, 13, depth_factor=1,
+                             use_cuda=True, focal_plane=fp).cpu().numpy()
+        ref = okb.bokeh_blur(g['img'], g['depth_u8'], 32, 13, fp)
+        for other in (ref, g['blur_' + tag]):
+            diff = np.abs(out.astype(np.int32) - other.astype(np.int32))
+            assert diff.max() <= 1 and (diff == 0).mean() > 0.995                # powf last-ulp differences only
+
+
+def test_shipped_yaml_configuration_runs_end_to_end(pipe_and_cfg):
+    """depth_field=True + inpainting = configs/3dkenburns.yaml's frame loop"""
+    pipe, kc, img, inst = pipe_and_cfg
+    kc.depth_field, kc.num_frame = True, 4
+    frames = pipe.autozoom(kc)
+    kc.depth_field = False
+    assert len(frames) == 4 and frames[0].shape == (kc.int_height, kc.int_width, 3)
+    assert all(np.isfinite(f.astype(np.float32)).all() for f in frames)
