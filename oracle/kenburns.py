@@ -160,10 +160,22 @@ def gray_r_lut():
     return ((1.0 - np.linspace(0.0, 1.0, 256)) * 255).astype(np.uint8)
 
 
+def _percentile(v, q):
+    """np.percentile(v, q) with method 'linear' as numpy 1.26 (the reference's pinned version, conda_env.yaml:280)
+    evaluates it: virtual index and lerp in float64.  (numpy >= 2 casts q to the array dtype first and differs in the
+    last digits, which is why the fixture -- generated under numpy 2.2 -- is compared with a +-1 level tolerance.)"""
+    s = np.sort(v.reshape(-1)); n = s.size
+    vi = (n - 1) * (q / 100.0)
+    lo = int(math.floor(vi)); hi = min(lo + 1, n - 1)
+    a, b, t = float(s[lo]), float(s[hi]), vi - lo
+    r = a + (b - a) * t if t < 0.5 else b - (b - a) * (1 - t)
+    return np.float32(r)
+
+
 def colorize_gray_r(value):
     """depth_modules/zoedepth/utils/misc.py:97-135 with cmap='gray_r', channel 0"""
     v = value.astype(np.float32).squeeze()
-    vmin, vmax = np.float32(np.percentile(v, 2)), np.float32(np.percentile(v, 85))
+    vmin, vmax = _percentile(v, 2), _percentile(v, 85)
     x = ((v - vmin) / (vmax - vmin)).astype(np.float32) if vmin != vmax else v * np.float32(0)
     xa = (x * np.float32(256)).astype(np.float32)
     xa[xa == 256] = 255
