@@ -166,6 +166,8 @@ class FrameWorkload(Workload):
                              refine_crf=False, depth_field=False, focal=size / 2.0,
                              mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 720})
         self.pipe = KenBurnsPipeline(cfg, device=str(device))
+        self.pipe.max_instances = self.INSTANCES          # synthetic weights score every prior ~0.49: cap like infer(max_instances=)
+        self.pipe.overlap_depth = os.environ.get("CSM_OVERLAP_DEPTH", "1") == "1"
         self.img = torch.from_numpy(synth.image_u8(size, size, 1234 + rank)).to(device)
         self.wf = ops.WarpFrame(size, size, device)
         self.out = torch.empty((size, size, 3), dtype=torch.uint8, device=device)
@@ -174,9 +176,8 @@ class FrameWorkload(Workload):
     def step(self):
         from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, f32, check
         pipe = self.pipe
-        inst = pipe.animeinsseg.infer(self.img, 0.3, pipe.cfg.mask_refine_kwargs, max_instances=self.INSTANCES, det_size=640)
-        self.n_inst = len(inst)
-        kc = pipe.generate_kenburns_config(self.img, instances=inst)
+        kc = pipe.generate_kenburns_config(self.img)          # seg (main stream) || LeReS (side stream) -> adjust -> points
+        self.n_inst = len(kc.instances)
         W, H = kc['intWidth'], kc['intHeight']
         d_from = kc['objDepthrange'][0]
         shift = self.ops.shift_vector({'fltShiftU': 30.0, 'fltShiftV': -20.0, 'fltDepthFrom': d_from, 'fltDepthTo': d_from / 1.25}, kc)

@@ -66,6 +66,7 @@ struct ConvArgs {
     int m_tiles;
     int ksplit;                        // >1: blockIdx.z = g*ksplit + s, raw partial sums go to `partial`
     float *partial;                    // [M][ksplit*cout] (groups == 1 only)
+    int dbg;                           // tuning aid: 1 = no global loads, 2 = no MFMA, 4 = no LDS stores, 8 = no epilogue stores
 };
 
 constexpr int kLdsLd = 36;  // floats per LDS row: 32 + 4 pad (conflict-free b128 reads, see MI355X LDS notes)
@@ -139,22 +140,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
     for (int it = 0; it < B_IT; ++it)
         wp[it] = a.w + ((int64_t)g * Tall + c_begin) * a.npad * 32 + (int64_t)(n0 + ((tid + NT * it) >> 3)) * 32 + c4;
 
-    float4 ra[A_IT], rb[B_IT];
-    auto gload = [&]() {
+    // two register sets: loads run TWO chunks ahead of the MFMAs (set = parity of the chunk), so a chunk's HBM/L2 latency
+    // is covered by two full compute phases; hipcc emits the counted vmcnt that leaves the younger set in flight.
+    float4 ra[2][A_IT] = {}, rb[2][B_IT] = {};
+    unsigned vbits[2] = {0u, 0u};           // validity of each load of a set (A: bit it, B: bit 8+it); zeros are applied at the LDS store
+    auto gload = [&](const int set, const bool live) {   // always issues the same number of loads (see below)
         const int64_t toff = ((int64_t)l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32;
-        const bool cv = l_cb * 32 + c4 < a.cin_g;
+        const bool cv = live && !(a.dbg & 1) && l_cb * 32 + c4 < a.cin_g;
+        unsigned vb = 0u;
+        // Loads are UNCONDITIONAL and their count per step is fixed (dead lanes / dead steps read a safe address): a branch
+        // around a load makes hipcc fall back to vmcnt(0..3) at the next use, which would serialise the two-deep prefetch.
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             bool v = cv && ((vmask[it] >> l_tap) & 1ull);
-            ra[it] = v ? *reinterpret_cast<const float4 *>(rowp[it] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *p = v ? rowp[it] + toff : a.in.p;
+            ra[set][it] = *reinterpret_cast<const float4 *>(p);
+            vb |= v ? (1u << it) : 0u;
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             int row = (tid + NT * it) >> 3;
-            bool v = n0 + row < a.npad && (B_FULL || row < BN);
-            rb[it] = v ? *reinterpret_cast<const float4 *>(wp[it]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bool v = live && !(a.dbg & 1) && n0 + row < a.npad && (B_FULL || row < BN);
+            const float *p = v ? wp[it] : a.w;
+            rb[set][it] = *reinterpret_cast<const float4 *>(p);
+            vb |= v ? (1u << (8 + it)) : 0u;
             wp[it] += (int64_t)a.npad * 32;
         }
+        vbits[set] = vb;
         if (++l_cb == a.ncb) { l_cb = 0; ++l_tap; if (++l_kw == a.kw) { l_kw = 0; ++l_kh; } }
     };
     auto put = [&](float *dst, float4 v) {
@@ -165,13 +177,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
             *reinterpret_cast<float2 *>(b8 + 4) = make_float2(v.y, v.w);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const int set, int buf) {
+        if (a.dbg & 4) return;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
-            if (A_FULL || ((tid + NT * it) >> 3) < BM) put(lds + buf * kStage + ((tid + NT * it) >> 3) * kLdsLd, ra[it]);
+            if (A_FULL || ((tid + NT * it) >> 3) < BM)
+                put(lds + buf * kStage + ((tid + NT * it) >> 3) * kLdsLd, (vbits[set] >> it) & 1u ? ra[set][it] : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
         for (int it = 0; it < B_IT; ++it)
-            if (B_FULL || ((tid + NT * it) >> 3) < BN) put(lds + buf * kStage + (BM + ((tid + NT * it) >> 3)) * kLdsLd, rb[it]);
+            if (B_FULL || ((tid + NT * it) >> 3) < BN)
+                put(lds + buf * kStage + (BM + ((tid + NT * it) >> 3)) * kLdsLd, (vbits[set] >> (8 + it)) & 1u ? rb[set][it] : make_float4(0.f, 0.f, 0.f, 0.f));
     };
 
     // accumulators start at the (folded-BN) bias
@@ -222,27 +237,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
         }
     };
 
-    gload();
-    lstore(c_begin & 1);
-    __syncthreads();
     int cb = c_begin % a.ncb;
-    for (int chunk = c_begin; chunk < T; ++chunk) {
+    auto compute = [&](int chunk) {
         const int buf = chunk & 1;
-        if (chunk + 1 < T) gload();
         int rem = a.cin_g - cb * 32;
         if (++cb == a.ncb) cb = 0;
         const float *A = lds + buf * kStage + (MT * wm + li) * kLdsLd + (MT == 32 ? 4 : 2) * lh;
         const float *B = lds + buf * kStage + (BM + MT * TN * wn + li) * kLdsLd + (MT == 32 ? 4 : 2) * lh;
-        if (rem >= 32) {
+        if (a.dbg & 2) {
+        } else if (rem >= 32) {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) kblock(A, B, kb);
         } else {
             int nkb = (rem + 7) >> 3;
             for (int kb = 0; kb < nkb; ++kb) kblock(A, B, kb);
         }
-        if (chunk + 1 < T) lstore(buf ^ 1);
+    };
+    gload(0, true);                             // chunk c_begin     -> set 0
+    lstore(0, c_begin & 1);
+    gload(1, c_begin + 1 < T);                  // chunk c_begin + 1 -> set 1, stays in flight
+    __syncthreads();
+    int chunk = c_begin;
+    for (; chunk + 1 < T; chunk += 2) {
+        gload(0, chunk + 2 < T);                // two ahead
+        compute(chunk);
+        lstore(1, (chunk + 1) & 1);             // needs only the older set: counted vmcnt keeps set 0 in flight
+        __syncthreads();
+        gload(1, chunk + 3 < T);
+        compute(chunk + 1);
+        lstore(0, (chunk + 2) & 1);             // (a dead step stores zeros into the idle buffer)
         __syncthreads();
     }
+    if (chunk < T) compute(chunk);
 
     // epilogue.  MT=32: lane holds column li, rows (r&3)+8*(r>>2)+4*lh.  MT=16: column li, rows 4*lh + r.
 #pragma unroll
@@ -256,6 +282,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
             int m = m0 + MT * wm + row;
             if (m >= a.M) continue;
             float v = acc[tn][r];
+            if (a.dbg & 8) { if (v == 123.456f) a.out.p[0] = v; continue; }
             if (a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
             if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
             v = apply_act(v, a.act, slope);
@@ -447,14 +474,15 @@ int launch_conv(const ConvArgs &a0, hipStream_t st) {
 // two-stage pipeline, so the default is the 64x64 tile (4 blocks = 16 waves per CU); narrow outputs get narrow tiles.
 enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CFG_128x32 = 4, CFG_64x16 = 5, CFG_COUNT = 6 };
 static int g_force_cfg = -1;
+static int g_dbg = 0;
 
 static int choose_cfg(int M, int N, int groups) {
     (void)M; (void)groups;
     if (g_force_cfg >= 0 && g_force_cfg < CFG_COUNT) return g_force_cfg;
     if (N <= 16) return CFG_64x16;
     if (N <= 32) return CFG_128x32;
-    // enough 128x128 tiles for >= 1 block of 8 waves per CU, twice over: the higher arithmetic intensity wins
-    if (N >= 128 && (int64_t)((M + 127) / 128) * ((N + 127) / 128) * groups >= 384) return CFG_128x128_8w;
+    // With the two-chunk-ahead loader the 64x64 tile wins on every layer measured (r01 sweep, second pass): the 128x128
+    // variants run out of registers (spills at the 128-VGPR occupancy bound) and are kept for tuning only.
     return CFG_64x64;
 }
 
@@ -515,6 +543,7 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 if ((in.ld & 3) || (op.cin_g & 3) || (((uintptr_t)in.p) & 15)) {
                     csm::set_error("op %d: conv input must be 16-byte aligned with channels %% 4 == 0", i); return CSM_ERR_ARG;
                 }
+                a.dbg = g_dbg;
                 rc = launch_conv_cfg(choose_cfg(a.M, op.cout_g, op.groups), a, st);
                 if (rc) return rc;
                 break;
@@ -599,4 +628,7 @@ extern "C" int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_t
 }
 
 // debug / tuning knob: force a conv tile configuration (-1 = cost model).  Not part of the stable ABI.
-extern "C" int csm_debug_force_conv_cfg(int cfg) { g_force_cfg = cfg; return CSM_OK; }
+extern "C" int csm_debug_force_conv_cfg(int cfg) {
+    if (cfg >= 0) { g_force_cfg = cfg & 0xff; g_dbg = cfg >> 8; } else { g_force_cfg = -1; g_dbg = 0; }
+    return CSM_OK;
+}

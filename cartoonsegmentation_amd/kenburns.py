@@ -118,17 +118,24 @@ def depth_adjustment_animesseg(instances, tenDisparity, tenImage, use_medium=Fal
     resized = tenDisparity.shape[2:] != tenImage.shape[2:]
     adj = torch.nn.functional.interpolate(tenDisparity, size=tuple(tenImage.shape[2:]), mode='bilinear', align_corners=False) \
         if resized else tenDisparity
+    rowidx = torch.arange(adj.shape[2], device=adj.device).view(1, 1, -1, 1)
     for m in masks:
         plane = adj * m
-        if plane.sum().item() == 0:
-            continue
-        if not use_medium:
-            cols, rows = (plane.sum([2], True) > 0.0).flatten().nonzero(), (plane.sum([3], True) > 0.0).flatten().nonzero()
-            top, bottom = rows[0].item(), rows[-1].item()
-            _ = cols[0].item(), cols[-1].item()
-            adj = ((1.0 - m) * adj) + (m * plane[:, :, int(round(top + (0.97 * (bottom - top)))):, :].max())
-        else:
+        if use_medium:
+            if plane.sum().item() == 0:
+                continue
             adj[plane > 0] = adj[plane > 0].median()
+            continue
+        # sync-free form of kenburns_effect.py:68-78: rows of the mask, r0 = round(top + 0.97*(bottom-top)) (python round =
+        # half-to-even, as torch.round), value = max of the plane from row r0 down; `plane.sum() == 0` -> unchanged.
+        has = (plane.sum([3], True) > 0.0)
+        anyrow = has.any()
+        top = torch.where(has, rowidx, rowidx.new_full((), adj.shape[2])).min()
+        bottom = torch.where(has, rowidx, rowidx.new_full((), -1)).max()
+        r0 = torch.round(top.double() + (0.97 * (bottom - top).double())).long()
+        val = torch.where(rowidx >= r0, plane, plane.new_full((), float('-inf'))).max()
+        new = ((1.0 - m) * adj) + (m * val)
+        adj = torch.where(anyrow & (plane.sum() != 0), new, adj)
     if resized:
         return torch.nn.functional.interpolate(adj, size=tuple(tenDisparity.shape[2:]), mode='bilinear', align_corners=False)
     return adj
@@ -149,6 +156,9 @@ class KenBurnsPipeline:
         self.animeinsseg = None
         self._leres, self._leres_weights, self._leres_ws = {}, None, None
         self._refine_ws, self._refine_progs = None, {}
+        self.max_instances = 100                 # AnimeInsSeg.infer default (animeinsseg/__init__.py:417)
+        self.overlap_depth = True                # MI355X: LeReS runs on a second HIP stream next to the segmentation nets
+        self._side_stream = None
         self.set_detector(cfg.detector)
         self.set_depth_estimation(cfg.depth_est)
         if self.cfg.default_depth_refine:
@@ -325,16 +335,17 @@ class KenBurnsPipeline:
         return depth
 
     def run_instance_segmentation(self, img, scale_down_to_maxsize=True):
-        inst = self.animeinsseg.infer(img, self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None, output_type='tensor')   # :869-872
+        inst = self.animeinsseg.infer(img, self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None, output_type='tensor',
+                                      max_instances=self.max_instances)                                              # :869-872
         return inst, img
 
-    def infer_disparity(self, img, instances=None, img_tensor=None, kcfg=None, **kw):
+    def infer_disparity(self, img, instances=None, img_tensor=None, kcfg=None, coarse=None, **kw):
         img_d = self.animeinsseg._upload(img)
         if instances is None:
             instances, _ = self.run_instance_segmentation(img, scale_down_to_maxsize=False)
         if img_tensor is None:
             img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
-        disparity = self._depth_est(img_tensor, img_d)
+        disparity = self._depth_est(img_tensor, img_d) if coarse is None else coarse
         disparity = depth_adjustment_animesseg(instances, disparity, img_tensor, self.cfg.depthest_use_medium)
         if self.cfg.default_depth_refine:                                        # kenburns_effect.py:619-622
             disparity = self.refine_depth(img_tensor, disparity)
@@ -347,7 +358,24 @@ class KenBurnsPipeline:
         if isinstance(img, str):
             raise NotImplementedError("pass a uint8 BGR ndarray (image decoding is not on the hot path)")
         with torch.no_grad():
-            if instances is None:
+            coarse = None
+            if instances is None and self.overlap_depth:
+                # Segmentation (RTMDet + ISNet) and the depth CNN only share the input image: run LeReS on a second HIP stream
+                # so its large GEMM-like layers fill the CUs that the detector's small feature maps leave idle.  Results are
+                # identical to the sequential order of the reference (kenburns_effect.py:914-923).
+                main = torch.cuda.current_stream(self.device)
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(self.device)
+                side = self._side_stream
+                img_dev = self.animeinsseg._upload(img)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    coarse = self._depth_est(None, img_dev)
+                instances, _ = self.run_instance_segmentation(img_dev, scale_down_to_maxsize=False)
+                main.wait_stream(side)
+                coarse.record_stream(main)
+                img = img_dev if isinstance(img, torch.Tensor) else img
+            elif instances is None:
                 instances, _ = self.run_instance_segmentation(img, scale_down_to_maxsize=False)
             H, W = img.shape[:2]
             if scaledown_size(H, W, self.cfg.max_size) != (H, W):
@@ -358,14 +386,15 @@ class KenBurnsPipeline:
             img_d = self.animeinsseg._upload(img)
             img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
             cfg = self.cfg.copy()
-            disparity = self.infer_disparity(img, instances, img_tensor, kcfg=cfg)
+            disparity = self.infer_disparity(img, instances, img_tensor, kcfg=cfg, coarse=coarse)
             disparity = disparity / disparity.max() * self.cfg.baseline
             depth, valid, pts, unaltered = ops.disparity_to_points(disparity, cfg.focal, cfg.baseline)
-            cfg['fltDispmin'], cfg['fltDispmax'] = disparity.min().item(), disparity.max().item()
             crop = depth[0, 0, 128:-128, 128:-128]                      # cv2.minMaxLoc(depth[128:-128,128:-128])
-            amin, amax = int(crop.argmin().item()), int(crop.argmax().item())
-            cw = crop.shape[1]
-            cfg['objDepthrange'] = (float(crop.min().item()), float(crop.max().item()), (amin % cw, amin // cw), (amax % cw, amax // cw))
+            st = torch.stack([disparity.min().double(), disparity.max().double(), crop.min().double(), crop.max().double(),
+                              crop.argmin().double(), crop.argmax().double()]).tolist()          # one host sync for all six scalars
+            cfg['fltDispmin'], cfg['fltDispmax'] = st[0], st[1]
+            amin, amax, cw = int(st[4]), int(st[5]), crop.shape[1]
+            cfg['objDepthrange'] = (st[2], st[3], (amin % cw, amin // cw), (amax % cw, amax // cw))
             cfg['tenRawImage'], cfg['tenRawDisparity'], cfg['tenRawDepth'] = img_tensor, disparity, depth
             cfg['tenRawPoints'], cfg['tenRawUnaltered'] = pts.view(1, 3, -1), unaltered.view(1, 3, -1)
             cfg.inpainted_img = img_tensor.view(1, 3, -1)

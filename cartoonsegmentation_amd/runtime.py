@@ -42,6 +42,12 @@ class CompiledProgram:
                                                   stream_ptr(), ms), "run_program_profile(%s)" % self.prog.name)
         return list(ms)
 
+    def view(self, t):
+        """zero-copy NHWC view [n,h,w,c] of a planned tensor whose buffer holds exactly its channels (e.g. net outputs)"""
+        b = t.buf
+        assert t.coff == 0 and t.c == b.c
+        return self.workspace[b.offset:b.offset + b.n * b.h * b.w * b.c].view(b.n, b.h, b.w, b.c)
+
     def read_view(self, t):
         """debug: copy a planned NHWC view out of the workspace as [n,h,w,c]"""
         b = t.buf

@@ -93,7 +93,7 @@ class AnimeInsSeg:
             blob = torch.load(ckpt, map_location='cpu', weights_only=False)
             self.cfg = config_from_ckpt_cfg(blob['meta']['cfg'])
             self._det_ws = StateDictWeights(blob['state_dict'])
-        self._det_programs, self._det_weights = {}, None
+        self._det_programs, self._det_weights, self._prior_cache = {}, None, {}
         self._refine_programs, self._refine_weights, self._refine_ws = {}, None, None
         self.refine_method = None
         self.set_refine_method(**(refine_kwargs or {'refine_method': 'none'}))
@@ -134,6 +134,14 @@ class AnimeInsSeg:
             self._det_weights = cp.weights
             self._det_programs[S] = (rp, cp)
         return self._det_programs[S]
+
+    def _priors(self, S, lvl, hl, wl, stride):
+        key = (S, lvl)
+        if key not in self._prior_cache:
+            ys, xs = torch.meshgrid(torch.arange(hl, device=self.device), torch.arange(wl, device=self.device), indexing='ij')
+            st = torch.full_like(xs.reshape(-1), stride)
+            self._prior_cache[key] = torch.stack([xs.reshape(-1) * stride, ys.reshape(-1) * stride, st, st], 1).float()
+        return self._prior_cache[key]
 
     def _refiner(self, n, T):
         if (n, T) not in self._refine_programs:
@@ -195,13 +203,10 @@ class AnimeInsSeg:
         cp.run(x)
         scores_l, boxes_l, priors_l, kern_l, labels_l = [], [], [], [], []
         for lvl, stride in enumerate(cfg.strides):
-            cls = cp.read_view(rp.cls[lvl]).reshape(-1, cfg.num_classes)          # sigmoid fused in rtm_cls epilogue
-            reg = cp.read_view(rp.reg[lvl]).reshape(-1, 4) * float(stride)        # F.relu(rtm_reg) * stride
-            ker = cp.read_view(rp.kern[lvl]).reshape(-1, cfg.num_gen_params)
-            hl, wl = rp.cls[lvl].h, rp.cls[lvl].w
-            ys, xs = torch.meshgrid(torch.arange(hl, device=self.device), torch.arange(wl, device=self.device), indexing='ij')
-            pri = torch.stack([xs.reshape(-1) * stride, ys.reshape(-1) * stride, torch.full_like(xs.reshape(-1), stride),
-                               torch.full_like(xs.reshape(-1), stride)], 1).float()
+            cls = cp.view(rp.cls[lvl]).reshape(-1, cfg.num_classes)               # sigmoid fused in rtm_cls epilogue
+            reg = cp.view(rp.reg[lvl]).reshape(-1, 4) * float(stride)             # F.relu(rtm_reg) * stride
+            ker = cp.view(rp.kern[lvl]).reshape(-1, cfg.num_gen_params)
+            pri = self._priors(S, lvl, rp.cls[lvl].h, rp.cls[lvl].w, stride)      # MlvlPointGenerator(offset=0), cached
             valid = cls > cfg.score_thr                                          # filter_scores_and_topk
             sc = cls[valid]
             idx = valid.nonzero()

@@ -171,3 +171,24 @@ def test_shipped_yaml_configuration_runs_end_to_end(pipe_and_cfg):
     kc.depth_field = False
     assert len(frames) == 4 and frames[0].shape == (kc.int_height, kc.int_width, 3)
     assert all(np.isfinite(f.astype(np.float32)).all() for f in frames)
+
+
+def test_overlapped_depth_equals_sequential():
+    """seg || LeReS on two HIP streams must give exactly the sequential result"""
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd import synth
+    img = synth.image_u8(320, 320, 21)
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=96, max_size=512, refine_crf=False, focal=160.0,
+                         mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 64})
+    pipe = KenBurnsPipeline(cfg)
+    pipe.max_instances = 2
+    pipe.animeinsseg.set_detect_size(96)
+    outs = []
+    for ov in (True, False, True):
+        pipe.overlap_depth = ov
+        kc = pipe.generate_kenburns_config(img)
+        torch.cuda.synchronize()
+        outs.append((kc['tenRawPoints'].clone(), kc['tenRawDepth'].clone(), kc.instances.masks.clone()))
+    for a, b in ((0, 1), (1, 2)):
+        assert all(torch.equal(x, y) for x, y in zip(outs[a], outs[b]))
