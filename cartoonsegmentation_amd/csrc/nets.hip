@@ -10,6 +10,8 @@
 //     (BM pixels x 128 B, fully coalesced because NHWC keeps a pixel's channels contiguous) and the
 //     pre-packed weight tile (BN x 128 B) are register-staged into LDS (row pitch 36 floats =>
 //     conflict-free ds_read_b128) and double buffered, one barrier per chunk.
+//   * global loads run two K-chunks ahead of the MFMAs in two register sets; they are unconditional with a fixed
+//     count per step so that hipcc emits counted s_waitcnt vmcnt(N) instead of draining the queue.
 //   * folded-BN bias initialises the accumulator; activation / residual are fused in the epilogue.
 //   * grouped 3x3 (ResNeXt, 32 groups) runs on the same kernel as block-diagonal 32-channel
 //     super-groups (zero-padded weights): fmaf(x, 0, acc) is exact, so numerics are unchanged.
@@ -468,8 +470,6 @@ int launch_conv(const ConvArgs &a0, hipStream_t st) {
 }
 
 // ---- tile selection ---------------------------------------------------------------------------------------
-// cost model: a tile occupies WM*WN SIMD slots for (K/2)*TN*64 cycles (MT=32) or (K/4)*TN*32 cycles (MT=16),
-// divided by an empirical per-config efficiency; the chip has 256 CUs x 4 SIMDs.  Pick the cheapest config.
 // Measured on the three nets (tools/conv_bench.py --sweep, profiles/): occupancy beats register-tile reuse in this
 // two-stage pipeline, so the default is the 64x64 tile (4 blocks = 16 waves per CU); narrow outputs get narrow tiles.
 enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CFG_128x32 = 4, CFG_64x16 = 5, CFG_COUNT = 6 };
@@ -627,7 +627,8 @@ extern "C" int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_t
     return rc;
 }
 
-// debug / tuning knob: force a conv tile configuration (-1 = cost model).  Not part of the stable ABI.
+// debug / tuning knob: low byte = forced conv tile configuration (-1 = built-in rule), bits 8.. = phase-ablation flags
+// (ConvArgs::dbg).  Not part of the stable ABI.
 extern "C" int csm_debug_force_conv_cfg(int cfg) {
     if (cfg >= 0) { g_force_cfg = cfg & 0xff; g_dbg = cfg >> 8; } else { g_force_cfg = -1; g_dbg = 0; }
     return CSM_OK;

@@ -49,10 +49,17 @@ def synth_tensor(name, shape, kind):
 
 
 class SynthWeights:
+    """closed-form weights.  With CSM_WEIGHTS_PLACEHOLDER=1 (ranks != 0 of a multi-GPU job) only shapes are produced
+    (zeros): the packed device buffers are then filled by the RCCL broadcast from rank 0 (shard.broadcast_weights)."""
+
     def __init__(self, prefix=""):
+        import os
         self.prefix = prefix
+        self.placeholder = os.environ.get("CSM_WEIGHTS_PLACEHOLDER", "0") == "1"
 
     def get(self, name, shape, kind):
+        if self.placeholder:
+            return np.zeros(tuple(shape), np.float32)
         return synth_tensor(self.prefix + name, tuple(shape), kind)
 
 
