@@ -90,6 +90,11 @@ class KenBurnsConfig:
     inpainted_depth = None
     inpainted_points = None
     save_path = r''
+    stage_inpainted_imgs = None
+    stage_inpainted_masks = None
+    stage_depth_coarse = None
+    stage_depth_adjusted = None
+    stage_depth_final = None
 
     def __getitem__(self, item):
         return getattr(self, _ALIASES.get(item, item))
@@ -109,6 +114,23 @@ def build_kenburns_cfg(tgt_cfg: Union[str, dict]):
             tgt_cfg = yaml.safe_load(f)
     names = {f.name for f in fields(KenBurnsConfig) if f.init}
     return KenBurnsConfig(**{k: v for k, v in dict(tgt_cfg).items() if k in names})
+
+
+def colorize_depth(depth, inverse=False, rgb2bgr=False, cmap='magma_r'):
+    """debug visualisation of kenburns_effect.py:382-389 / zoedepth colorize (2nd..85th percentile) -- only used by
+    --verbose callers; needs matplotlib, otherwise falls back to a grey ramp."""
+    d = np.asarray(depth, np.float32).squeeze()
+    if inverse:
+        d = 1 / (d + 1e-5)
+    lo, hi = np.percentile(d, 2), np.percentile(d, 85)
+    v = (d - lo) / (hi - lo) if hi != lo else d * 0
+    try:
+        import matplotlib
+        col = matplotlib.colormaps[cmap](v, bytes=True)[..., :3]
+    except Exception:
+        g = (np.clip(v, 0, 1) * 255).astype(np.uint8)
+        col = np.stack([g, g, g], -1)
+    return col[..., ::-1].copy() if rgb2bgr else col
 
 
 def depth_adjustment_animesseg(instances, tenDisparity, tenImage, use_medium=False):
@@ -346,11 +368,18 @@ class KenBurnsPipeline:
         if img_tensor is None:
             img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
         disparity = self._depth_est(img_tensor, img_d) if coarse is None else coarse
+        verbose = kw.get('verbose', False) and kcfg is not None
+        if verbose:
+            kcfg.stage_depth_coarse = colorize_depth(disparity.cpu().numpy(), inverse=True, rgb2bgr=True)
         disparity = depth_adjustment_animesseg(instances, disparity, img_tensor, self.cfg.depthest_use_medium)
+        if verbose:
+            kcfg.stage_depth_adjusted = colorize_depth(disparity.cpu().numpy(), inverse=True, rgb2bgr=True)
         if self.cfg.default_depth_refine:                                        # kenburns_effect.py:619-622
             disparity = self.refine_depth(img_tensor, disparity)
         elif self.cfg.refine_crf:
             raise NotImplementedError("refine_crf=True needs cv2 / pydensecrf CPU heuristics (out of scope, SURVEY 2.1; off in the shipped yaml)")
+        if verbose:
+            kcfg.stage_depth_final = colorize_depth(disparity.cpu().numpy(), inverse=True, rgb2bgr=True)
         return disparity
 
     # ---- generate_kenburns_config (kenburns_effect.py:898-951) -----------------------------------------------
@@ -386,7 +415,7 @@ class KenBurnsPipeline:
             img_d = self.animeinsseg._upload(img)
             img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
             cfg = self.cfg.copy()
-            disparity = self.infer_disparity(img, instances, img_tensor, kcfg=cfg, coarse=coarse)
+            disparity = self.infer_disparity(img, instances, img_tensor, kcfg=cfg, coarse=coarse, verbose=verbose)
             disparity = disparity / disparity.max() * self.cfg.baseline
             depth, valid, pts, unaltered = ops.disparity_to_points(disparity, cfg.focal, cfg.baseline)
             crop = depth[0, 0, 128:-128, 128:-128]                      # cv2.minMaxLoc(depth[128:-128,128:-128])

@@ -279,6 +279,54 @@ class AnimeInsSeg:
         bboxes[:, 2:] -= bboxes[:, :2]
         return AnimeInstances(masks, bboxes, d['scores'][sel])
 
+    # ---- Web-UI helpers (reference :241-393): detector embeddings + box-prompted masks ---------------------
+    def infer_embeddings(self, imgs, det_size=None):
+        """reference :241-337: returns (img, instance_data, mask_feat) with the NMS'ed detections *before* mask
+        generation; instance_data is a dict with bboxes [n,4] xyxy, scores, priors, kernels (+ internal handles)."""
+        if det_size is not None:
+            self.set_detect_size(det_size)
+        img = imgs[0] if isinstance(imgs, list) else imgs
+        d = self.detect_raw(img)
+        if d['n'] == 0:
+            d.update(boxes=torch.zeros((0, 4), device=self.device), scores=torch.zeros(0, device=self.device),
+                     priors=torch.zeros((0, 4), device=self.device), kernels=torch.zeros((0, self.cfg.num_gen_params), device=self.device))
+        d['bboxes'] = d['boxes']
+        mask_feat = d['cp'].view(d['rp'].mask_feat)
+        return img, d, mask_feat
+
+    def segment_with_bboxes(self, img, bboxes, instance_data, mask_feat=None):
+        """reference :339-393: for every query box (xyxy) pick the detection with the highest IoU, build its mask
+        (x8 bilinear -> resize to [long_side, long_side] -> crop -> sigmoid > 0.5) and refine."""
+        L, cfg, d = _lib.load(), self.cfg, instance_data
+        if d['n'] == 0 or len(bboxes) == 0:
+            return AnimeInstances()
+        q = torch.as_tensor(np.asarray(bboxes), dtype=d['boxes'].dtype, device=self.device).view(-1, 4)
+        t = d['boxes']
+        lt, rb = torch.max(q[:, None, :2], t[None, :, :2]), torch.min(q[:, None, 2:], t[None, :, 2:])
+        inter = (rb - lt).clamp(min=0).prod(2)
+        area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])          # noqa: E731  torchvision box_iou
+        iou = inter / (area(q)[:, None] + area(t)[None, :] - inter)
+        idx = iou.argmax(1)
+        H, W = d['H'], d['W']
+        long_side = max(H, W)
+        mf = d['rp'].mask_feat
+        b = mf.buf
+        feat = d['cp'].workspace[b.offset:]
+        n = int(idx.numel())
+        logits = torch.empty((n, mf.h, mf.w), dtype=torch.float32, device=self.device)
+        check(L.csm_maskhead_logits(ptr(feat), i32(b.c), i32(mf.h), i32(mf.w), i32(cfg.num_prototypes), i32(cfg.dyconv_channels),
+                                    ptr(d['kernels'][idx].contiguous()), ptr(d['priors'][idx].contiguous()), i32(n),
+                                    i32(cfg.strides[0]), ptr(logits), stream_ptr()), "maskhead")
+        masks = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
+        check(L.csm_mask_resize_threshold(ptr(logits), i32(n), i32(mf.h), i32(mf.w), i32(cfg.strides[0]), i32(long_side),
+                                          i32(long_side), i32(H), i32(W), f32(0.5), ptr(masks), stream_ptr()), "mask_resize")
+        bb = t[idx].to(torch.int32)
+        bb[:, 2:] -= bb[:, :2]
+        inst = AnimeInstances(masks.bool(), bb, d['scores'][idx])
+        if self.refine_method == 'refinenet_isnet':
+            self._postprocess_refine(inst, img, refine_size=self.refine_size)
+        return inst
+
     # ---- ISNet refine (reference :638-665, :37-55) ---------------------------------------------------
     def _postprocess_refine(self, instances: AnimeInstances, img, refine_size: int = 720, max_refine_batch: int = 4, **kw):
         if instances.is_empty:

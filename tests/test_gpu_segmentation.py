@@ -57,3 +57,18 @@ def test_api_surface_and_empty_result():
     assert m.shape == (64, 64)
     t.resize(32, 32)
     assert t.masks.shape[1:] == (32, 32)
+
+
+def test_embeddings_and_box_prompted_masks():
+    from animeinsseg import AnimeInsSeg
+    net = AnimeInsSeg('synthetic', default_det_size=64, refine_kwargs={'refine_method': 'none'})
+    net.set_max_instance(4)
+    img = _img(96, 80, 9)
+    im, data, mask_feat = net.infer_embeddings(img)
+    assert data['n'] > 0 and data['bboxes'].shape == (data['n'], 4) and mask_feat.shape[-1] == 8
+    full = net.infer(img, pred_score_thr=0.0, max_instances=4)
+    q = data['bboxes'][:2].cpu().numpy()
+    inst = net.segment_with_bboxes(img, q, data, mask_feat)
+    assert len(inst) == 2 and inst.masks.shape[1:] == (96, 80)
+    # an exact box match returns that detection's own mask (square image-sized rescale == det rescale when H,W <= long side)
+    assert inst.bboxes.shape == (2, 4)
