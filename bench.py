@@ -28,10 +28,11 @@ MFMA_F32_PEAK_TF = 157.3  # same guide: fp32-input MFMA dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--workload", default="auto", help="auto | warp | frame")
+    ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step (frame workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -59,13 +60,14 @@ class Workload:
         self.world, self.dist = world, dist
         self.gather_list = None
         if dist is not None and dist.get_rank() == 0:
-            self.gather_list = [torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=device) for _ in range(world)]
+            self.gather_list = [torch.empty((self.frames_per_step, self.H, self.W, 3), dtype=torch.uint8, device=device)
+                                for _ in range(world)]
 
     def step_and_gather(self):
         """one frame on this rank, then the per-rank gather of the uint8 output to rank 0"""
         frame = self.step()
         if self.dist is not None:
-            self.dist.gather(frame, self.gather_list, dst=0)
+            self.dist.gather(frame.view(self.frames_per_step, self.H, self.W, 3), self.gather_list, dst=0)
         return frame
 
     def extra(self):
@@ -157,7 +159,8 @@ class FrameWorkload(Workload):
     name = "seg+depth+warp"
     INSTANCES = 2
 
-    def __init__(self, size, rank, device):
+    def __init__(self, size, rank, device, batch=4):
+        self.frames_per_step = batch
         os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"          # no checkpoints exist offline: closed-form weights
         if rank != 0:
             os.environ["CSM_WEIGHTS_PLACEHOLDER"] = "1"    # shapes only; real values arrive by RCCL broadcast from rank 0
@@ -170,23 +173,27 @@ class FrameWorkload(Workload):
         self.pipe = KenBurnsPipeline(cfg, device=str(device))
         self.pipe.max_instances = self.INSTANCES          # synthetic weights score every prior ~0.49: cap like infer(max_instances=)
         self.pipe.overlap_depth = os.environ.get("CSM_OVERLAP_DEPTH", "1") == "1"
-        self.img = torch.from_numpy(synth.image_u8(size, size, 1234 + rank)).to(device)
+        self.imgs = [torch.from_numpy(synth.image_u8(size, size, 1234 + 64 * rank + k)).to(device) for k in range(batch)]
         self.wf = ops.WarpFrame(size, size, device)
-        self.out = torch.empty((size, size, 3), dtype=torch.uint8, device=device)
+        self.out = torch.empty((batch, size, size, 3), dtype=torch.uint8, device=device)
         self.n_inst = None
 
     def step(self):
         from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, f32, check
         pipe = self.pipe
-        kc = pipe.generate_kenburns_config(self.img)          # seg (main stream) || LeReS (side stream) -> adjust -> points
-        self.n_inst = len(kc.instances)
-        W, H = kc['intWidth'], kc['intHeight']
-        d_from = kc['objDepthrange'][0]
-        shift = self.ops.shift_vector({'fltShiftU': 30.0, 'fltShiftV': -20.0, 'fltDepthFrom': d_from, 'fltDepthTo': d_from / 1.25}, kc)
-        frame, _ = self.wf(kc['tenInpaPoints'], kc.inpainted_img, kc['tenInpaDepth'], kc['fltFocal'], kc['fltBaseline'], shift)
-        pw, ph = int(0.97 * W), int(0.97 * H)
-        check(load().csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0), ptr(self.out),
-                                        stream_ptr()))
+        if self.frames_per_step == 1:
+            kcs = [pipe.generate_kenburns_config(self.imgs[0])]     # seg (main stream) || LeReS (side stream)
+        else:
+            kcs = pipe.generate_kenburns_configs(self.imgs)         # batched detector / refine / LeReS, per-frame glue
+        self.n_inst = len(kcs[0].instances)
+        for k, kc in enumerate(kcs):
+            W, H = kc['intWidth'], kc['intHeight']
+            d_from = kc['objDepthrange'][0]
+            shift = self.ops.shift_vector({'fltShiftU': 30.0, 'fltShiftV': -20.0, 'fltDepthFrom': d_from, 'fltDepthTo': d_from / 1.25}, kc)
+            frame, _ = self.wf(kc['tenInpaPoints'], kc.inpainted_img, kc['tenInpaDepth'], kc['fltFocal'], kc['fltBaseline'], shift)
+            pw, ph = int(0.97 * W), int(0.97 * H)
+            check(load().csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0), ptr(self.out[k]),
+                                            stream_ptr()))
         return self.out
 
     def weight_buffers(self):
@@ -204,19 +211,21 @@ class FrameWorkload(Workload):
         return n
 
     def _programs(self):
+        """every compiled layer program of the pipeline with random ext tensors of the right shapes"""
         a = self.pipe.animeinsseg
-        (rp, det), = a._det_programs.values()
-        items = [("rtmdet-ins-l@640", det, [torch.randn(1, 3, 640, 640, device=self.device)])]
-        for (n, T), cp in a._refine_programs.items():
-            items.append(("isnet n=%d@%d" % (n, T), cp, [torch.rand(n, 4, T, T, device=self.device), torch.empty(n, 1, T, T, device=self.device)]))
-        for (h, w), cp in self.pipe._leres.items():
-            items.append(("leres@%dx%d" % (w, h), cp, [torch.randn(1, 3, h, w, device=self.device), torch.empty(1, 1, h, w, device=self.device)]))
+        cps = [("rtmdet-ins-l@%d n=%d" % k, v[1]) for k, v in a._det_programs.items()]
+        cps += [("isnet n=%d@%d" % k, v) for k, v in a._refine_programs.items()]
+        cps += [("leres@%dx%d n=%d" % (k[1], k[0], k[2]), v) for k, v in self.pipe._leres.items()]
+        items = []
+        for name, cp in cps:
+            ext = sorted((b for b in cp.prog.bufs if b.ext >= 0), key=lambda b: b.ext)
+            items.append((name, cp, [torch.randn(b.n, b.c, b.h, b.w, device=self.device) for b in ext]))
         return items
 
     def config(self, world):
         return {"workload": "seg(RTMDet-Ins-L det640 + maskhead + ISNet refine@720, %d instances) + LeReS depth@640 + 1 warp, "
                             "frame %dx%d" % (self.n_inst or self.INSTANCES, self.W, self.H),
-                "frames_per_gpu_step": 1, "parallelism": "frames sharded x%d (no data-path collective; uint8 frame gather)" % world,
+                "frames_per_gpu_step": self.frames_per_step, "global_batch": self.frames_per_step * world, "parallelism": "frames sharded x%d (no data-path collective; uint8 frame gather)" % world,
                 "weights": "closed-form synthetic (no checkpoints offline)", "precision": "fp32 exact (v_mfma_f32_32x32x2_f32)"}
 
     def roofline(self):
@@ -234,7 +243,8 @@ class FrameWorkload(Workload):
             tot_ms += cms; tot_fl += cp.prog.flops
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         n_launch = sum(v["conv_launches"] for v in per_net.values())
-        return {"bound": "mfma", "kernel": "k_conv_mfma (fp32 implicit GEMM, all conv launches of one frame)",
+        tot_fl /= self.frames_per_step
+        return {"bound": "mfma", "kernel": "k_conv_mfma (fp32 implicit GEMM, all conv launches of one step = %d frames)" % self.frames_per_step,
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                 "traffic": load_traffic("k_conv_mfma"), "algorithmic_flops_per_frame": tot_fl,
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_frame": n_launch, "per_net": per_net}
@@ -247,9 +257,9 @@ class FrameWorkload(Workload):
         return oframe.cpu_baseline(seconds)
 
 
-def make_workload(kind, size, rank, device, world, dist):
+def make_workload(kind, size, rank, device, world, dist, batch=4):
     if kind in ("auto", "frame"):
-        wl = FrameWorkload(size, rank, device)
+        wl = FrameWorkload(size, rank, device, batch)
     elif kind == "warp":
         wl = WarpWorkload(size, rank, device)
     else:
@@ -284,7 +294,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    wl = make_workload(a.workload, a.size, rank, device, world, dist)
+    wl = make_workload(a.workload, a.size, rank, device, world, dist, a.batch)
 
     wl.step_and_gather()                      # compiles the layer programs (lazy) -- untimed
     bcast_bytes = wl.broadcast_weights() if (dist is not None and hasattr(wl, "broadcast_weights")) else 0

@@ -372,20 +372,35 @@ __device__ __forceinline__ void src_index(int dst, int in_size, int out_size, fl
     l0 = 1.0f - l1;
 }
 
-// bilinear resize, generic channel count (float4 fast path when c%4==0 and pitches allow)
+// bilinear resize: VEC = 4 handles 4 channels per lane with 16-byte accesses (c, pitches and bases 16-byte aligned),
+// VEC = 1 is the generic path (single-channel side outputs).  Same expression per element in both.
+template <int VEC>
 __global__ __launch_bounds__(256) void k_bilinear(View in, View out, int align, float sh, float sw) {
+    const int cv = out.c / VEC;
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int64_t total = (int64_t)out.n * out.h * out.w * out.c;
+    int64_t total = (int64_t)out.n * out.h * out.w * cv;
     if (idx >= total) return;
-    int c = (int)(idx % out.c); int64_t pix = idx / out.c;
+    int c = (int)(idx % cv) * VEC; int64_t pix = idx / cv;
     int ox = (int)(pix % out.w); int64_t t = pix / out.w; int oy = (int)(t % out.h); int n = (int)(t / out.h);
     int y0, y1, x0, x1; float hl0, hl1, wl0, wl1;
     src_index(oy, in.h, out.h, sh, align != 0, y0, y1, hl0, hl1);
     src_index(ox, in.w, out.w, sw, align != 0, x0, x1, wl0, wl1);
     const float *P = in.p + (int64_t)n * in.h * in.w * in.ld + c;
-    float p00 = P[((int64_t)y0 * in.w + x0) * in.ld], p01 = P[((int64_t)y0 * in.w + x1) * in.ld];
-    float p10 = P[((int64_t)y1 * in.w + x0) * in.ld], p11 = P[((int64_t)y1 * in.w + x1) * in.ld];
-    out.p[pix * out.ld + c] = hl0 * (wl0 * p00 + wl1 * p01) + hl1 * (wl0 * p10 + wl1 * p11);
+    const float *a00 = P + ((int64_t)y0 * in.w + x0) * in.ld, *a01 = P + ((int64_t)y0 * in.w + x1) * in.ld;
+    const float *a10 = P + ((int64_t)y1 * in.w + x0) * in.ld, *a11 = P + ((int64_t)y1 * in.w + x1) * in.ld;
+    float *O = out.p + pix * out.ld + c;
+    if (VEC == 4) {
+        float4 p00 = *reinterpret_cast<const float4 *>(a00), p01 = *reinterpret_cast<const float4 *>(a01);
+        float4 p10 = *reinterpret_cast<const float4 *>(a10), p11 = *reinterpret_cast<const float4 *>(a11);
+        float4 r;
+        r.x = hl0 * (wl0 * p00.x + wl1 * p01.x) + hl1 * (wl0 * p10.x + wl1 * p11.x);
+        r.y = hl0 * (wl0 * p00.y + wl1 * p01.y) + hl1 * (wl0 * p10.y + wl1 * p11.y);
+        r.z = hl0 * (wl0 * p00.z + wl1 * p01.z) + hl1 * (wl0 * p10.z + wl1 * p11.z);
+        r.w = hl0 * (wl0 * p00.w + wl1 * p01.w) + hl1 * (wl0 * p10.w + wl1 * p11.w);
+        *reinterpret_cast<float4 *>(O) = r;
+    } else {
+        O[0] = hl0 * (wl0 * a00[0] + wl1 * a01[0]) + hl1 * (wl0 * a10[0] + wl1 * a11[0]);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_nearest(View in, View out) {
@@ -564,7 +579,9 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 float sh, sw;
                 if (align) { sh = out.h > 1 ? (float)(in.h - 1) / (float)(out.h - 1) : 0.0f; sw = out.w > 1 ? (float)(in.w - 1) / (float)(out.w - 1) : 0.0f; }
                 else { sh = (float)in.h / (float)out.h; sw = (float)in.w / (float)out.w; }
-                k_bilinear<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw);
+                bool vec = !(out.c & 3) && !(in.ld & 3) && !(out.ld & 3) && !(((uintptr_t)in.p | (uintptr_t)out.p) & 15);
+                if (vec) k_bilinear<4><<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw);
+                else k_bilinear<1><<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw);
                 break;
             }
             case CSM_OP_NEAREST:

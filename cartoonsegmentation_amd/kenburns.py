@@ -327,12 +327,40 @@ class KenBurnsPipeline:
         return o
 
     # ---- depth (kenburns_effect.py:563-581) ------------------------------------------------------------
-    def _leres_prog(self, h, w):
-        if (h, w) not in self._leres:
-            cp = CompiledProgram(build_leres(self._leres_ws, 1, h, w), self.device, weights=self._leres_weights)
+    def _leres_prog(self, h, w, n=1):
+        if (h, w, n) not in self._leres:
+            cp = CompiledProgram(build_leres(self._leres_ws, n, h, w), self.device, weights=self._leres_weights)
             self._leres_weights = cp.weights
-            self._leres[(h, w)] = cp
-        return self._leres[(h, w)]
+            self._leres[(h, w, n)] = cp
+        return self._leres[(h, w, n)]
+
+    def _depth_est_leres_batch(self, imgs_d):
+        """LeReS on several equally sized frames in one program run (per-sample results as _depth_est_leres)"""
+        L = _lib.load()
+        nb = len(imgs_d)
+        H, W = int(imgs_d[0].shape[0]), int(imgs_d[0].shape[1])
+        h, w = scaledown_size(H, W, self.cfg.depth_est_size)
+        h, w = int(math.ceil(h / 32) * 32), int(math.ceil(w / 32) * 32)
+        if h > H or w > W:
+            raise NotImplementedError("LeReS map larger than the frame needs cv2 INTER_LANCZOS4 (not restated)")
+        x = torch.empty((nb, 3, h, w), dtype=torch.float32, device=self.device)
+        for bi, im in enumerate(imgs_d):
+            check(L.csm_leres_input(ptr(im), i32(H), i32(W), i32(h), i32(w), ptr(x[bi]), stream_ptr()), "leres_input")
+        y = torch.empty((nb, 1, h, w), dtype=torch.float32, device=self.device)
+        self._leres_prog(h, w, nb).run(x, y)
+        outs = []
+        for bi in range(nb):
+            yb = y[bi]
+            mnmx = torch.stack([yb.min(), yb.max()])
+            q = torch.empty((h, w), dtype=torch.uint8, device=self.device)
+            check(L.csm_leres_quantize(ptr(yb), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
+            depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
+            check(L.csm_resize_u8_to_f32(ptr(q), i32(h), i32(w), i32(H), i32(W), ptr(depth), stream_ptr()), "resize_u8")
+            pos = depth[depth > 0]
+            if pos.numel():
+                depth[depth == 0] = pos.min()
+            outs.append(depth)
+        return outs
 
     def _depth_est_leres(self, img_tensor, img_d):
         """img_d: uint8 BGR HWC device tensor -> 'depth' (inverse-depth like, 1..255) fp32 [1,1,H,W]"""
@@ -416,21 +444,52 @@ class KenBurnsPipeline:
             img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
             cfg = self.cfg.copy()
             disparity = self.infer_disparity(img, instances, img_tensor, kcfg=cfg, coarse=coarse, verbose=verbose)
-            disparity = disparity / disparity.max() * self.cfg.baseline
-            depth, valid, pts, unaltered = ops.disparity_to_points(disparity, cfg.focal, cfg.baseline)
-            crop = depth[0, 0, 128:-128, 128:-128]                      # cv2.minMaxLoc(depth[128:-128,128:-128])
-            st = torch.stack([disparity.min().double(), disparity.max().double(), crop.min().double(), crop.max().double(),
-                              crop.argmin().double(), crop.argmax().double()]).tolist()          # one host sync for all six scalars
-            cfg['fltDispmin'], cfg['fltDispmax'] = st[0], st[1]
-            amin, amax, cw = int(st[4]), int(st[5]), crop.shape[1]
-            cfg['objDepthrange'] = (st[2], st[3], (amin % cw, amin // cw), (amax % cw, amax // cw))
-            cfg['tenRawImage'], cfg['tenRawDisparity'], cfg['tenRawDepth'] = img_tensor, disparity, depth
-            cfg['tenRawPoints'], cfg['tenRawUnaltered'] = pts.view(1, 3, -1), unaltered.view(1, 3, -1)
-            cfg.inpainted_img = img_tensor.view(1, 3, -1)
-            cfg['tenInpaDisparity'], cfg['tenInpaDepth'] = disparity.view(1, 1, -1), depth.view(1, 1, -1)
-            cfg['tenInpaPoints'] = cfg['tenRawPoints']
-            cfg.instances, cfg.original_img_nparray = instances, img
-            return cfg
+            return self._finish_config(cfg, img, img_tensor, instances, disparity)
+
+    def generate_kenburns_configs(self, imgs, verbose: bool = False):
+        """MI355X addition (the reference loops image by image, run_kenburns_batch.py:36-62): equally sized frames share one
+        batched detector run, shared ISNet refine batches and one batched LeReS run; the per-frame glue is unchanged."""
+        with torch.no_grad():
+            imgs_d = [self.animeinsseg._upload(im) for im in imgs]
+            insts = self.animeinsseg.infer(list(imgs_d), self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None,
+                                           output_type='tensor', max_instances=self.max_instances)
+            coarse = self._depth_est_leres_batch(imgs_d)
+            saved = self.overlap_depth
+            try:
+                self.overlap_depth = False
+                return [self._config_from(im, inst, c, verbose) for im, inst, c in zip(imgs_d, insts, coarse)]
+            finally:
+                self.overlap_depth = saved
+
+    def _config_from(self, img, instances, coarse, verbose=False):
+        H, W = img.shape[:2]
+        if scaledown_size(H, W, self.cfg.max_size) != (H, W):
+            raise NotImplementedError("max_size smaller than the image needs cv2.resize of the frame (not restated)")
+        instances.resize(H, W)
+        self.cfg.int_height, self.cfg.int_width = H, W
+        img_d = self.animeinsseg._upload(img)
+        img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+        cfg = self.cfg.copy()
+        disparity = self.infer_disparity(img, instances, img_tensor, kcfg=cfg, coarse=coarse, verbose=verbose)
+        return self._finish_config(cfg, img, img_tensor, instances, disparity)
+
+    def _finish_config(self, cfg, img, img_tensor, instances, disparity):
+        """kenburns_effect.py:928-951"""
+        disparity = disparity / disparity.max() * self.cfg.baseline
+        depth, valid, pts, unaltered = ops.disparity_to_points(disparity, cfg.focal, cfg.baseline)
+        crop = depth[0, 0, 128:-128, 128:-128]                      # cv2.minMaxLoc(depth[128:-128,128:-128])
+        st = torch.stack([disparity.min().double(), disparity.max().double(), crop.min().double(), crop.max().double(),
+                          crop.argmin().double(), crop.argmax().double()]).tolist()          # one host sync for all six scalars
+        cfg['fltDispmin'], cfg['fltDispmax'] = st[0], st[1]
+        amin, amax, cw = int(st[4]), int(st[5]), crop.shape[1]
+        cfg['objDepthrange'] = (st[2], st[3], (amin % cw, amin // cw), (amax % cw, amax // cw))
+        cfg['tenRawImage'], cfg['tenRawDisparity'], cfg['tenRawDepth'] = img_tensor, disparity, depth
+        cfg['tenRawPoints'], cfg['tenRawUnaltered'] = pts.view(1, 3, -1), unaltered.view(1, 3, -1)
+        cfg.inpainted_img = img_tensor.view(1, 3, -1)
+        cfg['tenInpaDisparity'], cfg['tenInpaDepth'] = disparity.view(1, 1, -1), depth.view(1, 1, -1)
+        cfg['tenInpaPoints'] = cfg['tenRawPoints']
+        cfg.instances, cfg.original_img_nparray = instances, img
+        return cfg
 
     # ---- autozoom (kenburns_effect.py:953-977, common.py:86-142) ------------------------------------------------
     def process_autozoom(self, objSettings, objCommon):

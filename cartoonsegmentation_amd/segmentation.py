@@ -127,13 +127,13 @@ class AnimeInsSeg:
         self.cfg.max_per_img = num_ins
 
     # ---- compiled programs ----------------------------------------------------------------------
-    def _detector(self, S):
-        if S not in self._det_programs:
-            rp, _ = build_rtmdet(self._det_ws, 1, S, S, self.cfg)
+    def _detector(self, S, n=1):
+        if (S, n) not in self._det_programs:
+            rp, _ = build_rtmdet(self._det_ws, n, S, S, self.cfg)
             cp = CompiledProgram(rp.prog, self.device, weights=self._det_weights)
             self._det_weights = cp.weights
-            self._det_programs[S] = (rp, cp)
-        return self._det_programs[S]
+            self._det_programs[(S, n)] = (rp, cp)
+        return self._det_programs[(S, n)]
 
     def _priors(self, S, lvl, hl, wl, stride):
         key = (S, lvl)
@@ -168,15 +168,22 @@ class AnimeInsSeg:
         if isinstance(imgs, str):
             raise NotImplementedError("image decoding (mmcv.imread) is not part of the hot path: pass a uint8 BGR ndarray")
         imgs = imgs if return_list else [imgs]
-        preds = []
-        for img in imgs:
-            inst = self._det_forward(img, pred_score_thr)
+        same = len(imgs) > 1 and all(tuple(im.shape) == tuple(imgs[0].shape) for im in imgs)
+        if same:            # equally sized frames: one batched detector run + refine batches shared across frames
+            insts = [self._instances_from(d, pred_score_thr) for d in self.detect_raw_batch(imgs)]
             if self.refine_method == 'refinenet_isnet':
-                self._postprocess_refine(inst, img, refine_size=self.refine_size)
-            if output_type == 'numpy':
+                self._refine_many(list(zip(insts, imgs)), self.refine_size)
+        else:
+            insts = []
+            for img in imgs:
+                inst = self._det_forward(img, pred_score_thr)
+                if self.refine_method == 'refinenet_isnet':
+                    self._postprocess_refine(inst, img, refine_size=self.refine_size)
+                insts.append(inst)
+        if output_type == 'numpy':
+            for inst in insts:
                 inst.to_numpy()
-            preds.append(inst)
-        return preds if return_list else preds[0]
+        return insts if return_list else insts[0]
 
     # ---- detector forward + post-process (reference :447-462 + mmdet predict_by_feat) ---------------
     def _upload(self, img):
@@ -189,23 +196,36 @@ class AnimeInsSeg:
 
     def detect_raw(self, img):
         """returns dict with kept boxes/scores/kernels/priors (score-sorted, after NMS) + scale info"""
+        return self.detect_raw_batch([img])[0]
+
+    def detect_raw_batch(self, imgs):
+        """MI355X addition: frames of equal size run through ONE detector program (batch n) -- the small feature maps
+        of the head/neck then fill the chip.  Every op is per-sample; the only batch-size dependence is the host's split-K
+        choice (csm_op.ksplit follows the total pixel count), i.e. fp32 summation grouping at the ulp level."""
         L, cfg = _lib.load(), self.cfg
-        img_d = self._upload(img)
-        H, W = int(img_d.shape[0]), int(img_d.shape[1])
+        imgs_d = [self._upload(im) for im in imgs]
+        H, W = int(imgs_d[0].shape[0]), int(imgs_d[0].shape[1])
+        assert all(tuple(t.shape) == (H, W, 3) for t in imgs_d), "detect_raw_batch needs equally sized images"
+        nb = len(imgs_d)
         S = self.default_det_size
         rh, rw = rescale_size(H, W, (S, S))
         w_scale, h_scale = rw / W, rh / H
-        rp, cp = self._detector(S)
-        x = torch.empty((1, 3, S, S), dtype=torch.float32, device=self.device)
+        rp, cp = self._detector(S, nb)
+        x = torch.empty((nb, 3, S, S), dtype=torch.float32, device=self.device)
         mean = (ctypes.c_float * 3)(*cfg.mean); std = (ctypes.c_float * 3)(*cfg.std)
-        check(L.csm_det_preprocess(ptr(img_d), i32(H), i32(W), i32(rh), i32(rw), i32(S), i32(S), mean, std,
-                                   f32(cfg.pad_value), ptr(x), stream_ptr()), "det_preprocess")
+        for bi, img_d in enumerate(imgs_d):
+            check(L.csm_det_preprocess(ptr(img_d), i32(H), i32(W), i32(rh), i32(rw), i32(S), i32(S), mean, std,
+                                       f32(cfg.pad_value), ptr(x[bi]), stream_ptr()), "det_preprocess")
         cp.run(x)
+        return [self._decode_one(rp, cp, bi, H, W, S, rh, rw, w_scale, h_scale) for bi in range(nb)]
+
+    def _decode_one(self, rp, cp, bi, H, W, S, rh, rw, w_scale, h_scale):
+        L, cfg = _lib.load(), self.cfg
         scores_l, boxes_l, priors_l, kern_l, labels_l = [], [], [], [], []
         for lvl, stride in enumerate(cfg.strides):
-            cls = cp.view(rp.cls[lvl]).reshape(-1, cfg.num_classes)               # sigmoid fused in rtm_cls epilogue
-            reg = cp.view(rp.reg[lvl]).reshape(-1, 4) * float(stride)             # F.relu(rtm_reg) * stride
-            ker = cp.view(rp.kern[lvl]).reshape(-1, cfg.num_gen_params)
+            cls = cp.view(rp.cls[lvl])[bi].reshape(-1, cfg.num_classes)           # sigmoid fused in rtm_cls epilogue
+            reg = cp.view(rp.reg[lvl])[bi].reshape(-1, 4) * float(stride)         # F.relu(rtm_reg) * stride
+            ker = cp.view(rp.kern[lvl])[bi].reshape(-1, cfg.num_gen_params)
             pri = self._priors(S, lvl, rp.cls[lvl].h, rp.cls[lvl].w, stride)      # MlvlPointGenerator(offset=0), cached
             valid = cls > cfg.score_thr                                          # filter_scores_and_topk
             sc = cls[valid]
@@ -226,7 +246,7 @@ class AnimeInsSeg:
             if not bool(ok.all()):
                 scores, labels, boxes, priors, kernels = scores[ok], labels[ok], boxes[ok], priors[ok], kernels[ok]
         n = int(scores.shape[0])
-        out = dict(H=H, W=W, S=S, rh=rh, rw=rw, w_scale=w_scale, h_scale=h_scale, rp=rp, cp=cp)
+        out = dict(H=H, W=W, S=S, rh=rh, rw=rw, w_scale=w_scale, h_scale=h_scale, rp=rp, cp=cp, bi=bi)
         if n == 0:
             out.update(n=0)
             return out
@@ -254,8 +274,8 @@ class AnimeInsSeg:
         n = int(pri.shape[0])
         mf_view = d['rp'].mask_feat
         b = mf_view.buf
-        mf = d['cp'].workspace[b.offset:]
         h, w = mf_view.h, mf_view.w
+        mf = d['cp'].workspace[b.offset + d.get('bi', 0) * h * w * b.c:]
         logits = torch.empty((n, h, w), dtype=torch.float32, device=self.device)
         check(L.csm_maskhead_logits(ptr(mf), i32(b.c), i32(h), i32(w), i32(cfg.num_prototypes), i32(cfg.dyconv_channels),
                                     ptr(ker), ptr(pri), i32(n), i32(cfg.strides[0]), ptr(logits), stream_ptr()), "maskhead")
@@ -268,7 +288,9 @@ class AnimeInsSeg:
         return masks
 
     def _det_forward(self, img, pred_score_thr: float = 0.3) -> AnimeInstances:
-        d = self.detect_raw(img)
+        return self._instances_from(self.detect_raw(img), pred_score_thr)
+
+    def _instances_from(self, d, pred_score_thr: float = 0.3) -> AnimeInstances:
         if d['n'] == 0:
             return AnimeInstances()
         sel = (d['scores'] > pred_score_thr).nonzero()[:, 0]                       # reference :452
@@ -291,7 +313,7 @@ class AnimeInsSeg:
             d.update(boxes=torch.zeros((0, 4), device=self.device), scores=torch.zeros(0, device=self.device),
                      priors=torch.zeros((0, 4), device=self.device), kernels=torch.zeros((0, self.cfg.num_gen_params), device=self.device))
         d['bboxes'] = d['boxes']
-        mask_feat = d['cp'].view(d['rp'].mask_feat)
+        mask_feat = d['cp'].view(d['rp'].mask_feat)[d.get('bi', 0)]
         return img, d, mask_feat
 
     def segment_with_bboxes(self, img, bboxes, instance_data, mask_feat=None):
@@ -311,7 +333,7 @@ class AnimeInsSeg:
         long_side = max(H, W)
         mf = d['rp'].mask_feat
         b = mf.buf
-        feat = d['cp'].workspace[b.offset:]
+        feat = d['cp'].workspace[b.offset + d.get('bi', 0) * mf.h * mf.w * b.c:]
         n = int(idx.numel())
         logits = torch.empty((n, mf.h, mf.w), dtype=torch.float32, device=self.device)
         check(L.csm_maskhead_logits(ptr(feat), i32(b.c), i32(mf.h), i32(mf.w), i32(cfg.num_prototypes), i32(cfg.dyconv_channels),
@@ -326,6 +348,40 @@ class AnimeInsSeg:
         if self.refine_method == 'refinenet_isnet':
             self._postprocess_refine(inst, img, refine_size=self.refine_size)
         return inst
+
+    def _refine_many(self, pairs, refine_size=720, max_batch=8):
+        """ISNet refine of several (instances, image) pairs of equal image size with shared batches (per-sample results are
+        those of _postprocess_refine; the reference's per-image limit of 4 only bounds its memory use)."""
+        L = _lib.load()
+        jobs = []
+        for inst, img in pairs:
+            if inst.is_empty:
+                continue
+            img_d = self._upload(img)
+            segs = inst.masks.to(self.device).to(torch.uint8).contiguous()
+            jobs.append((inst, img_d, segs))
+        if not jobs:
+            return
+        H, W = int(jobs[0][1].shape[0]), int(jobs[0][1].shape[1])
+        T = refine_size
+        rh, rw = scaledown_size(H, W, T)
+        flat = [(j, k) for j, (_, _, segs) in enumerate(jobs) for k in range(segs.shape[0])]
+        outs = [torch.empty((segs.shape[0], H, W), dtype=torch.uint8, device=self.device) for _, _, segs in jobs]
+        for c0 in range(0, len(flat), max_batch):
+            chunk = flat[c0:c0 + max_batch]
+            b = len(chunk)
+            cp = self._refiner(b, T)
+            batch = torch.empty((b, 4, T, T), dtype=torch.float32, device=self.device)
+            for i, (j, k) in enumerate(chunk):
+                check(L.csm_refine_prepare_batch(ptr(jobs[j][1]), ptr(jobs[j][2][k:k + 1]), i32(1), i32(H), i32(W), i32(rh), i32(rw),
+                                                 i32(T), ptr(batch[i:i + 1]), stream_ptr()), "refine_prepare")
+            logits = torch.empty((b, 1, T, T), dtype=torch.float32, device=self.device)
+            cp.run(batch, logits)
+            for i, (j, k) in enumerate(chunk):
+                check(L.csm_refine_threshold(ptr(logits[i:i + 1]), i32(1), i32(T), i32(T), i32(rh), i32(rw), i32(H), i32(W),
+                                             f32(self.mask_thr), ptr(outs[j][k:k + 1]), stream_ptr()), "refine_threshold")
+        for (inst, _, _), o in zip(jobs, outs):
+            inst.masks = o.bool()
 
     # ---- ISNet refine (reference :638-665, :37-55) ---------------------------------------------------
     def _postprocess_refine(self, instances: AnimeInstances, img, refine_size: int = 720, max_refine_batch: int = 4, **kw):

@@ -192,3 +192,25 @@ def test_overlapped_depth_equals_sequential():
         outs.append((kc['tenRawPoints'].clone(), kc['tenRawDepth'].clone(), kc.instances.masks.clone()))
     for a, b in ((0, 1), (1, 2)):
         assert all(torch.equal(x, y) for x, y in zip(outs[a], outs[b]))
+
+
+def test_batched_configs_match_single_frame_path():
+    """generate_kenburns_configs (batched detector / refine / LeReS) vs the per-image reference order: same instances and
+    point clouds up to the split-K summation grouping (csm_op.ksplit depends on the batch) -> fp32 tolerance, IoU ~ 1"""
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd import synth
+    imgs = [synth.image_u8(320, 320, 31 + k) for k in range(3)]
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=96, max_size=512, refine_crf=False, focal=160.0,
+                         mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 64})
+    pipe = KenBurnsPipeline(cfg)
+    pipe.max_instances, pipe.overlap_depth = 2, False
+    pipe.animeinsseg.set_detect_size(96)
+    batched = pipe.generate_kenburns_configs(imgs)
+    for im, kb in zip(imgs, batched):
+        ks = pipe.generate_kenburns_config(im)
+        assert len(ks.instances) == len(kb.instances) and torch.equal(ks.instances.bboxes, kb.instances.bboxes)
+        inter = (ks.instances.masks & kb.instances.masks).sum().item(); union = (ks.instances.masks | kb.instances.masks).sum().item()
+        assert inter / max(union, 1) > 0.999
+        a, b = ks['tenRawDepth'], kb['tenRawDepth']
+        assert ((a - b).abs() <= 1e-3 * b.abs() + 1e-6).float().mean().item() > 0.999
