@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_to_points(const float *__restr
 }
 
 // kenburns_effect.py:928-933 fused into one pass over the disparity map
-__global__ __launch_bounds__(kBlock) void k_disparity_to_points(const float *__restrict__ disp, float disp_max, int H,
+__global__ __launch_bounds__(kBlock) void k_disparity_to_points(const float *__restrict__ disp, const float *__restrict__ disp_max_p, int H,
                                                                  int W, float fb, float eps, float invf, float x_start,
                                                                  float y_start, float *__restrict__ depth,
                                                                  float *__restrict__ valid, float *__restrict__ pts,
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kBlock) void k_disparity_to_points(const float *__r
     if (x >= W || y >= H) return;
     const int64_t plane = (int64_t)H * W, o = (int64_t)y * W + x;
     float d = (1.0f / (disp[o] + eps)) * fb;  // float / Tensor == reciprocal()*float in torch
-    float lap = laplacian_at(disp, x, y, H, W, disp_max);
+    float lap = laplacian_at(disp, x, y, H, W, disp_max_p[0]);
     float v = fabsf(lap) < 0.03f ? 1.0f : 0.0f;
     float hx = (x_start + (float)x) * invf, vy = (y_start + (float)y) * invf;
     depth[o] = d; valid[o] = v;
@@ -570,9 +570,9 @@ extern "C" int csm_depth_to_points(const float *depth, float *pts, int B, int H,
     return csm::check_launch("k_depth_to_points");
 }
 
-extern "C" int csm_disparity_to_points(const float *disp, float disp_max, int H, int W, double focal, double baseline,
+extern "C" int csm_disparity_to_points(const float *disp, const float *disp_max, int H, int W, double focal, double baseline,
                                        float eps, float *depth, float *valid, float *pts, float *unaltered, void *stream) {
-    CSM_REQUIRE(disp && depth && valid && pts && unaltered && H > 0 && W > 0 && focal != 0.0);
+    CSM_REQUIRE(disp && disp_max && depth && valid && pts && unaltered && H > 0 && W > 0 && focal != 0.0);
     k_disparity_to_points<<<grid2d(W, H, 1, 64, 4), kBlock, 0, (hipStream_t)stream>>>(
         disp, disp_max, H, W, (float)(focal * baseline), eps, (float)(1.0 / focal), (float)(-0.5 * W + 0.5),
         (float)(-0.5 * H + 0.5), depth, valid, pts, unaltered);

@@ -133,6 +133,13 @@ def colorize_depth(depth, inverse=False, rgb2bgr=False, cmap='magma_r'):
     return col[..., ::-1].copy() if rgb2bgr else col
 
 
+def _fill_zero_with_min_positive(depth):
+    """`depth[depth == 0] = depth[depth > 0].min()` (leres/__init__.py:143-145 semantics: skipped when nothing is positive)
+    without the boolean-index host sync"""
+    mn = torch.where(depth > 0, depth, depth.new_full((), float('inf'))).min()
+    return torch.where((depth == 0) & torch.isfinite(mn), mn, depth)
+
+
 def depth_adjustment_animesseg(instances, tenDisparity, tenImage, use_medium=False):
     """kenburns_effect.py:39-91: flatten every instance to the disparity at the bottom 3% of its rows"""
     assert tenDisparity.shape[0] == 1
@@ -356,10 +363,7 @@ class KenBurnsPipeline:
             check(L.csm_leres_quantize(ptr(yb), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
             depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
             check(L.csm_resize_u8_to_f32(ptr(q), i32(h), i32(w), i32(H), i32(W), ptr(depth), stream_ptr()), "resize_u8")
-            pos = depth[depth > 0]
-            if pos.numel():
-                depth[depth == 0] = pos.min()
-            outs.append(depth)
+            outs.append(_fill_zero_with_min_positive(depth))
         return outs
 
     def _depth_est_leres(self, img_tensor, img_d):
@@ -379,10 +383,7 @@ class KenBurnsPipeline:
         check(L.csm_leres_quantize(ptr(y), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
         depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
         check(L.csm_resize_u8_to_f32(ptr(q), i32(h), i32(w), i32(H), i32(W), ptr(depth), stream_ptr()), "resize_u8")
-        pos = depth[depth > 0]
-        if pos.numel():
-            depth[depth == 0] = pos.min()
-        return depth
+        return _fill_zero_with_min_positive(depth)
 
     def run_instance_segmentation(self, img, scale_down_to_maxsize=True):
         inst = self.animeinsseg.infer(img, self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None, output_type='tensor',

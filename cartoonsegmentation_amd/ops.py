@@ -108,7 +108,8 @@ def disparity_to_points(tenDisparity, fltFocal, fltBaseline, eps=0.00001):
     H, W = d.shape[-2:]
     depth, valid = torch.empty_like(d), torch.empty_like(d)
     pts, un = d.new_empty([1, 3, H, W]), d.new_empty([1, 3, H, W])
-    check(_lib.load().csm_disparity_to_points(ptr(d), f32(float(d.max().item())), i32(H), i32(W), f64(fltFocal),
+    dmax = d.max().reshape(1)                                                  # stays on the device: no host sync
+    check(_lib.load().csm_disparity_to_points(ptr(d), ptr(dmax), i32(H), i32(W), f64(fltFocal),
                                               f64(fltBaseline), f32(eps), ptr(depth), ptr(valid), ptr(pts), ptr(un), stream_ptr()),
           "disparity_to_points")
     return depth, valid, pts, un

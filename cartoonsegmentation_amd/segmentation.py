@@ -217,55 +217,68 @@ class AnimeInsSeg:
             check(L.csm_det_preprocess(ptr(img_d), i32(H), i32(W), i32(rh), i32(rw), i32(S), i32(S), mean, std,
                                        f32(cfg.pad_value), ptr(x[bi]), stream_ptr()), "det_preprocess")
         cp.run(x)
-        return [self._decode_one(rp, cp, bi, H, W, S, rh, rw, w_scale, h_scale) for bi in range(nb)]
+        return self._decode_batch(rp, cp, nb, H, W, S, rh, rw, w_scale, h_scale)
 
-    def _decode_one(self, rp, cp, bi, H, W, S, rh, rw, w_scale, h_scale):
-        L, cfg = _lib.load(), self.cfg
-        scores_l, boxes_l, priors_l, kern_l, labels_l = [], [], [], [], []
+    def _decode_batch(self, rp, cp, nb, H, W, S, rh, rw, w_scale, h_scale):
+        """mmdet RTMDetInsHead.predict_by_feat / _bbox_mask_post_process up to NMS, for all images of the batch with FIXED
+        shapes and one host sync: instead of filtering (`scores > score_thr`, data-dependent sizes) invalid candidates get
+        score -1, which the stable descending sorts push behind every valid one; they cannot suppress a valid box in the
+        greedy NMS (a box only suppresses lower-ranked ones) and are dropped at the end.  Same kept set and order as the
+        filter-then-topk of the reference."""
+        L, cfg, dev = _lib.load(), self.cfg, self.device
+        nc = cfg.num_classes
+        sc_l, lab_l, dist_l, pri_l, ker_l = [], [], [], [], []
         for lvl, stride in enumerate(cfg.strides):
-            cls = cp.view(rp.cls[lvl])[bi].reshape(-1, cfg.num_classes)           # sigmoid fused in rtm_cls epilogue
-            reg = cp.view(rp.reg[lvl])[bi].reshape(-1, 4) * float(stride)         # F.relu(rtm_reg) * stride
-            ker = cp.view(rp.kern[lvl])[bi].reshape(-1, cfg.num_gen_params)
-            pri = self._priors(S, lvl, rp.cls[lvl].h, rp.cls[lvl].w, stride)      # MlvlPointGenerator(offset=0), cached
-            valid = cls > cfg.score_thr                                          # filter_scores_and_topk
-            sc = cls[valid]
-            idx = valid.nonzero()
-            k = min(cfg.nms_pre, idx.shape[0])
-            sc, order = sc.sort(descending=True, stable=True)
-            sc, idx = sc[:k], idx[order[:k]]
-            keep, lab = idx[:, 0], idx[:, 1]
-            scores_l.append(sc); labels_l.append(lab); boxes_l.append(reg[keep]); priors_l.append(pri[keep]); kern_l.append(ker[keep])
-        scores, labels = torch.cat(scores_l), torch.cat(labels_l)
-        dist, priors, kernels = torch.cat(boxes_l), torch.cat(priors_l), torch.cat(kern_l)
-        x1 = (priors[:, 0] - dist[:, 0]).clamp(0, rw); y1 = (priors[:, 1] - dist[:, 1]).clamp(0, rh)   # distance2bbox(max_shape)
-        x2 = (priors[:, 0] + dist[:, 2]).clamp(0, rw); y2 = (priors[:, 1] + dist[:, 3]).clamp(0, rh)
-        sf = torch.tensor([1 / w_scale, 1 / h_scale] * 2, dtype=torch.float32, device=self.device)       # rescale=True
-        boxes = torch.stack([x1, y1, x2, y2], 1) * sf
+            cls = cp.view(rp.cls[lvl]).reshape(nb, -1)                             # [nb, P_l*nc], sigmoid fused in the conv epilogue
+            k = min(cfg.nms_pre, cls.shape[1])
+            masked = torch.where(cls > cfg.score_thr, cls, cls.new_full((), -1.0))  # filter_scores_and_topk
+            sc, order = masked.sort(dim=1, descending=True, stable=True)
+            sc, order = sc[:, :k], order[:, :k]
+            keep, lab = order // nc, order % nc
+            reg = cp.view(rp.reg[lvl]).reshape(nb, -1, 4) * float(stride)           # F.relu(rtm_reg) * stride
+            ker = cp.view(rp.kern[lvl]).reshape(nb, -1, cfg.num_gen_params)
+            pri = self._priors(S, lvl, rp.cls[lvl].h, rp.cls[lvl].w, stride)        # MlvlPointGenerator(offset=0), cached
+            sc_l.append(sc); lab_l.append(lab)
+            dist_l.append(torch.gather(reg, 1, keep[..., None].expand(-1, -1, 4)))
+            ker_l.append(torch.gather(ker, 1, keep[..., None].expand(-1, -1, cfg.num_gen_params)))
+            pri_l.append(pri[keep])
+        scores, labels = torch.cat(sc_l, 1), torch.cat(lab_l, 1)
+        dist, priors, kernels = torch.cat(dist_l, 1), torch.cat(pri_l, 1), torch.cat(ker_l, 1)
+        x1 = (priors[..., 0] - dist[..., 0]).clamp(0, rw); y1 = (priors[..., 1] - dist[..., 1]).clamp(0, rh)   # distance2bbox
+        x2 = (priors[..., 0] + dist[..., 2]).clamp(0, rw); y2 = (priors[..., 1] + dist[..., 3]).clamp(0, rh)
+        sf = torch.tensor([1 / w_scale, 1 / h_scale] * 2, dtype=torch.float32, device=dev)                     # rescale=True
+        boxes = torch.stack([x1, y1, x2, y2], 2) * sf
+        valid = scores > cfg.score_thr
         if cfg.min_bbox_size >= 0:
-            ok = ((boxes[:, 2] - boxes[:, 0]) > cfg.min_bbox_size) & ((boxes[:, 3] - boxes[:, 1]) > cfg.min_bbox_size)
-            if not bool(ok.all()):
-                scores, labels, boxes, priors, kernels = scores[ok], labels[ok], boxes[ok], priors[ok], kernels[ok]
-        n = int(scores.shape[0])
-        out = dict(H=H, W=W, S=S, rh=rh, rw=rw, w_scale=w_scale, h_scale=h_scale, rp=rp, cp=cp, bi=bi)
-        if n == 0:
-            out.update(n=0)
-            return out
-        scores, order = scores.sort(descending=True, stable=True)
-        scores, order = scores[:4096], order[:4096]
-        boxes, priors, kernels, labels = boxes[order].contiguous(), priors[order], kernels[order], labels[order]
-        n = int(scores.shape[0])
-        offs = None
-        if cfg.num_classes > 1:                                                  # batched_nms coordinate trick
-            offs = (labels.float() * (boxes.max() + 1)).contiguous()
-        keep = torch.empty(cfg.max_per_img, dtype=torch.int32, device=self.device)
-        nk = torch.zeros(1, dtype=torch.int32, device=self.device)
-        scratch = torch.empty(L.csm_nms_scratch_bytes(i32(n)), dtype=torch.uint8, device=self.device)
-        check(L.csm_nms(ptr(boxes), ptr(offs), i32(n), f32(cfg.nms_iou), i32(cfg.max_per_img), ptr(keep), ptr(nk),
-                        ptr(scratch), stream_ptr()), "nms")
-        kidx = keep[:int(nk.item())].long()
-        out.update(n=int(kidx.shape[0]), boxes=boxes[kidx], scores=scores[kidx], priors=priors[kidx].contiguous(),
-                   kernels=kernels[kidx].contiguous(), labels=labels[kidx])
-        return out
+            valid = valid & ((boxes[..., 2] - boxes[..., 0]) > cfg.min_bbox_size) & ((boxes[..., 3] - boxes[..., 1]) > cfg.min_bbox_size)
+        scores = torch.where(valid, scores, scores.new_full((), -1.0))
+        boxes = boxes * valid[..., None]
+        scores, order = scores.sort(dim=1, descending=True, stable=True)
+        K = min(scores.shape[1], 4096)
+        scores, order = scores[:, :K], order[:, :K]
+        g4 = order[..., None].expand(-1, -1, 4)
+        boxes, priors = torch.gather(boxes, 1, g4).contiguous(), torch.gather(priors, 1, g4)
+        kernels = torch.gather(kernels, 1, order[..., None].expand(-1, -1, cfg.num_gen_params))
+        labels = torch.gather(labels, 1, order)
+        offs = (labels.float() * (boxes.amax(dim=(1, 2), keepdim=False)[:, None] + 1)).contiguous() if nc > 1 else None
+        keep = torch.zeros((nb, cfg.max_per_img), dtype=torch.int32, device=dev)
+        nk = torch.zeros(nb, dtype=torch.int32, device=dev)
+        scratch = torch.empty(L.csm_nms_scratch_bytes(i32(K)), dtype=torch.uint8, device=dev)
+        for bi in range(nb):
+            check(L.csm_nms(ptr(boxes[bi]), ptr(None if offs is None else offs[bi]), i32(K), f32(cfg.nms_iou), i32(cfg.max_per_img),
+                            ptr(keep[bi]), ptr(nk[bi:bi + 1]), ptr(scratch), stream_ptr()), "nms")
+        kept_scores = torch.gather(scores, 1, keep.long())
+        nk_h, ks_h = nk.tolist(), kept_scores.tolist()                             # the one host sync of the decode
+        outs = []
+        for bi in range(nb):
+            n = sum(1 for j in range(nk_h[bi]) if ks_h[bi][j] > cfg.score_thr)    # valid ones come first in keep[]
+            out = dict(H=H, W=W, S=S, rh=rh, rw=rw, w_scale=w_scale, h_scale=h_scale, rp=rp, cp=cp, bi=bi, n=n)
+            if n:
+                kidx = keep[bi, :n].long()
+                out.update(boxes=boxes[bi][kidx], scores=scores[bi][kidx], priors=priors[bi][kidx].contiguous(),
+                           kernels=kernels[bi][kidx].contiguous(), labels=labels[bi][kidx], scores_host=ks_h[bi][:n])
+            outs.append(out)
+        return outs
 
     def _masks_from(self, d, sel=None):
         """dynamic-conv mask head + resize + sigmoid + threshold -> uint8 [n,H,W] on device"""
@@ -293,9 +306,16 @@ class AnimeInsSeg:
     def _instances_from(self, d, pred_score_thr: float = 0.3) -> AnimeInstances:
         if d['n'] == 0:
             return AnimeInstances()
-        sel = (d['scores'] > pred_score_thr).nonzero()[:, 0]                       # reference :452
-        if sel.numel() < 1:
-            return AnimeInstances()
+        hs = d.get('scores_host')
+        if hs is not None:                                                         # reference :452, decided from the synced copy
+            idx = [j for j, v in enumerate(hs) if np.float32(v) > np.float32(pred_score_thr)]
+            if not idx:
+                return AnimeInstances()
+            sel = torch.tensor(idx, dtype=torch.long, device=self.device)
+        else:
+            sel = (d['scores'] > pred_score_thr).nonzero()[:, 0]
+            if sel.numel() < 1:
+                return AnimeInstances()
         masks = self._masks_from(d, sel).bool()
         bboxes = d['boxes'][sel].to(torch.int32)                                   # :458-459 xyxy -> xywh (truncation)
         bboxes[:, 2:] -= bboxes[:, :2]

@@ -78,9 +78,10 @@ int csm_spatial_filter_median5(const float *in, float *out, int BC, int H, int W
 int csm_depth_to_points(const float *depth, float *pts, int B, int H, int W, double focal, void *stream);
 
 /* kenburns_effect.py:928-933 fused: normalised disparity [1,1,H,W] (already /max*baseline) ->
- * depth = (1/(disp+eps))*focal*baseline, valid, points (depth*valid), unaltered points.  disp_max = max(disparity);
+ * depth = (1/(disp+eps))*focal*baseline, valid, points (depth*valid), unaltered points.  disp_max -> ONE float in device
+ * memory holding max(disparity) (a device pointer so the caller needs no host sync);
  * eps = 1e-5 at kenburns_effect.py:929, 1e-7 at :458 and pointcloud_inpainting.py:117. */
-int csm_disparity_to_points(const float *disp, float disp_max, int H, int W, double focal, double baseline, float eps,
+int csm_disparity_to_points(const float *disp, const float *disp_max, int H, int W, double focal, double baseline, float eps,
                             float *depth, float *valid, float *pts, float *unaltered, void *stream);
 
 /* tensor part of process_shift   common.py:74-81 ; shift = float32(sx,sy,sz) */
