@@ -244,7 +244,7 @@ class FrameWorkload(Workload):
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         n_launch = sum(v["conv_launches"] for v in per_net.values())
         tot_fl /= self.frames_per_step
-        return {"bound": "mfma", "kernel": "k_conv_mfma (fp32 implicit GEMM, all conv launches of one step = %d frames)" % self.frames_per_step,
+        return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_mfma (fp32 implicit GEMM, all conv launches of one step = %d frames)" % self.frames_per_step,
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                 "traffic": load_traffic("k_conv_mfma"), "algorithmic_flops_per_frame": tot_fl,
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_frame": n_launch, "per_net": per_net}

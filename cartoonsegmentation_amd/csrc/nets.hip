@@ -19,6 +19,9 @@
 //     that the 3x3 halo re-reads of neighbouring tiles hit the same 4 MiB L2.
 // Numerical contract: see include/csm355.h (one fmaf chain per output, fixed K order).
 #include "csm_common.h"
+#include <array>
+#include <cstdlib>
+#include <map>
 #include <vector>
 
 namespace {
@@ -82,7 +85,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 //            1024 SIMDs get work.  LDS 8-blocks are stored permuted [0,2,4,6,1,3,5,7]; lane (i, g) reads float2 at
 //            position 2g: MFMA 1 multiplies channels (0,4,1,5), MFMA 2 (2,6,3,7).
 // Both give the contract's chain order 0,4,1,5,2,6,3,7 per 8-block, so they are bit-identical to each other.
-template <int MT, int WM, int WN, int TN>
+// FULLK: cin_g % 32 == 0, every chunk is 4 full 8-channel blocks -> the MFMA phase is straight-line code (no branch
+// around it: a branch makes hipcc copy the 16 accumulator registers out and back every chunk behind a full MFMA drain).
+#ifdef CSM_CONV_ABLATE
+#define CSM_DBG(a) ((a).dbg)          // tuning build only (make ABLATE=1): phases can be switched off at run time
+#else
+#define CSM_DBG(a) 0
+#endif
+template <int MT, int WM, int WN, int TN, bool FULLK>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_mfma(ConvArgs a) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = MT * WM, BN = MT * WN * TN;
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
     unsigned vbits[2] = {0u, 0u};           // validity of each load of a set (A: bit it, B: bit 8+it); zeros are applied at the LDS store
     auto gload = [&](const int set, const bool live) {   // always issues the same number of loads (see below)
         const int64_t toff = ((int64_t)l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32;
-        const bool cv = live && !(a.dbg & 1) && l_cb * 32 + c4 < a.cin_g;
+        const bool cv = live && !(CSM_DBG(a) & 1) && (FULLK || l_cb * 32 + c4 < a.cin_g);
         unsigned vb = 0u;
         // Loads are UNCONDITIONAL and their count per step is fixed (dead lanes / dead steps read a safe address): a branch
         // around a load makes hipcc fall back to vmcnt(0..3) at the next use, which would serialise the two-deep prefetch.
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             int row = (tid + NT * it) >> 3;
-            bool v = live && !(a.dbg & 1) && n0 + row < a.npad && (B_FULL || row < BN);
+            bool v = live && !(CSM_DBG(a) & 1) && n0 + row < a.npad && (B_FULL || row < BN);
             const float *p = v ? wp[it] : a.w;
             rb[set][it] = *reinterpret_cast<const float4 *>(p);
             vb |= v ? (1u << (8 + it)) : 0u;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
         }
     };
     auto lstore = [&](const int set, int buf) {
-        if (a.dbg & 4) return;
+        if (CSM_DBG(a) & 4) return;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
             if (A_FULL || ((tid + NT * it) >> 3) < BM)
@@ -242,16 +252,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
     int cb = c_begin % a.ncb;
     auto compute = [&](int chunk) {
         const int buf = chunk & 1;
-        int rem = a.cin_g - cb * 32;
-        if (++cb == a.ncb) cb = 0;
         const float *A = lds + buf * kStage + (MT * wm + li) * kLdsLd + (MT == 32 ? 4 : 2) * lh;
         const float *B = lds + buf * kStage + (BM + MT * TN * wn + li) * kLdsLd + (MT == 32 ? 4 : 2) * lh;
-        if (a.dbg & 2) {
-        } else if (rem >= 32) {
+        if (CSM_DBG(a) & 2) return;
+        if (FULLK) {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) kblock(A, B, kb);
         } else {
-            int nkb = (rem + 7) >> 3;
+            int rem = a.cin_g - cb * 32;
+            if (++cb == a.ncb) cb = 0;
+            int nkb = rem >= 32 ? 4 : (rem + 7) >> 3;
+#pragma unroll 1
             for (int kb = 0; kb < nkb; ++kb) kblock(A, B, kb);
         }
     };
@@ -284,13 +295,187 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
             int m = m0 + MT * wm + row;
             if (m >= a.M) continue;
             float v = acc[tn][r];
-            if (a.dbg & 8) { if (v == 123.456f) a.out.p[0] = v; continue; }
+            if (CSM_DBG(a) & 8) { if (v == 123.456f) a.out.p[0] = v; continue; }
             if (a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
             if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
             v = apply_act(v, a.act, slope);
             if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
             a.out.p[(int64_t)m * a.out.ld + cout_off + n] = v;
         }
+    }
+}
+
+
+// ---- LDS-DMA implicit-GEMM convolution (the main kernel) ------------------------------------------------------------
+// Same arithmetic as k_conv_mfma (one fmaf chain per output, chunk = (tap, 32 channels), 8-block order 0,4,1,5,2,6,3,7) --
+// what changes is how operands reach the matrix pipe:
+//  * tiles go global -> LDS by `buffer_load_dwordx4 ... lds` (no staging VGPRs, no ds_write, no per-element zero select):
+//    one wave-instruction moves 8 rows x 128 B.  Out-of-image taps, M / N tails use the buffer range check: their lanes
+//    carry offset 0x80000000, the load is out of range and the DMA writes zeros.
+//  * LDS rows are exactly 128 B (the DMA writes lane-linear), 16-B slots XOR-swizzled by (row>>1)&7: applied to the SOURCE
+//    address of the DMA and to the ds_read_b128 address, conflict-free for the 4x16 lane groups of ds_read_b128.
+//  * each wave owns TM x TN accumulators of 32x32 (independent MFMA chains interleave, A/B fragments reused TN/TM times);
+//    block tile (32 TM WM) x (32 TN WN), two LDS stages, ONE raw s_barrier per chunk, vmcnt counted by hand (the loads are
+//    asm: with the builtin hipcc puts vmcnt(0) in front of every ds_read and the prefetch serialises).
+// Requirements (host-checked, else k_conv_mfma): cin_g % 32 == 0, kh*kw <= 32, views < 2 GiB.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma16(unsigned voff, i32x4 rsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;          // DMA pieces (8 rows) per wave per chunk
+    static_assert(GA * 8 * NW == BM && GB * 8 * NW == BN, "tile rows must split evenly over the waves");
+    constexpr int kStageF = (BM + BN) * 32;                     // floats per stage
+    constexpr unsigned kOob = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int mt;
+    {   // XCD-aware M-tile remap (speed only): block b runs on XCD b%8; each XCD gets a contiguous tile range
+        const int nt = a.m_tiles, b = blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = b & 7, loc = b >> 3;
+        mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int m0 = mt * BM, n0 = blockIdx.y * BN;
+    const int g = blockIdx.z / a.ksplit, ks = blockIdx.z - g * a.ksplit;
+    const int ho = a.out.h, wo = a.out.w;
+    const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
+    const int Tall = a.kh * a.kw * a.ncb;
+    const int c_begin = (int)(((int64_t)ks * Tall) / a.ksplit), T = (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
+
+    // buffer descriptors (raw, range-checked): activations view and this op's packed weights
+    i32x4 ra, rb;
+    {
+        uint64_t pa = (uint64_t)a.in.p, pb = (uint64_t)a.w;
+        unsigned na = (unsigned)((((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4);
+        unsigned nb = (unsigned)((int64_t)a.groups * Tall * a.npad * 128);
+        ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
+        rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
+    }
+    // per-lane loader state.  A piece g: rows 8*(wave*GA+g)+lane/8 of the tile; physical slot lane%8 holds logical slot
+    // (lane%8) ^ ((row>>1)&7).  offA = byte offset of (pixel's receptive-field origin, channel) -- may be "negative" (wraps)
+    // for border pixels; a VALID tap always brings it back inside the view.
+    unsigned offA[GA], vmA[GA], offB[GB];
+#pragma unroll
+    for (int p = 0; p < GA; ++p) {
+        int row = 8 * (wave * GA + p) + (lane >> 3);
+        int slot = (lane & 7) ^ ((row >> 1) & 7);
+        int m = m0 + row;
+        bool rv = m < a.M;
+        int mm = rv ? m : 0;
+        int n = mm / (ho * wo), rem = mm - n * ho * wo;
+        int oy = rem / wo, ox = rem - oy * wo;
+        int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        offA[p] = (unsigned)(((n * a.in.h + iy0) * a.in.w + ix0) * a.in.ld + cin_off + slot * 4) * 4u;
+        unsigned vm = 0u;
+        if (rv)
+            for (int kh = 0; kh < a.kh; ++kh)
+                for (int kw = 0; kw < a.kw; ++kw) {
+                    int iy = iy0 + kh * a.dil, ix = ix0 + kw * a.dil;
+                    if (iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w) vm |= 1u << (kh * a.kw + kw);
+                }
+        vmA[p] = vm;
+    }
+#pragma unroll
+    for (int p = 0; p < GB; ++p) {
+        int row = 8 * (wave * GB + p) + (lane >> 3);
+        int slot = (lane & 7) ^ ((row >> 1) & 7);
+        offB[p] = n0 + row < a.npad ? (unsigned)((n0 + row) * 32 + slot * 4) * 4u : kOob;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned ldsA = lds0 + (unsigned)(wave * GA * 8) * 128u, ldsB = lds0 + (unsigned)(BM + wave * GB * 8) * 128u;
+
+    // loader position = the NEXT chunk to fetch (block-uniform)
+    int l_tap = c_begin / a.ncb, l_cb = c_begin - l_tap * a.ncb;
+    int l_kh = l_tap / a.kw, l_kw = l_tap - l_kh * a.kw;
+    unsigned l_w = (unsigned)(((int64_t)g * Tall + c_begin) * a.npad * 128);     // byte offset of the chunk's weight tile
+    auto issue = [&](int stage) {
+        const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
+        const unsigned sb = (unsigned)stage * (unsigned)(kStageF * 4);
+#pragma unroll
+        for (int p = 0; p < GA; ++p)
+            dma16(((vmA[p] >> l_tap) & 1u) ? offA[p] + coff : kOob, ra, ldsA + sb + (unsigned)p * 1024u);
+#pragma unroll
+        for (int p = 0; p < GB; ++p)
+            dma16(offB[p] == kOob ? kOob : offB[p] + l_w, rb, ldsB + sb + (unsigned)p * 1024u);
+        l_w += (unsigned)a.npad * 128u;
+        if (++l_cb == a.ncb) { l_cb = 0; ++l_tap; if (++l_kw == a.kw) { l_kw = 0; ++l_kh; } }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int n = n0 + 32 * (TN * wn + j) + li;
+        float b = (a.bias && ks == 0 && n < a.cout_g) ? a.bias[cout_off + n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+    }
+    // MFMA-side fragment addresses: row (32*tile + li), logical slot 2*kb + lh -> physical ^ ((li>>1)&7)
+    int sw[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) sw[kb] = ((2 * kb + lh) ^ ((li >> 1) & 7)) * 4;
+    const int rowA = (32 * TM * wm + li) * 32, rowB = (BM + 32 * TN * wn + li) * 32;
+    auto compute = [&](int stage) {
+        const float *S = lds + stage * kStageF;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(S + rowA + i * 1024 + sw[kb]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(S + rowB + j * 1024 + sw[kb]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = t == 0 ? af[i].x : (t == 1 ? af[i].y : (t == 2 ? af[i].z : af[i].w));
+                        const float bv = t == 0 ? bf[j].x : (t == 1 ? bf[j].y : (t == 2 ? bf[j].z : bf[j].w));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+        }
+    };
+
+    issue(0);
+    for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of `chunk` have landed ...
+        __builtin_amdgcn_s_barrier();                          // ... everybody's have, and everybody is done reading stage st^1
+        if (chunk + 1 < T) issue(st ^ 1);
+        compute(st);
+    }
+
+    // epilogue: lane holds column li of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int n = n0 + 32 * (TN * wn + j) + li;
+        if (n >= a.cout_g) continue;
+        float slope = a.slope ? a.slope[cout_off + n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r];
+                if (a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
+                if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
+                v = apply_act(v, a.act, slope);
+                if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
+                a.out.p[(int64_t)m * a.out.ld + cout_off + n] = v;
+            }
     }
 }
 
@@ -464,41 +649,84 @@ __global__ __launch_bounds__(256) void k_nhwc_to_nchw(View in, float *__restrict
     dst[idx] = in.p[(n * hw + p) * in.ld + c];
 }
 
-template <int MT, int WM, int WN, int TN>
-int launch_conv(const ConvArgs &a0, hipStream_t st) {
+template <int MT, int WM, int WN, int TN, bool FULLK>
+int launch_conv_k(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = MT * WM, BN = MT * WN * TN;
     ConvArgs a = a0;
     a.m_tiles = (a.M + BM - 1) / BM;
     size_t lds = (size_t)2 * (BM + BN) * kLdsLd * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_mfma<MT, WM, WN, TN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_mfma<MT, WM, WN, TN, FULLK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * a.ksplit);
-    k_conv_mfma<MT, WM, WN, TN><<<grid, 64 * WM * WN, lds, st>>>(a);
+    k_conv_mfma<MT, WM, WN, TN, FULLK><<<grid, 64 * WM * WN, lds, st>>>(a);
     int rc = csm::check_launch("k_conv_mfma");
     if (rc || a.ksplit <= 1) return rc;
     k_splitk_reduce<<<(unsigned)(((int64_t)a.M * a.cout_g + 255) / 256), 256, 0, st>>>(a);
     return csm::check_launch("k_splitk_reduce");
 }
 
+template <int MT, int WM, int WN, int TN>
+int launch_conv(const ConvArgs &a, hipStream_t st) {
+    return (a.cin_g & 31) == 0 ? launch_conv_k<MT, WM, WN, TN, true>(a, st) : launch_conv_k<MT, WM, WN, TN, false>(a, st);
+}
+
+
+template <int WM, int WN, int TM, int TN>
+int launch_conv_dma(const ConvArgs &a0, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    ConvArgs a = a0;
+    a.m_tiles = (a.M + BM - 1) / BM;
+    size_t lds = (size_t)2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma<WM, WN, TM, TN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * a.ksplit);
+    k_conv_dma<WM, WN, TM, TN><<<grid, 64 * WM * WN, lds, st>>>(a);
+    int rc = csm::check_launch("k_conv_dma");
+    if (rc || a.ksplit <= 1) return rc;
+    k_splitk_reduce<<<(unsigned)(((int64_t)a.M * a.cout_g + 255) / 256), 256, 0, st>>>(a);
+    return csm::check_launch("k_splitk_reduce");
+}
+
+static bool dma_eligible(const ConvArgs &a) {
+    int64_t bytes_in = (((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4;
+    int64_t bytes_w = (int64_t)a.groups * a.kh * a.kw * a.ncb * a.npad * 128;
+    return (a.cin_g & 31) == 0 && a.kh * a.kw <= 32 && bytes_in < (1ll << 31) && bytes_w < (1ll << 31) && !(a.in.ld & 3) &&
+           !(((uintptr_t)a.in.p | (uintptr_t)a.w) & 15);
+}
+
 // ---- tile selection ---------------------------------------------------------------------------------------
 // Measured on the three nets (tools/conv_bench.py --sweep, profiles/): occupancy beats register-tile reuse in this
 // two-stage pipeline, so the default is the 64x64 tile (4 blocks = 16 waves per CU); narrow outputs get narrow tiles.
-enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CFG_128x32 = 4, CFG_64x16 = 5, CFG_COUNT = 6 };
+enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CFG_128x32 = 4, CFG_64x16 = 5,
+       // LDS-DMA kernel (k_conv_dma)
+       CFG_D64x64 = 6, CFG_D128x64 = 7, CFG_D128x128 = 8, CFG_D128x128_8w = 9, CFG_D256x128_8w = 10, CFG_D64x128 = 11, CFG_D128x32 = 12, CFG_COUNT = 13 };
 static int g_force_cfg = -1;
 static int g_dbg = 0;
 
-static int choose_cfg(int M, int N, int groups) {
-    (void)M; (void)groups;
+static void read_force_env() {
+    static bool env_read = false;
+    if (env_read) return;      // tuning aid: CSM_FORCE_CONV_CFG=<n> forces one tile configuration for every eligible conv
+    env_read = true;
+    const char *e = getenv("CSM_FORCE_CONV_CFG");
+    if (e && *e) g_force_cfg = atoi(e);
+}
+
+// Default rule when an op carries no tuned tile (csm_op.tile == 0): the LDS-DMA kernel with the 64x64 tile wins or ties on
+// every layer of the three nets at batch 1 (profiles/r01_conv_sweep.txt); narrow outputs get narrow tiles.
+static int choose_cfg(const ConvArgs &a, int N) {
+    read_force_env();
     if (g_force_cfg >= 0 && g_force_cfg < CFG_COUNT) return g_force_cfg;
     if (N <= 16) return CFG_64x16;
-    if (N <= 32) return CFG_128x32;
-    // With the two-chunk-ahead loader the 64x64 tile wins on every layer measured (r01 sweep, second pass): the 128x128
-    // variants run out of registers (spills at the 128-VGPR occupancy bound) and are kept for tuning only.
-    return CFG_64x64;
+    if (N <= 32) return dma_eligible(a) ? CFG_D128x32 : CFG_128x32;
+    return CFG_D64x64;
 }
 
 static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
@@ -508,6 +736,13 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_128x128_8w: return launch_conv<32, 4, 2, 2>(a, st);
         case CFG_128x32: return launch_conv<32, 4, 1, 1>(a, st);
         case CFG_64x16: return launch_conv<16, 4, 1, 1>(a, st);
+        case CFG_D64x64: return launch_conv_dma<2, 2, 1, 1>(a, st);
+        case CFG_D128x64: return launch_conv_dma<2, 2, 2, 1>(a, st);
+        case CFG_D64x128: return launch_conv_dma<2, 2, 1, 2>(a, st);
+        case CFG_D128x128: return launch_conv_dma<2, 2, 2, 2>(a, st);
+        case CFG_D128x128_8w: return launch_conv_dma<2, 4, 2, 1>(a, st);
+        case CFG_D256x128_8w: return launch_conv_dma<4, 2, 2, 2>(a, st);
+        case CFG_D128x32: return launch_conv_dma<4, 1, 1, 1>(a, st);
         default: return launch_conv<32, 2, 2, 1>(a, st);
     }
 }
@@ -559,7 +794,9 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                     csm::set_error("op %d: conv input must be 16-byte aligned with channels %% 4 == 0", i); return CSM_ERR_ARG;
                 }
                 a.dbg = g_dbg;
-                rc = launch_conv_cfg(choose_cfg(a.M, op.cout_g, op.groups), a, st);
+                int cfg = (op.tile > 0 && op.tile <= CFG_COUNT && g_force_cfg < 0) ? op.tile - 1 : choose_cfg(a, op.cout_g);
+                if (cfg >= CFG_D64x64 && !dma_eligible(a)) cfg = op.cout_g <= 16 ? CFG_64x16 : (op.cout_g <= 32 ? CFG_128x32 : CFG_64x64);
+                rc = launch_conv_cfg(cfg, a, st);
                 if (rc) return rc;
                 break;
             }
@@ -642,6 +879,60 @@ extern "C" int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_t
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+static std::map<std::array<int, 16>, int> g_tile_cache;
+
+extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors, const float *weights,
+                                 float *workspace, void *const *ext, int n_ext, void *stream, int reps) {
+    CSM_REQUIRE(ops && tensors && n_ops >= 0 && n_tensors > 0);
+    read_force_env();
+    if (g_force_cfg >= 0) return 0;
+    if (reps < 1) reps = 3;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t ev[2];
+    CSM_HIP(hipEventCreate(&ev[0])); CSM_HIP(hipEventCreate(&ev[1]));
+    int tuned = 0, rc = CSM_OK;
+    for (int i = 0; i < n_ops && rc == CSM_OK; ++i) {
+        csm_op &op = ops[i];
+        if (op.kind != CSM_OP_CONV) continue;
+        const int npad = (op.cout_g + 31) / 32 * 32;
+        static const int cand_all[] = {CFG_64x64, CFG_128x32, CFG_64x16, CFG_D64x64, CFG_D128x64, CFG_D64x128, CFG_D128x128,
+                                       CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32};
+        static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32};
+        // identical layers (same shapes / strides / split) share one measurement, also across programs
+        View vin{}, vout{};
+        rc = make_view(tensors, n_tensors, op.in0, workspace, ext, n_ext, vin); if (rc) break;
+        rc = make_view(tensors, n_tensors, op.out, workspace, ext, n_ext, vout); if (rc) break;
+        const std::array<int, 16> key = {vin.n, vin.h, vin.w, vin.ld, vout.h, vout.w, vout.ld, op.kh, op.kw, op.stride, op.dil,
+                                         op.groups, op.cin_g, op.cout_g, op.ksplit, op.pad};
+        auto hit = g_tile_cache.find(key);
+        if (hit != g_tile_cache.end()) { op.tile = hit->second; ++tuned; continue; }
+        float best = 1e30f; int best_cfg = -1;
+        for (size_t c = 0; c < sizeof(cand_all) / sizeof(int); ++c) {
+            if (cand_bn[c] >= 2 * npad && cand_bn[c] > 32) continue;      // tile much wider than the output: never wins
+            if (cand_bn[c] == 16 && op.cout_g > 16) continue;
+            if (cand_bn[c] == 32 && op.cout_g > 64) continue;
+            op.tile = cand_all[c] + 1;
+            float tmin = 1e30f;
+            for (int r = 0; r <= reps; ++r) {                              // r == 0 warms up (and sets the LDS attribute)
+                CSM_HIP(hipEventRecord(ev[0], st));
+                rc = run_ops(&op, 1, tensors, n_tensors, weights, workspace, ext, n_ext, st, nullptr);
+                if (rc) break;
+                CSM_HIP(hipEventRecord(ev[1], st));
+                CSM_HIP(hipEventSynchronize(ev[1]));
+                float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+                if (r > 0 && ms < tmin) tmin = ms;
+            }
+            if (rc) break;
+            if (tmin < best) { best = tmin; best_cfg = cand_all[c]; }
+        }
+        op.tile = best_cfg >= 0 ? best_cfg + 1 : 0;
+        g_tile_cache[key] = op.tile;
+        ++tuned;
+    }
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    return rc == CSM_OK ? tuned : -rc;
 }
 
 // debug / tuning knob: low byte = forced conv tile configuration (-1 = built-in rule), bits 8.. = phase-ablation flags

@@ -28,7 +28,7 @@ class CsmOp(ctypes.Structure):
                 ("cout_g", ctypes.c_int32), ("act", ctypes.c_int32), ("res_mode", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64), ("aux_off", ctypes.c_int64),
                 ("flags", ctypes.c_int32), ("ksplit", ctypes.c_int32), ("scratch", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("tile", ctypes.c_int32)]
 
 
 def fold_bn(w, b, gamma, beta, mean, var, eps):
@@ -325,7 +325,7 @@ class Program:
             nat = d.pop('nat')
             if oracle and nat:
                 d.update(nat)
-            ops[i] = CsmOp(**{k: int(v) for k, v in d.items()}, reserved=0)
+            ops[i] = CsmOp(**{k: int(v) for k, v in d.items()}, tile=0)
         ws = self.w_nat if oracle else self.w_hip
         weights = np.concatenate(ws) if ws else np.zeros(4, np.float32)
         return ops, tens, weights

@@ -1,5 +1,6 @@
 """Device-side execution of a lowered Program through libcsm355's csm_run_program."""
 import ctypes
+import os
 
 import torch
 
@@ -19,13 +20,31 @@ class CompiledProgram:
         self.workspace = torch.empty(max(prog.workspace_floats, 64), dtype=torch.float32, device=self.device)
         self.n_ext = prog.n_ext
         self._ext = (ctypes.c_void_p * max(self.n_ext, 1))()
+        self._tuned = os.environ.get("CSM_AUTOTUNE", "1") != "1"
 
-    def run(self, *ext_tensors):
+    def _bind(self, ext_tensors):
         assert len(ext_tensors) == self.n_ext, (len(ext_tensors), self.n_ext)
         for i, t in enumerate(ext_tensors):
             if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
                 raise _lib.CsmError("program ext tensor %d must be a contiguous float32 device tensor" % i)
             self._ext[i] = t.data_ptr()
+
+    def autotune(self, *ext_tensors, reps=3):
+        """time every eligible tile configuration of every conv op once (csm_conv_autotune) and keep the fastest in
+        ops[i].tile.  Speed only -- all configurations give the same bits.  Clobbers the workspace and ext outputs."""
+        self._bind(ext_tensors)
+        n = _lib.load().csm_conv_autotune(self.ops, ctypes.c_int(len(self.ops)), self.tensors, ctypes.c_int(len(self.tensors)),
+                                          ctypes.c_void_p(self.weights.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()),
+                                          self._ext, ctypes.c_int(self.n_ext), stream_ptr(), ctypes.c_int(reps))
+        if n < 0:
+            check(-n, "conv_autotune(%s)" % self.prog.name)
+        self._tuned = True
+        return n
+
+    def run(self, *ext_tensors):
+        if not self._tuned:                       # first call: pick tiles on the real buffers (CSM_AUTOTUNE=0 disables)
+            self.autotune(*ext_tensors)
+        self._bind(ext_tensors)
         check(_lib.load().csm_run_program(self.ops, ctypes.c_int(len(self.ops)), self.tensors,
                                           ctypes.c_int(len(self.tensors)), ctypes.c_void_p(self.weights.data_ptr()),
                                           ctypes.c_void_p(self.workspace.data_ptr()), self._ext, ctypes.c_int(self.n_ext),
@@ -33,8 +52,10 @@ class CompiledProgram:
 
     def profile(self, *ext_tensors):
         """per-op durations in ms (HIP events on the launch stream); returns list aligned with prog.ops"""
-        for i, t in enumerate(ext_tensors):
-            self._ext[i] = t.data_ptr()
+        if ext_tensors:
+            if not self._tuned:
+                self.autotune(*ext_tensors)
+            self._bind(ext_tensors)
         ms = (ctypes.c_float * len(self.ops))()
         check(_lib.load().csm_run_program_profile(self.ops, ctypes.c_int(len(self.ops)), self.tensors,
                                                   ctypes.c_int(len(self.tensors)), ctypes.c_void_p(self.weights.data_ptr()),

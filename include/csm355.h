@@ -155,8 +155,15 @@ typedef struct csm_op {
                                 [s*T/ksplit, (s+1)*T/ksplit); each run is its own fmaf chain (run 0 starts at the bias,
                                 the others at 0) and the runs are added in order ((p0+p1)+p2)...  1 = single chain */
     int32_t scratch;         /* tensor id of the [n,h,w,ksplit*cout] partial-sum buffer when ksplit > 1, else -1 */
-    int32_t reserved;
+    int32_t tile;            /* CONV: 0 = built-in tile rule, k > 0 = tile configuration k-1 (speed only: every configuration
+                                produces the same bits); filled in by csm_conv_autotune */
 } csm_op;
+
+/* Measure every eligible tile configuration of every CONV op on the device (HIP events on `stream`, `reps` timed launches
+ * each, minimum taken) and store the fastest in ops[i].tile.  Results are unchanged by construction (same fmaf chains);
+ * the workspace contents are clobbered.  Returns the number of ops tuned (>= 0) or a negative status. */
+int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors, const float *weights,
+                      float *workspace, void *const *ext, int n_ext, void *stream, int reps);
 
 /* Execute ops[0..n_ops) in order on `stream`.  `weights` and `workspace` are device pointers;
  * ext[i] are device pointers of external (caller-owned) tensors. */
