@@ -452,9 +452,25 @@ class KenBurnsPipeline:
         batched detector run, shared ISNet refine batches and one batched LeReS run; the per-frame glue is unchanged."""
         with torch.no_grad():
             imgs_d = [self.animeinsseg._upload(im) for im in imgs]
-            insts = self.animeinsseg.infer(list(imgs_d), self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None,
-                                           output_type='tensor', max_instances=self.max_instances)
-            coarse = self._depth_est_leres_batch(imgs_d)
+            seg = lambda: self.animeinsseg.infer(list(imgs_d), self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None,
+                                                 output_type='tensor', max_instances=self.max_instances)
+            if self.overlap_depth:
+                # LeReS only needs the images: it runs on a second HIP stream while the detector / ISNet batches (and the
+                # detector's one host sync) occupy the main stream, so kernel tails of one net are filled by the other.
+                main = torch.cuda.current_stream(self.device)
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(self.device)
+                side = self._side_stream
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    coarse = self._depth_est_leres_batch(imgs_d)
+                insts = seg()
+                main.wait_stream(side)
+                for c in coarse:
+                    c.record_stream(main)
+            else:
+                insts = seg()
+                coarse = self._depth_est_leres_batch(imgs_d)
             saved = self.overlap_depth
             try:
                 self.overlap_depth = False

@@ -10,7 +10,11 @@ from cartoonsegmentation_amd.weights import SynthWeights
 KIND = {1: 'conv', 2: 'dwconv', 3: 'maxpool', 4: 'bilinear', 5: 'nearest', 6: 'add', 7: 'gavg', 8: 'scale', 9: 'to_nhwc', 10: 'to_nchw', 11: 'act', 12: 'copy'}
 
 
-def prof(name, prog, ext, top=14):
+TOP = int(os.environ.get('LP_TOP', 14))
+B = int(os.environ.get('LP_BATCH', 1))
+
+
+def prof(name, prog, ext, top=TOP):
     cp = CompiledProgram(prog, 'cuda')
     cp.run(*ext)
     ms = None
@@ -27,7 +31,7 @@ def prof(name, prog, ext, top=14):
         if o['kind'] == 1:
             nat = o['nat']
             fl = 2 * v_out.n * v_out.h * v_out.w * nat['cout_g'] * nat['groups'] * nat['cin_g'] * o['kh'] * o['kw']
-        rows.append((t, k, "%dx%dx%d->%dx%dx%d k%d s%d d%d g%d" % (v_in.h, v_in.w, v_in.c, v_out.h, v_out.w, v_out.c, o['kh'], o['stride'], o['dil'], o['groups']), fl))
+        rows.append((t, k, "%dx%dx%dx%d->%dx%dx%d k%d s%d d%d g%d S%d T%d" % (v_in.n, v_in.h, v_in.w, v_in.c, v_out.h, v_out.w, v_out.c, o['kh'], o['stride'], o['dil'], o['groups'], o.get('ksplit', 1), cp.ops[len(rows)].tile - 1), fl))
     tot = sum(ms)
     print("== %s: %.3f ms total (event-bracketed), %.1f GFLOP -> %.1f TF/s ; by kind: %s" % (name, tot, prog.flops / 1e9, prog.flops / tot / 1e9,
           ", ".join("%s %.2f" % kv for kv in sorted(by_kind.items(), key=lambda kv: -kv[1]))))
@@ -35,18 +39,19 @@ def prof(name, prog, ext, top=14):
     for t, k, d, fl in rows:
         a = agg.setdefault((k, d), [0.0, 0, 0]); a[0] += t; a[1] += 1; a[2] += fl
     for (k, d), (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
-        print("   %7.3f ms  x%-3d %-7s %-44s %6.1f TF/s" % (t, n, k, d, fl / t / 1e9 if t > 0 else 0))
+        print("   %7.3f ms  x%-3d %-7s %-52s %6.1f TF/s" % (t, n, k, d, fl / t / 1e9 if t > 0 else 0))
 
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['isnet', 'leres', 'rtmdet']
     dev = 'cuda'
     if 'isnet' in which:
-        p = nets.build_isnet(SynthWeights('isnet.'), 2, 720, 720)
-        prof('isnet n=2 720', p, [torch.rand(2, 4, 720, 720, device=dev), torch.empty(2, 1, 720, 720, device=dev)])
+        nb = min(2 * B, 8)
+        p = nets.build_isnet(SynthWeights('isnet.'), nb, 720, 720)
+        prof('isnet n=%d 720' % nb, p, [torch.rand(nb, 4, 720, 720, device=dev), torch.empty(nb, 1, 720, 720, device=dev)])
     if 'leres' in which:
-        p = nets.build_leres(SynthWeights('leres.'), 1, 640, 640)
-        prof('leres 640', p, [torch.randn(1, 3, 640, 640, device=dev), torch.empty(1, 1, 640, 640, device=dev)])
+        p = nets.build_leres(SynthWeights('leres.'), B, 640, 640)
+        prof('leres n=%d 640' % B, p, [torch.randn(B, 3, 640, 640, device=dev), torch.empty(B, 1, 640, 640, device=dev)])
     if 'rtmdet' in which:
-        rp, _ = nets.build_rtmdet(SynthWeights('rtmdet.'), 1, 640, 640)
-        prof('rtmdet 640', rp.prog, [torch.randn(1, 3, 640, 640, device=dev)])
+        rp, _ = nets.build_rtmdet(SynthWeights('rtmdet.'), B, 640, 640)
+        prof('rtmdet n=%d 640' % B, rp.prog, [torch.randn(B, 3, 640, 640, device=dev)])
