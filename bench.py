@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--workload", default="auto", help="auto | warp | frame")
-    ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step (frame workload)")
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (frame workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -159,7 +159,7 @@ class FrameWorkload(Workload):
     name = "seg+depth+warp"
     INSTANCES = 2
 
-    def __init__(self, size, rank, device, batch=4):
+    def __init__(self, size, rank, device, batch=8):
         self.frames_per_step = batch
         os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"          # no checkpoints exist offline: closed-form weights
         if rank != 0:
@@ -215,7 +215,7 @@ class FrameWorkload(Workload):
         a = self.pipe.animeinsseg
         cps = [("rtmdet-ins-l@%d n=%d" % k, v[1]) for k, v in a._det_programs.items()]
         cps += [("isnet n=%d@%d" % k, v) for k, v in a._refine_programs.items()]
-        cps += [("leres@%dx%d n=%d" % (k[1], k[0], k[2]), v) for k, v in self.pipe._leres.items()]
+        cps += [("leres@%dx%d n=%d%s" % (k[1], k[0], k[2], "" if k[3] == 0 else " #%d" % k[3]), v) for k, v in self.pipe._leres.items()]
         items = []
         for name, cp in cps:
             ext = sorted((b for b in cp.prog.bufs if b.ext >= 0), key=lambda b: b.ext)
@@ -229,7 +229,8 @@ class FrameWorkload(Workload):
                 "weights": "closed-form synthetic (no checkpoints offline)", "precision": "fp32 exact (v_mfma_f32_32x32x2_f32)"}
 
     def roofline(self):
-        """dominant kernel = k_conv_mfma: algorithmic conv FLOPs / summed launch durations (HIP events per op)"""
+        """dominant kernel = the implicit-GEMM conv (k_conv_dma tiles + k_conv_mfma fallback): algorithmic conv FLOPs / summed launch
+        durations (HIP events around every op on the launch stream)"""
         tot_ms, tot_fl, per_net = 0.0, 0.0, {}
         for name, cp, ext in self._programs():
             cp.run(*ext)
@@ -246,7 +247,7 @@ class FrameWorkload(Workload):
         tot_fl /= self.frames_per_step
         return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_mfma (fp32 implicit GEMM, all conv launches of one step = %d frames)" % self.frames_per_step,
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
-                "traffic": load_traffic("k_conv_mfma"), "algorithmic_flops_per_frame": tot_fl,
+                "traffic": load_traffic("k_conv"), "algorithmic_flops_per_frame": tot_fl,
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_frame": n_launch, "per_net": per_net}
 
     def extra(self):
@@ -257,7 +258,7 @@ class FrameWorkload(Workload):
         return oframe.cpu_baseline(seconds)
 
 
-def make_workload(kind, size, rank, device, world, dist, batch=4):
+def make_workload(kind, size, rank, device, world, dist, batch=8):
     if kind in ("auto", "frame"):
         wl = FrameWorkload(size, rank, device, batch)
     elif kind == "warp":

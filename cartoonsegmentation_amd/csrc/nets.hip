@@ -20,6 +20,7 @@
 // Numerical contract: see include/csm355.h (one fmaf chain per output, fixed K order).
 #include "csm_common.h"
 #include <array>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <vector>
@@ -933,6 +934,35 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
     }
     (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
     return rc == CSM_OK ? tuned : -rc;
+}
+
+// Tuned tiles as a text file (one line per layer signature: 16 integers + tile) so that a later process can skip the
+// measurement: load merges into the in-memory table that csm_conv_autotune consults first.
+extern "C" int csm_conv_tile_cache_save(const char *path) {
+    CSM_REQUIRE(path);
+    FILE *f = fopen(path, "w");
+    if (!f) { csm::set_error("cannot write %s", path); return CSM_ERR_ARG; }
+    for (const auto &kv : g_tile_cache) {
+        for (int v : kv.first) fprintf(f, "%d ", v);
+        fprintf(f, "%d\n", kv.second);
+    }
+    fclose(f);
+    return CSM_OK;
+}
+
+extern "C" int csm_conv_tile_cache_load(const char *path) {
+    CSM_REQUIRE(path);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;                       // no file yet: nothing cached
+    int n = 0;
+    for (;;) {
+        std::array<int, 16> key; int tile = 0; bool ok = true;
+        for (int &v : key) ok = ok && fscanf(f, "%d", &v) == 1;
+        if (!ok || fscanf(f, "%d", &tile) != 1) break;
+        if (tile >= 0 && tile <= CFG_COUNT) { g_tile_cache[key] = tile; ++n; }
+    }
+    fclose(f);
+    return n;
 }
 
 // debug / tuning knob: low byte = forced conv tile configuration (-1 = built-in rule), bits 8.. = phase-ablation flags

@@ -188,6 +188,8 @@ class KenBurnsPipeline:
         self.max_instances = 100                 # AnimeInsSeg.infer default (animeinsseg/__init__.py:417)
         self.overlap_depth = True                # MI355X: LeReS runs on a second HIP stream next to the segmentation nets
         self._side_stream = None
+        self._side_streams = []
+        self.depth_streams = int(os.environ.get('CSM_DEPTH_STREAMS', '1'))   # batched path: LeReS sub-batches on this many side streams
         self.set_detector(cfg.detector)
         self.set_depth_estimation(cfg.depth_est)
         if self.cfg.default_depth_refine:
@@ -334,14 +336,15 @@ class KenBurnsPipeline:
         return o
 
     # ---- depth (kenburns_effect.py:563-581) ------------------------------------------------------------
-    def _leres_prog(self, h, w, n=1):
-        if (h, w, n) not in self._leres:
+    def _leres_prog(self, h, w, n=1, slot=0):
+        """slot: programs that may run concurrently on different streams need their own workspace (weights are shared)"""
+        if (h, w, n, slot) not in self._leres:
             cp = CompiledProgram(build_leres(self._leres_ws, n, h, w), self.device, weights=self._leres_weights)
             self._leres_weights = cp.weights
-            self._leres[(h, w, n)] = cp
-        return self._leres[(h, w, n)]
+            self._leres[(h, w, n, slot)] = cp
+        return self._leres[(h, w, n, slot)]
 
-    def _depth_est_leres_batch(self, imgs_d):
+    def _depth_est_leres_batch(self, imgs_d, slot=0):
         """LeReS on several equally sized frames in one program run (per-sample results as _depth_est_leres)"""
         L = _lib.load()
         nb = len(imgs_d)
@@ -354,7 +357,7 @@ class KenBurnsPipeline:
         for bi, im in enumerate(imgs_d):
             check(L.csm_leres_input(ptr(im), i32(H), i32(W), i32(h), i32(w), ptr(x[bi]), stream_ptr()), "leres_input")
         y = torch.empty((nb, 1, h, w), dtype=torch.float32, device=self.device)
-        self._leres_prog(h, w, nb).run(x, y)
+        self._leres_prog(h, w, nb, slot).run(x, y)
         outs = []
         for bi in range(nb):
             yb = y[bi]
@@ -458,14 +461,22 @@ class KenBurnsPipeline:
                 # LeReS only needs the images: it runs on a second HIP stream while the detector / ISNet batches (and the
                 # detector's one host sync) occupy the main stream, so kernel tails of one net are filled by the other.
                 main = torch.cuda.current_stream(self.device)
-                if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream(self.device)
-                side = self._side_stream
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    coarse = self._depth_est_leres_batch(imgs_d)
+                k = max(1, min(self.depth_streams, len(imgs_d)))
+                while len(self._side_streams) < k:
+                    self._side_streams.append(torch.cuda.Stream(self.device))
+                per = (len(imgs_d) + k - 1) // k
+                coarse = []
+                for si in range(k):
+                    grp = imgs_d[si * per:(si + 1) * per]
+                    if not grp:
+                        continue
+                    side = self._side_streams[si]
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        coarse += self._depth_est_leres_batch(grp, slot=si)
                 insts = seg()
-                main.wait_stream(side)
+                for side in self._side_streams[:k]:
+                    main.wait_stream(side)
                 for c in coarse:
                     c.record_stream(main)
             else:

@@ -10,7 +10,8 @@ from ._lib import check, stream_ptr
 
 class CompiledProgram:
     """weights + workspace resident in HBM; run() enqueues the whole net on the current stream
-    (no allocation, no host sync -> capturable in a hipGraph via torch.cuda.graph)."""
+    (no allocation, no host sync -> capturable in a hipGraph via torch.cuda.graph; the first run() tunes the conv tiles)."""
+    _cache_loaded = False
 
     def __init__(self, prog, device, weights=None):
         self.prog = prog
@@ -33,12 +34,18 @@ class CompiledProgram:
         """time every eligible tile configuration of every conv op once (csm_conv_autotune) and keep the fastest in
         ops[i].tile.  Speed only -- all configurations give the same bits.  Clobbers the workspace and ext outputs."""
         self._bind(ext_tensors)
+        cache = os.environ.get("CSM_TUNE_CACHE")          # optional file shared between processes / runs
+        if cache and not CompiledProgram._cache_loaded:
+            _lib.load().csm_conv_tile_cache_load(cache.encode())
+            CompiledProgram._cache_loaded = True
         n = _lib.load().csm_conv_autotune(self.ops, ctypes.c_int(len(self.ops)), self.tensors, ctypes.c_int(len(self.tensors)),
                                           ctypes.c_void_p(self.weights.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()),
                                           self._ext, ctypes.c_int(self.n_ext), stream_ptr(), ctypes.c_int(reps))
         if n < 0:
             check(-n, "conv_autotune(%s)" % self.prog.name)
         self._tuned = True
+        if cache:
+            check(_lib.load().csm_conv_tile_cache_save(cache.encode()), "tile_cache_save")
         return n
 
     def run(self, *ext_tensors):

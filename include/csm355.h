@@ -165,6 +165,11 @@ typedef struct csm_op {
 int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors, const float *weights,
                       float *workspace, void *const *ext, int n_ext, void *stream, int reps);
 
+/* Persist / restore the tuned tiles (text file: layer signature -> tile).  load returns the number of entries merged (0 if the
+ * file does not exist); csm_conv_autotune consults the table before measuring. */
+int csm_conv_tile_cache_save(const char *path);
+int csm_conv_tile_cache_load(const char *path);
+
 /* Execute ops[0..n_ops) in order on `stream`.  `weights` and `workspace` are device pointers;
  * ext[i] are device pointers of external (caller-owned) tensors. */
 int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
