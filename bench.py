@@ -232,23 +232,28 @@ class FrameWorkload(Workload):
         """dominant kernel = the implicit-GEMM conv (k_conv_dma tiles + k_conv_mfma fallback): algorithmic conv FLOPs / summed launch
         durations (HIP events around every op on the launch stream)"""
         tot_ms, tot_fl, per_net = 0.0, 0.0, {}
-        for name, cp, ext in self._programs():
+        progs = self._programs()
+        before = [cp.runs for _, cp, _ in progs]
+        self.step(); torch.cuda.synchronize()                      # how often each program runs in one step (ISNet: once per 8 instances)
+        n_launch = 0
+        for (name, cp, ext), b in zip(progs, before):
+            per_step = cp.runs - b
             cp.run(*ext)
             ms = None
             for _ in range(3):
                 m = cp.profile(*ext)
                 ms = m if ms is None else [min(a, b) for a, b in zip(ms, m)]
             cms = sum(t for t, o in zip(ms, cp.prog.ops) if o['kind'] == 1)
+            nconv = sum(1 for o in cp.prog.ops if o['kind'] == 1)
             per_net[name] = {"conv_ms": round(cms, 3), "all_ops_ms": round(sum(ms), 3), "gflop": round(cp.prog.flops / 1e9, 1),
-                             "conv_launches": sum(1 for o in cp.prog.ops if o['kind'] == 1)}
-            tot_ms += cms; tot_fl += cp.prog.flops
+                             "conv_launches": nconv, "runs_per_step": per_step}
+            tot_ms += cms * per_step; tot_fl += cp.prog.flops * per_step; n_launch += nconv * per_step
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        n_launch = sum(v["conv_launches"] for v in per_net.values())
         tot_fl /= self.frames_per_step
         return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_mfma (fp32 implicit GEMM, all conv launches of one step = %d frames)" % self.frames_per_step,
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                 "traffic": load_traffic("k_conv"), "algorithmic_flops_per_frame": tot_fl,
-                "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_frame": n_launch, "per_net": per_net}
+                "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_step": n_launch, "per_net": per_net}
 
     def extra(self):
         return {}

@@ -7,6 +7,7 @@ op emission.  The same Program object yields
 so that the two executions share nothing but the op order and tensor plan.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -63,6 +64,12 @@ def pack_conv_weights(w, groups):
     full[:, :cout_sg, :cin_sg] = wsg
     packed = full.reshape(sg, npad, ncb, 32, kh, kw).transpose(0, 4, 5, 2, 1, 3)     # sg,kh,kw,cb,npad,32
     return np.ascontiguousarray(packed).reshape(-1), sg, cin_sg, cout_sg
+
+
+# split-K rule (part of the numerical contract of a lowered program): below KSPLIT_BELOW 64x64 output tiles, cut K so that about
+# KSPLIT_TARGET blocks exist
+KSPLIT_BELOW = int(os.environ.get('CSM_KSPLIT_BELOW', '256'))
+KSPLIT_TARGET = int(os.environ.get('CSM_KSPLIT_TARGET', '768'))
 
 
 class Buf:
@@ -193,9 +200,9 @@ class Program:
         if not self.split_k or groups != 1:
             return 1
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        if tiles >= 256 or T < 8:      # >= 1 block per CU: the extra reduce launch (~6 us) costs more than it buys
+        if tiles >= KSPLIT_BELOW or T < 8:      # enough blocks per CU: the extra reduce launch (~6 us) costs more than it buys
             return 1
-        s = min(-(-768 // tiles), T // 4, 16)
+        s = min(-(-KSPLIT_TARGET // tiles), T // 4, 16)
         return s if s >= 2 else 1
 
     def dwconv(self, x, w, b=None, stride=1, pad=0, dil=1, act=None, out=None):

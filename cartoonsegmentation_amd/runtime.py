@@ -22,6 +22,7 @@ class CompiledProgram:
         self.n_ext = prog.n_ext
         self._ext = (ctypes.c_void_p * max(self.n_ext, 1))()
         self._tuned = os.environ.get("CSM_AUTOTUNE", "1") != "1"
+        self.runs = 0                              # number of run() calls (bench.py weights its per-op profile by it)
 
     def _bind(self, ext_tensors):
         assert len(ext_tensors) == self.n_ext, (len(ext_tensors), self.n_ext)
@@ -52,6 +53,7 @@ class CompiledProgram:
         if not self._tuned:                       # first call: pick tiles on the real buffers (CSM_AUTOTUNE=0 disables)
             self.autotune(*ext_tensors)
         self._bind(ext_tensors)
+        self.runs += 1
         check(_lib.load().csm_run_program(self.ops, ctypes.c_int(len(self.ops)), self.tensors,
                                           ctypes.c_int(len(self.tensors)), ctypes.c_void_p(self.weights.data_ptr()),
                                           ctypes.c_void_p(self.workspace.data_ptr()), self._ext, ctypes.c_int(self.n_ext),

@@ -14,6 +14,8 @@ python tools/layer_profile.py 2>/dev/null > $OUT/layer_profile.txt; grep "^==" $
 [ "$2" = "quick" ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o frame -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+# same workload with the LeReS side stream off: kernels do not overlap, so durations are per-kernel clean (HIP-event comparable)
+CSM_OVERLAP_DEPTH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o frame -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats_serial.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_warp -o warp -- python /root/repo/bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_warp.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o frame -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
