@@ -304,6 +304,8 @@ def main():
 
     wl.step_and_gather()                      # compiles the layer programs (lazy) -- untimed
     bcast_bytes = wl.broadcast_weights() if (dist is not None and hasattr(wl, "broadcast_weights")) else 0
+    if dist is not None:
+        wl.step_and_gather()                  # ranks != 0 now hold real weights: build/tune whatever their first step skipped -- untimed
     for _ in range(a.warmup):
         wl.step_and_gather()
     if dist is not None:

@@ -68,7 +68,7 @@ def pack_conv_weights(w, groups):
 
 # split-K rule (part of the numerical contract of a lowered program): below KSPLIT_BELOW 64x64 output tiles, cut K so that about
 # KSPLIT_TARGET blocks exist
-KSPLIT_BELOW = int(os.environ.get('CSM_KSPLIT_BELOW', '256'))
+KSPLIT_BELOW = int(os.environ.get('CSM_KSPLIT_BELOW', '512'))
 KSPLIT_TARGET = int(os.environ.get('CSM_KSPLIT_TARGET', '768'))
 
 
