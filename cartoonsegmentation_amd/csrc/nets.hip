@@ -480,6 +480,122 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     }
 }
 
+
+// ---- narrow-output convolution (cout <= 4, groups == 1, no split-K): ISNet side outputs / LeReS last conv -------------------
+// An N = 1 output wastes 31/32 of an MFMA tile; this is the same fmaf chain (taps row-major, 8-channel blocks in the order
+// 0,4,1,5,2,6,3,7; out-of-image taps contribute exact zeros) evaluated one output pixel per lane on the VALU.  A lane's chain
+// cannot be shared between lanes, so a lane reads whole pixels: straight from global that is 64 scattered 16-B pieces per
+// load instruction (TA-bound, measured no faster than the MFMA path); instead the block stages its input region
+// (TH x 32 outputs + halo, all channels) into LDS with coalesced loads -- pixel pitch cin+4 floats makes the per-lane
+// ds_read_b128 conflict-free -- and the weights too.  HBM-bound: the input is read once.
+template <int NOUT, int TH>
+__global__ __launch_bounds__(32 * TH) void k_conv_narrow(ConvArgs a, int tiles_x, int tiles_y, int rh, int rw) {
+    constexpr int TW = 32, NT = 32 * TH;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int T = a.kh * a.kw * a.ncb, pitch = a.cin_g + 4;
+    float *wl = sm;                                   // [tap][cb][NOUT][32]
+    float *xl = sm + ((T * NOUT * 32 + 3) & ~3);      // [rh][rw][pitch]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < T * NOUT * 32; i += NT) {
+        int c = i & 31, n = (i >> 5) % NOUT, ch = i / (32 * NOUT);
+        wl[i] = n < a.cout_g ? a.w[((int64_t)ch * a.npad + n) * 32 + c] : 0.0f;
+    }
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y, n = b / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
+    const int c4n = a.cin_g >> 2, total = rh * rw * c4n;
+    for (int i0 = tid; i0 < total; i0 += NT * 8) {               // 8 loads in flight per lane before the first LDS store
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int i = i0 + u * NT;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < total) {
+                int c4 = i % c4n, pix = i / c4n;
+                int ry = pix / rw, rx = pix - ry * rw;
+                int iy = iy0 + ry, ix = ix0 + rx;
+                if (iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w)
+                    v[u] = *reinterpret_cast<const float4 *>(a.in.p + ((int64_t)(n * a.in.h + iy) * a.in.w + ix) * a.in.ld + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int i = i0 + u * NT;
+            if (i < total) *reinterpret_cast<float4 *>(xl + (i / c4n) * pitch + (i % c4n) * 4) = v[u];
+        }
+    }
+    __syncthreads();
+    const int ly = tid >> 5, lx = tid & 31;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    if (oy >= a.out.h || ox >= a.out.w) return;
+    float acc[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) acc[j] = (a.bias && j < a.cout_g) ? a.bias[j] : 0.0f;
+    for (int kh = 0; kh < a.kh; ++kh)
+        for (int kw = 0; kw < a.kw; ++kw) {
+            const float *P = xl + ((ly * a.stride + kh * a.dil) * rw + lx * a.stride + kw * a.dil) * pitch;
+            const float *W = wl + (kh * a.kw + kw) * a.ncb * NOUT * 32;
+#pragma unroll 4
+            for (int c8 = 0; c8 < a.cin_g; c8 += 8) {                // cin_g % 4 == 0; a trailing half block is 4 channels
+                const float4 lo = *reinterpret_cast<const float4 *>(P + c8);
+                const float4 hi = c8 + 4 < a.cin_g ? *reinterpret_cast<const float4 *>(P + c8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float *w8 = W + (c8 >> 5) * NOUT * 32 + (c8 & 31);
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) {
+                    const float *w = w8 + j * 32;
+                    float v = acc[j];
+                    v = fmaf(lo.x, w[0], v); v = fmaf(hi.x, w[4], v);
+                    v = fmaf(lo.y, w[1], v); v = fmaf(hi.y, w[5], v);
+                    v = fmaf(lo.z, w[2], v); v = fmaf(hi.z, w[6], v);
+                    v = fmaf(lo.w, w[3], v); v = fmaf(hi.w, w[7], v);
+                    acc[j] = v;
+                }
+            }
+        }
+    const int64_t m = ((int64_t)n * a.out.h + oy) * a.out.w + ox;
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        if (j >= a.cout_g) break;
+        float v = acc[j];
+        float slope = a.slope ? a.slope[j] : 0.0f;
+        if (a.res_mode == 1) v += a.res.p[m * a.res.ld + j];
+        v = apply_act(v, a.act, slope);
+        if (a.res_mode == 2) v += a.res.p[m * a.res.ld + j];
+        a.out.p[m * a.out.ld + j] = v;
+    }
+}
+
+// LDS bytes of k_conv_narrow for a TH-row tile; 0 = does not fit
+static size_t narrow_lds(const ConvArgs &a, int TH, int *rh_out, int *rw_out) {
+    int nout = a.cout_g == 1 ? 1 : 4;
+    int rh = (TH - 1) * a.stride + (a.kh - 1) * a.dil + 1, rw = 31 * a.stride + (a.kw - 1) * a.dil + 1;
+    size_t fl = (((size_t)a.kh * a.kw * a.ncb * nout * 32 + 3) & ~(size_t)3) + (size_t)rh * rw * (a.cin_g + 4);
+    if (rh_out) { *rh_out = rh; *rw_out = rw; }
+    return fl * 4 <= 150 * 1024 ? fl * 4 : 0;
+}
+
+template <int NOUT, int TH>
+static int launch_narrow_t(const ConvArgs &a, size_t lds, int rh, int rw, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_narrow<NOUT, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    int tiles_x = (a.out.w + 31) / 32, tiles_y = (a.out.h + TH - 1) / TH;
+    k_conv_narrow<NOUT, TH><<<(unsigned)(tiles_x * tiles_y * a.out.n), 32 * TH, lds, st>>>(a, tiles_x, tiles_y, rh, rw);
+    return csm::check_launch("k_conv_narrow");
+}
+
+static int launch_narrow(const ConvArgs &a, hipStream_t st) {
+    int rh, rw;
+    size_t lds = narrow_lds(a, 8, &rh, &rw);
+    if (lds && lds <= 50 * 1024) return a.cout_g == 1 ? launch_narrow_t<1, 8>(a, lds, rh, rw, st) : launch_narrow_t<4, 8>(a, lds, rh, rw, st);
+    lds = narrow_lds(a, 4, &rh, &rw);
+    return a.cout_g == 1 ? launch_narrow_t<1, 4>(a, lds, rh, rw, st) : launch_narrow_t<4, 4>(a, lds, rh, rw, st);
+}
+
 // split-K tail: v = ((p0 + p1) + p2) + ... in run order, then the usual epilogue
 __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs a) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -696,6 +812,10 @@ int launch_conv_dma(const ConvArgs &a0, hipStream_t st) {
     return csm::check_launch("k_splitk_reduce");
 }
 
+static bool narrow_eligible(const ConvArgs &a) {
+    return a.cout_g <= 4 && a.groups == 1 && a.ksplit == 1 && !(a.cin_g & 3) && !(a.in.ld & 3) && narrow_lds(a, 4, nullptr, nullptr) != 0;
+}
+
 static bool dma_eligible(const ConvArgs &a) {
     int64_t bytes_in = (((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4;
     int64_t bytes_w = (int64_t)a.groups * a.kh * a.kw * a.ncb * a.npad * 128;
@@ -708,7 +828,9 @@ static bool dma_eligible(const ConvArgs &a) {
 // two-stage pipeline, so the default is the 64x64 tile (4 blocks = 16 waves per CU); narrow outputs get narrow tiles.
 enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CFG_128x32 = 4, CFG_64x16 = 5,
        // LDS-DMA kernel (k_conv_dma)
-       CFG_D64x64 = 6, CFG_D128x64 = 7, CFG_D128x128 = 8, CFG_D128x128_8w = 9, CFG_D256x128_8w = 10, CFG_D64x128 = 11, CFG_D128x32 = 12, CFG_COUNT = 13 };
+       CFG_D64x64 = 6, CFG_D128x64 = 7, CFG_D128x128 = 8, CFG_D128x128_8w = 9, CFG_D256x128_8w = 10, CFG_D64x128 = 11, CFG_D128x32 = 12,
+       CFG_NARROW = 13,   // k_conv_narrow (cout <= 4)
+       CFG_COUNT = 14 };
 static int g_force_cfg = -1;
 static int g_dbg = 0;
 
@@ -725,7 +847,7 @@ static void read_force_env() {
 static int choose_cfg(const ConvArgs &a, int N) {
     read_force_env();
     if (g_force_cfg >= 0 && g_force_cfg < CFG_COUNT) return g_force_cfg;
-    if (N <= 16) return CFG_64x16;
+    if (N <= 16) return CFG_64x16;      // (k_conv_narrow is an autotune candidate only: it wins on some cout = 1 layers, loses on others)
     if (N <= 32) return dma_eligible(a) ? CFG_D128x32 : CFG_128x32;
     return CFG_D64x64;
 }
@@ -744,6 +866,7 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_D128x128_8w: return launch_conv_dma<2, 4, 2, 1>(a, st);
         case CFG_D256x128_8w: return launch_conv_dma<4, 2, 2, 2>(a, st);
         case CFG_D128x32: return launch_conv_dma<4, 1, 1, 1>(a, st);
+        case CFG_NARROW: return launch_narrow(a, st);
         default: return launch_conv<32, 2, 2, 1>(a, st);
     }
 }
@@ -796,7 +919,8 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 }
                 a.dbg = g_dbg;
                 int cfg = (op.tile > 0 && op.tile <= CFG_COUNT && g_force_cfg < 0) ? op.tile - 1 : choose_cfg(a, op.cout_g);
-                if (cfg >= CFG_D64x64 && !dma_eligible(a)) cfg = op.cout_g <= 16 ? CFG_64x16 : (op.cout_g <= 32 ? CFG_128x32 : CFG_64x64);
+                if (cfg == CFG_NARROW && !narrow_eligible(a)) cfg = CFG_64x16;
+                if (cfg >= CFG_D64x64 && cfg != CFG_NARROW && !dma_eligible(a)) cfg = op.cout_g <= 16 ? CFG_64x16 : (op.cout_g <= 32 ? CFG_128x32 : CFG_64x64);
                 rc = launch_conv_cfg(cfg, a, st);
                 if (rc) return rc;
                 break;
@@ -899,8 +1023,8 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         if (op.kind != CSM_OP_CONV) continue;
         const int npad = (op.cout_g + 31) / 32 * 32;
         static const int cand_all[] = {CFG_64x64, CFG_128x32, CFG_64x16, CFG_D64x64, CFG_D128x64, CFG_D64x128, CFG_D128x128,
-                                       CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32};
-        static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32};
+                                       CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32, CFG_NARROW};
+        static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32, 4};
         // identical layers (same shapes / strides / split) share one measurement, also across programs
         View vin{}, vout{};
         rc = make_view(tensors, n_tensors, op.in0, workspace, ext, n_ext, vin); if (rc) break;
@@ -912,6 +1036,7 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         float best = 1e30f; int best_cfg = -1;
         for (size_t c = 0; c < sizeof(cand_all) / sizeof(int); ++c) {
             if (cand_bn[c] >= 2 * npad && cand_bn[c] > 32) continue;      // tile much wider than the output: never wins
+            if (cand_bn[c] == 4 && (op.cout_g > 4 || op.groups != 1 || op.ksplit > 1)) continue;
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
             if (cand_bn[c] == 32 && op.cout_g > 64) continue;
             op.tile = cand_all[c] + 1;

@@ -197,7 +197,7 @@ class Program:
 
     def choose_ksplit(self, M, N, T, groups):
         """small feature maps: not enough 64x64 output tiles to fill 256 CUs -> cut K (part of the numerical contract)"""
-        if not self.split_k or groups != 1:
+        if not self.split_k or groups != 1 or N <= 4:      # N <= 4: k_conv_narrow, one output pixel per lane, needs no split
             return 1
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
         if tiles >= KSPLIT_BELOW or T < 8:      # enough blocks per CU: the extra reduce launch (~6 us) costs more than it buys

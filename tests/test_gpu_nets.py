@@ -52,6 +52,11 @@ CONV_CASES = [
     (1, 40, 17, 17, 48, 3, 1, 1, 1, 1, 'sigmoid', 0),
     (1, 16, 90, 90, 16, 3, 1, 1, 1, 1, 'relu', 0),
     (1, 768, 12, 12, 256, 1, 1, 0, 1, 1, None, 0),
+    (2, 64, 70, 66, 1, 3, 1, 1, 1, 1, None, 0),            # narrow-output kernel (cout <= 4)
+    (1, 128, 33, 47, 1, 3, 1, 1, 1, 1, 'sigmoid', 0),
+    (1, 64, 20, 20, 3, 3, 1, 2, 2, 1, 'relu', 0),
+    (1, 36, 21, 21, 2, 3, 1, 1, 1, 1, None, 0),
+    (1, 96, 30, 30, 4, 1, 1, 0, 1, 1, 'relu', 1),
 ]
 
 
