@@ -75,6 +75,20 @@ struct ConvArgs {
     int dbg;                           // tuning aid: 1 = no global loads, 2 = no MFMA, 4 = no LDS stores, 8 = no epilogue stores
 };
 
+// Block -> tile map (speed only).  Workgroups are handed to the 8 XCDs round-robin in launch order, and each XCD has its own L2:
+// give XCD x a CONTIGUOUS run of tiles in the order (z, m-tile, n-tile) with n fastest, so the blocks resident on one XCD
+// share a few activation tiles (read from HBM once, all their N tiles hit L2) instead of streaming the whole activation
+// tensor once per N tile.  L -> (x = L%8, i = L/8) -> j = start(x) + i is a bijection because both sides split `total`
+// into 8 runs whose lengths differ by at most one, longer runs first.
+__device__ __forceinline__ void block_to_tile(int &mt, int &nt, int &z) {
+    const unsigned nm = gridDim.x, nn = gridDim.y, total = nm * nn * gridDim.z;
+    const unsigned L = blockIdx.x + nm * (blockIdx.y + nn * blockIdx.z);
+    const unsigned x = L & 7u, i = L >> 3, q = total >> 3, r = total & 7u;
+    const unsigned j = x * q + (x < r ? x : r) + i;
+    const unsigned per_z = nm * nn, zz = j / per_z, rem = j - zz * per_z;
+    z = (int)zz; mt = (int)(rem / nn); nt = (int)(rem - (rem / nn) * nn);
+}
+
 constexpr int kLdsLd = 36;  // floats per LDS row: 32 + 4 pad (conflict-free b128 reads, see MI355X LDS notes)
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -108,15 +122,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
     const int li = MT == 32 ? (lane & 31) : (lane & 15);
     const int lh = MT == 32 ? (lane >> 5) : (lane >> 4);
 
-    // XCD-aware M-tile remap (speed only): block b runs on XCD b%8; give each XCD a contiguous tile range.
-    int mt;
-    {
-        const int nt = a.m_tiles, b = blockIdx.x;
-        const int q = nt >> 3, r = nt & 7, xcd = b & 7, loc = b >> 3;
-        mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int m0 = mt * BM, n0 = blockIdx.y * BN;
-    const int g = blockIdx.z / a.ksplit, ks = blockIdx.z - g * a.ksplit;
+    int mt, ntile, zz;
+    block_to_tile(mt, ntile, zz);
+    const int m0 = mt * BM, n0 = ntile * BN;
+    const int g = zz / a.ksplit, ks = zz - g * a.ksplit;
     const int ho = a.out.h, wo = a.out.w;
     const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
 
@@ -341,14 +350,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    int mt;
-    {   // XCD-aware M-tile remap (speed only): block b runs on XCD b%8; each XCD gets a contiguous tile range
-        const int nt = a.m_tiles, b = blockIdx.x;
-        const int q = nt >> 3, r = nt & 7, xcd = b & 7, loc = b >> 3;
-        mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int m0 = mt * BM, n0 = blockIdx.y * BN;
-    const int g = blockIdx.z / a.ksplit, ks = blockIdx.z - g * a.ksplit;
+    int mt, ntile, zz;
+    block_to_tile(mt, ntile, zz);
+    const int m0 = mt * BM, n0 = ntile * BN;
+    const int g = zz / a.ksplit, ks = zz - g * a.ksplit;
     const int ho = a.out.h, wo = a.out.w;
     const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
     const int Tall = a.kh * a.kw * a.ncb;
@@ -830,7 +835,9 @@ enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CF
        // LDS-DMA kernel (k_conv_dma)
        CFG_D64x64 = 6, CFG_D128x64 = 7, CFG_D128x128 = 8, CFG_D128x128_8w = 9, CFG_D256x128_8w = 10, CFG_D64x128 = 11, CFG_D128x32 = 12,
        CFG_NARROW = 13,   // k_conv_narrow (cout <= 4)
-       CFG_COUNT = 14 };
+       // odd tile heights (1x4 waves, wave tile 32*TM x 32): more block counts for the tuner to dodge grid quantisation with
+       CFG_D96x128 = 14, CFG_D160x128 = 15, CFG_D224x128 = 16, CFG_D192x128 = 17,
+       CFG_COUNT = 18 };
 static int g_force_cfg = -1;
 static int g_dbg = 0;
 
@@ -867,6 +874,10 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_D256x128_8w: return launch_conv_dma<4, 2, 2, 2>(a, st);
         case CFG_D128x32: return launch_conv_dma<4, 1, 1, 1>(a, st);
         case CFG_NARROW: return launch_narrow(a, st);
+        case CFG_D96x128: return launch_conv_dma<1, 4, 3, 1>(a, st);
+        case CFG_D160x128: return launch_conv_dma<1, 4, 5, 1>(a, st);
+        case CFG_D224x128: return launch_conv_dma<1, 4, 7, 1>(a, st);
+        case CFG_D192x128: return launch_conv_dma<1, 4, 6, 1>(a, st);
         default: return launch_conv<32, 2, 2, 1>(a, st);
     }
 }
@@ -1023,8 +1034,9 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         if (op.kind != CSM_OP_CONV) continue;
         const int npad = (op.cout_g + 31) / 32 * 32;
         static const int cand_all[] = {CFG_64x64, CFG_128x32, CFG_64x16, CFG_D64x64, CFG_D128x64, CFG_D64x128, CFG_D128x128,
-                                       CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32, CFG_NARROW};
-        static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32, 4};
+                                       CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32, CFG_NARROW, CFG_D96x128, CFG_D160x128,
+                                       CFG_D224x128, CFG_D192x128};
+        static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32, 4, 128, 128, 128, 128};
         // identical layers (same shapes / strides / split) share one measurement, also across programs
         View vin{}, vout{};
         rc = make_view(tensors, n_tensors, op.in0, workspace, ext, n_ext, vin); if (rc) break;

@@ -15,7 +15,7 @@ p.conv(x, W, np.zeros(cout, np.float32), stride=s, pad=d * (k // 2), dil=d, grou
 os.environ["CSM_AUTOTUNE"] = "0"
 cp = CompiledProgram(p, 'cuda'); cp.workspace.normal_()
 L = _lib.load()
-names = ["128x128_4w", "128x64", "64x64", "128x128_8w", "128x32", "64x16", "D64x64", "D128x64", "D128x128", "D128x128_8w", "D256x128_8w", "D64x128", "D128x32", "NARROW"]
+names = ["128x128_4w", "128x64", "64x64", "128x128_8w", "128x32", "64x16", "D64x64", "D128x64", "D128x128", "D128x128_8w", "D256x128_8w", "D64x128", "D128x32", "NARROW", "D96x128", "D160x128", "D224x128", "D192x128"]
 print("ksplit", p.ops[0]['ksplit'], "GFLOP %.2f" % (p.flops / 1e9))
 for cfg in range(len(names)):
     L.csm_debug_force_conv_cfg(cfg); cp.run()
