@@ -5,7 +5,7 @@
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN, int TM, int TN, int NSTAGE>
+template <int WM, int WN, int TM, int TN, int NSTAGE, int PIPE>
 __global__ __launch_bounds__(64 * WM * WN) void k_glds(const float *__restrict__ src, float *out, int chunks, int64_t stride,
                                                          int footprint_blocks) {
     constexpr int NT = 64 * WM * WN, NW = WM * WN;
@@ -39,31 +39,46 @@ __global__ __launch_bounds__(64 * WM * WN) void k_glds(const float *__restrict__
         }
     };
     const int li = lane & 31, lh = lane >> 5;
+    auto frags = [&](const float *S, int kb, float4 *af, float4 *bf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int row = 32 * (TM * wm + i) + li;
+            af[i] = *reinterpret_cast<const float4 *>(S + row * 32 + (((2 * kb + lh) ^ ((row >> 1) & 7)) << 2));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int row = BM + 32 * (TN * wn + j) + li;
+            bf[j] = *reinterpret_cast<const float4 *>(S + row * 32 + (((2 * kb + lh) ^ ((row >> 1) & 7)) << 2));
+        }
+    };
+    auto mfmas = [&](const float4 *af, const float4 *bf) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float a = t == 0 ? af[i].x : t == 1 ? af[i].y : t == 2 ? af[i].z : af[i].w;
+                    float b = t == 0 ? bf[j].x : t == 1 ? bf[j].y : t == 2 ? bf[j].z : bf[j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                }
+    };
     auto compute = [&](int stage) {
         const float *S = lds + stage * kStage;
+        if (PIPE) {   // fragments of kb+1 are requested before the MFMAs of kb are issued
+            float4 a0[TM], b0[TN], a1[TM], b1[TN];
+            frags(S, 0, a0, b0);
+            frags(S, 1, a1, b1); __builtin_amdgcn_sched_barrier(0); mfmas(a0, b0); __builtin_amdgcn_sched_barrier(0);
+            frags(S, 2, a0, b0); __builtin_amdgcn_sched_barrier(0); mfmas(a1, b1); __builtin_amdgcn_sched_barrier(0);
+            frags(S, 3, a1, b1); __builtin_amdgcn_sched_barrier(0); mfmas(a0, b0); __builtin_amdgcn_sched_barrier(0);
+            mfmas(a1, b1);
+        } else {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int row = 32 * (TM * wm + i) + li;
-                af[i] = *reinterpret_cast<const float4 *>(S + row * 32 + (((2 * kb + lh) ^ ((row >> 1) & 7)) << 2));
+            for (int kb = 0; kb < 4; ++kb) {
+                float4 af[TM], bf[TN];
+                frags(S, kb, af, bf);
+                mfmas(af, bf);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int row = BM + 32 * (TN * wn + j) + li;
-                bf[j] = *reinterpret_cast<const float4 *>(S + row * 32 + (((2 * kb + lh) ^ ((row >> 1) & 7)) << 2));
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        float a = t == 0 ? af[i].x : t == 1 ? af[i].y : t == 2 ? af[i].z : af[i].w;
-                        float b = t == 0 ? bf[j].x : t == 1 ? bf[j].y : t == 2 ? bf[j].z : bf[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
-                    }
         }
     };
     if (NSTAGE == 2) {
@@ -96,19 +111,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_glds(const float *__restrict__
     if (s == 12345.678f) out[0] = s;
 }
 
-template <int WM, int WN, int TM, int TN, int NSTAGE>
+template <int WM, int WN, int TM, int TN, int NSTAGE, int PIPE>
 void run(const char *name, const float *src, float *out, int tiles64, int chunks, int footprint) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     size_t ldsb = (size_t)NSTAGE * (BM + BN) * 32 * sizeof(float);
     int grid = (int)((int64_t)tiles64 * 64 * 64 / (BM * BN));
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_glds<WM, WN, TM, TN, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_glds<WM, WN, TM, TN, NSTAGE, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k_glds<WM, WN, TM, TN, NSTAGE><<<grid, 64 * WM * WN, ldsb>>>(src, out, chunks, 2304, footprint);
+    k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN, ldsb>>>(src, out, chunks, 2304, footprint);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return; }
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        k_glds<WM, WN, TM, TN, NSTAGE><<<grid, 64 * WM * WN, ldsb>>>(src, out, chunks, 2304, footprint);
+        k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN, ldsb>>>(src, out, chunks, 2304, footprint);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -122,18 +137,18 @@ int main() {
     float *src, *out;
     size_t n = (size_t)4 * 256 * 2304 + 4096;
     hipMalloc(&src, n * 4); hipMemset(src, 0, n * 4); hipMalloc(&out, 4);
-    for (int tiles : {1024, 1600, 4096}) {
+    for (int tiles : {1024, 4096}) {
         printf("-- work = %d 64x64 tiles x 72 chunks\n", tiles);
-        run<2, 2, 1, 1, 2>("64x64 4w(32x32) 2-stage", src, out, tiles, 72, 2);
-        run<2, 2, 1, 1, 3>("64x64 4w(32x32) 3-stage", src, out, tiles, 72, 2);
-        run<2, 2, 2, 1, 2>("128x64 4w(64x32) 2-stage", src, out, tiles, 72, 2);
-        run<2, 2, 2, 1, 3>("128x64 4w(64x32) 3-stage", src, out, tiles, 72, 2);
-        run<2, 2, 2, 2, 2>("128x128 4w(64x64) 2-stage", src, out, tiles, 72, 2);
-        run<2, 2, 2, 2, 3>("128x128 4w(64x64) 3-stage", src, out, tiles, 72, 2);
-        run<2, 4, 2, 1, 2>("128x128 8w(64x32) 2-stage", src, out, tiles, 72, 2);
-        run<2, 4, 2, 1, 3>("128x128 8w(64x32) 3-stage", src, out, tiles, 72, 2);
-        run<2, 2, 4, 2, 2>("256x128 4w(128x64) 2-stage", src, out, tiles, 72, 2);
-        run<4, 2, 2, 2, 2>("256x128 8w(64x64) 2-stage", src, out, tiles, 72, 2);
+        run<2, 2, 1, 1, 2, 0>("64x64 4w(32x32)", src, out, tiles, 72, 2);
+        run<2, 2, 1, 1, 2, 1>("64x64 4w(32x32) frag-pipelined", src, out, tiles, 72, 2);
+        run<2, 2, 2, 1, 2, 0>("128x64 4w(64x32)", src, out, tiles, 72, 2);
+        run<2, 2, 2, 1, 2, 1>("128x64 4w(64x32) frag-pipelined", src, out, tiles, 72, 2);
+        run<2, 2, 2, 2, 2, 0>("128x128 4w(64x64)", src, out, tiles, 72, 2);
+        run<2, 2, 2, 2, 2, 1>("128x128 4w(64x64) frag-pipelined", src, out, tiles, 72, 2);
+        run<2, 4, 2, 1, 2, 0>("128x128 8w(64x32)", src, out, tiles, 72, 2);
+        run<2, 4, 2, 1, 2, 1>("128x128 8w(64x32) frag-pipelined", src, out, tiles, 72, 2);
+        run<4, 2, 2, 2, 2, 0>("256x128 8w(64x64)", src, out, tiles, 72, 2);
+        run<4, 2, 2, 2, 2, 1>("256x128 8w(64x64) frag-pipelined", src, out, tiles, 72, 2);
     }
     return 0;
 }
