@@ -644,6 +644,74 @@ __global__ __launch_bounds__(256) void k_dwconv(DwArgs a) {
     *reinterpret_cast<float4 *>(a.out.p + pix * a.out.ld + c) = acc;
 }
 
+
+// depthwise conv, stride 1 / dilation 1 (CSPNeXt 5x5): same chain as k_dwconv, but the block first stages its input region
+// (8x16 outputs + halo, 32 channels) in LDS -- every input element is used by kh*kw outputs, and from global that re-use
+// came out of L2 (measured ~12 TB/s of L2 traffic, L2-bound); from LDS the kernel is HBM-bound.  Out-of-image taps add
+// exact zeros.  Thread = (channel quad, 4 output pixels).
+__global__ __launch_bounds__(256) void k_dwconv_lds(DwArgs a, int tiles_x, int tiles_y) {
+    constexpr int TH = 8, TW = 16;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int rh = TH + a.kh - 1, rw = TW + a.kw - 1, taps = a.kh * a.kw;
+    float *wl = sm;                       // [tap][32]
+    float *xl = sm + taps * 32;           // [rh*rw][32]
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y, n = b / tiles_y;
+    const int c0 = blockIdx.y * 32;
+    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+    for (int i = tid; i < taps * 32; i += 256) wl[i] = a.w[(int64_t)(i >> 5) * a.out.c + c0 + (i & 31)];
+    const int total = rh * rw * 8;
+    for (int i0 = tid; i0 < total; i0 += 256 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int i = i0 + u * 256;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < total) {
+                int c4 = i & 7, pix = i >> 3;
+                int ry = pix / rw, rx = pix - ry * rw;
+                int iy = iy0 + ry, ix = ix0 + rx;
+                if (iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w)
+                    v[u] = *reinterpret_cast<const float4 *>(a.in.p + ((int64_t)(n * a.in.h + iy) * a.in.w + ix) * a.in.ld + c0 + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int i = i0 + u * 256;
+            if (i < total) *reinterpret_cast<float4 *>(xl + (i >> 3) * 32 + (i & 7) * 4) = v[u];
+        }
+    }
+    __syncthreads();
+    const int c4 = tid & 7, p0 = tid >> 3;              // pixels p0 + 32*j of the 8x16 tile
+    const float4 bias = a.bias ? *reinterpret_cast<const float4 *>(a.bias + c0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 sl = a.slope ? *reinterpret_cast<const float4 *>(a.slope + c0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = bias;
+    for (int kh = 0; kh < a.kh; ++kh)
+        for (int kw = 0; kw < a.kw; ++kw) {
+            const float4 w = *reinterpret_cast<const float4 *>(wl + (kh * a.kw + kw) * 32 + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pix = p0 + 32 * j, py = pix >> 4, px = pix & 15;
+                const float4 x = *reinterpret_cast<const float4 *>(xl + ((py + kh) * rw + px + kw) * 32 + c4 * 4);
+                acc[j].x = fmaf(x.x, w.x, acc[j].x); acc[j].y = fmaf(x.y, w.y, acc[j].y);
+                acc[j].z = fmaf(x.z, w.z, acc[j].z); acc[j].w = fmaf(x.w, w.w, acc[j].w);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pix = p0 + 32 * j, oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+        if (oy >= a.out.h || ox >= a.out.w) continue;
+        float4 v = acc[j];
+        v.x = apply_act(v.x, a.act, sl.x); v.y = apply_act(v.y, a.act, sl.y);
+        v.z = apply_act(v.z, a.act, sl.z); v.w = apply_act(v.w, a.act, sl.w);
+        *reinterpret_cast<float4 *>(a.out.p + ((int64_t)(n * a.out.h + oy) * a.out.w + ox) * a.out.ld + c0 + c4 * 4) = v;
+    }
+}
+
 // max pooling (window clipped to the input; ceil_mode handled by the host-computed output size)
 __global__ __launch_bounds__(256) void k_maxpool(View in, View out, int k, int stride, int pad) {
     const int c4n = out.c >> 2;
@@ -940,7 +1008,12 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 if ((in.ld & 3) || (out.ld & 3) || (out.c & 3)) { csm::set_error("op %d: dwconv needs c%%4==0", i); return CSM_ERR_ARG; }
                 DwArgs a{in, out, weights + op.w_off, op.b_off >= 0 ? weights + op.b_off : nullptr,
                          op.aux_off >= 0 ? weights + op.aux_off : nullptr, op.kh, op.kw, op.stride, op.pad, op.dil, op.act};
-                k_dwconv<<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(a);
+                size_t lds = ((size_t)op.kh * op.kw * 32 + (size_t)(8 + op.kh - 1) * (16 + op.kw - 1) * 32) * 4;
+                if (op.stride == 1 && op.dil == 1 && !(out.c & 31) && lds <= 64 * 1024 && out.h == in.h + 2 * op.pad - op.kh + 1) {
+                    int tiles_x = (out.w + 15) / 16, tiles_y = (out.h + 7) / 8;
+                    k_dwconv_lds<<<dim3((unsigned)(tiles_x * tiles_y * out.n), (unsigned)(out.c / 32)), 256, lds, st>>>(a, tiles_x, tiles_y);
+                } else
+                    k_dwconv<<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(a);
                 break;
             }
             case CSM_OP_MAXPOOL:
