@@ -131,6 +131,86 @@ extern "C" int csm_leres_quantize(const float *depth, int64_t n, const float *mi
     return csm::check_launch("k_leres_quantize");
 }
 
+// ---- depth_adjustment_animesseg, one instance (kenburns_effect.py:68-78), in place ------------------------------------------
+// plane = disp * mask.  Rows of the instance = rows whose plane has a positive entry (the reference tests `plane.sum(3) > 0`;
+// disparities are non-negative, so "sum > 0" == "any > 0"); r0 = round_half_even(top + 0.97 (bottom - top)) in float64;
+// val = max of the plane over rows >= r0 (zeros outside the mask included, like the reference's slice); pixels of the mask
+// become val.  Skipped when the plane is empty (`plane.sum() == 0`).  scratch: H row maxima, H row flags, {val, apply}.
+__global__ __launch_bounds__(256) void k_adjust_rows(const float *__restrict__ disp, const uint8_t *__restrict__ mask, int W,
+                                                       float *__restrict__ rowmax, float *__restrict__ rowflag) {
+    __shared__ float smax[256];
+    __shared__ int sflag[256];
+    const int r = blockIdx.x;
+    float mx = -INFINITY; int fl = 0;           // bit 0: a positive entry, bit 1: a non-zero entry
+    for (int x = threadIdx.x; x < W; x += 256) {
+        float p = disp[(int64_t)r * W + x] * (mask[(int64_t)r * W + x] ? 1.0f : 0.0f);
+        mx = fmaxf(mx, p);
+        fl |= (p > 0.0f ? 1 : 0) | (p != 0.0f ? 2 : 0);
+    }
+    smax[threadIdx.x] = mx; sflag[threadIdx.x] = fl;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + st]);
+            sflag[threadIdx.x] |= sflag[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { rowmax[r] = smax[0]; rowflag[r] = (float)sflag[0]; }
+}
+
+__global__ __launch_bounds__(256) void k_adjust_pick(const float *__restrict__ rowmax, const float *__restrict__ rowflag, int H,
+                                                       float *__restrict__ out2) {
+    __shared__ int stop[256], sbot[256], snz[256];
+    __shared__ float smax[256];
+    int top = H, bot = -1, nz = 0;
+    for (int r = threadIdx.x; r < H; r += 256) {
+        int f = (int)rowflag[r];
+        if (f & 1) { top = min(top, r); bot = max(bot, r); }
+        nz |= f & 2;
+    }
+    stop[threadIdx.x] = top; sbot[threadIdx.x] = bot; snz[threadIdx.x] = nz;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            stop[threadIdx.x] = min(stop[threadIdx.x], stop[threadIdx.x + st]);
+            sbot[threadIdx.x] = max(sbot[threadIdx.x], sbot[threadIdx.x + st]);
+            snz[threadIdx.x] |= snz[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    top = stop[0]; bot = sbot[0]; nz = snz[0];
+    const bool apply = bot >= 0 && nz != 0;
+    const int r0 = apply ? (int)rint((double)top + (0.97 * (double)(bot - top))) : H;
+    float mx = -INFINITY;
+    for (int r = threadIdx.x; r < H; r += 256)
+        if (r >= r0) mx = fmaxf(mx, rowmax[r]);
+    smax[threadIdx.x] = mx;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = smax[0]; out2[1] = apply ? 1.0f : 0.0f; }
+}
+
+__global__ __launch_bounds__(256) void k_adjust_apply(float *__restrict__ disp, const uint8_t *__restrict__ mask, int64_t n,
+                                                        const float *__restrict__ out2) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || out2[1] == 0.0f) return;
+    const float m = mask[i] ? 1.0f : 0.0f;
+    disp[i] = ((1.0f - m) * disp[i]) + (m * out2[0]);          // kenburns_effect.py:78, literally
+}
+
+extern "C" int csm_depth_adjust_instance(float *disp, const uint8_t *mask, int H, int W, float *scratch, void *stream) {
+    CSM_REQUIRE(disp && mask && scratch && H > 0 && W > 0);
+    hipStream_t st = (hipStream_t)stream;
+    k_adjust_rows<<<H, 256, 0, st>>>(disp, mask, W, scratch, scratch + H);
+    k_adjust_pick<<<1, 256, 0, st>>>(scratch, scratch + H, H, scratch + 2 * H);
+    k_adjust_apply<<<csm::cdiv((int64_t)H * W, 256), 256, 0, st>>>(disp, mask, (int64_t)H * W, scratch + 2 * H);
+    return csm::check_launch("k_adjust_*");
+}
+
 extern "C" int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream) {
     CSM_REQUIRE(src && out && h > 0 && w > 0 && H >= h && W >= w);
     k_resize_u8_to_f32<<<dim3(csm::cdiv(W, 256), H), 256, 0, (hipStream_t)stream>>>(src, h, w, H, W, out);

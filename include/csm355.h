@@ -232,6 +232,10 @@ int csm_leres_input(const uint8_t *img_hwc, int H, int W, int h, int w, float *o
 /* depth_modules/leres/__init__.py:121-145: min-max -> uint16 -> convertScaleAbs(255/65535) -> bitwise_not.
  * min_max_dev: DEVICE pointer to {min, max} of depth. */
 int csm_leres_quantize(const float *depth, int64_t n, const float *min_max_dev, uint8_t *out, void *stream);
+/* depth_adjustment_animesseg for ONE instance, in place (kenburns_effect.py:68-78, the non-median branch): pixels of `mask`
+ * (bool/uint8 [H,W]) take the maximum of disp*mask over the rows from round(top + 0.97 (bottom - top)) down; untouched when the
+ * instance plane is empty.  scratch: 2*H + 2 floats (device).  No host sync. */
+int csm_depth_adjust_instance(float *disp, const uint8_t *mask, int H, int W, float *scratch, void *stream);
 /* kenburns_effect.py:572-575: cv2.resize(u8 depth, (W,H), INTER_AREA) (enlarging) -> float32 */
 int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream);
 /* kenburns_effect.py:1069-1070: cv2.getRectSubPix(frame,(patch_w,patch_h),center) + cv2.resize(INTER_LINEAR) to (W,H) */
