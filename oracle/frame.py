@@ -8,7 +8,7 @@ import time
 import numpy as np
 
 
-def cpu_baseline(seconds_budget=20.0, frame=128, det=96, depth=96, refine=96, instances=2):
+def cpu_baseline(seconds_budget=20.0, frame=256, det=192, depth=192, refine=192, instances=2):
     from cartoonsegmentation_amd import synth
     from cartoonsegmentation_amd.nets import build_isnet, build_leres, build_rtmdet
     from cartoonsegmentation_amd.weights import SynthWeights
