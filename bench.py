@@ -235,7 +235,7 @@ class FrameWorkload(Workload):
         progs = self._programs()
         before = [cp.runs for _, cp, _ in progs]
         self.step(); torch.cuda.synchronize()                      # how often each program runs in one step (ISNet: once per 8 instances)
-        n_launch = 0
+        n_launch, alg_bytes = 0, 0
         for (name, cp, ext), b in zip(progs, before):
             per_step = cp.runs - b
             cp.run(*ext)
@@ -248,11 +248,17 @@ class FrameWorkload(Workload):
             per_net[name] = {"conv_ms": round(cms, 3), "all_ops_ms": round(sum(ms), 3), "gflop": round(cp.prog.flops / 1e9, 1),
                              "conv_launches": nconv, "runs_per_step": per_step}
             tot_ms += cms * per_step; tot_fl += cp.prog.flops * per_step; n_launch += nconv * per_step
+            for o in cp.prog.ops:                                  # algorithmic bytes of a conv = input + output + weights, once each
+                if o['kind'] == 1:
+                    vi, vo, nat = cp.prog.views[o['in0']], cp.prog.views[o['out']], o['nat']
+                    alg_bytes += per_step * 4 * (vi.n * vi.h * vi.w * vi.c + vo.n * vo.h * vo.w * vo.c +
+                                                 nat['cout_g'] * nat['groups'] * nat['cin_g'] * o['kh'] * o['kw'])
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         tot_fl /= self.frames_per_step
         return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_mfma (fp32 implicit GEMM, all conv launches of one step = %d frames)" % self.frames_per_step,
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
-                "traffic": load_traffic("k_conv"), "algorithmic_flops_per_frame": tot_fl,
+                "traffic": load_traffic("k_conv"), "algorithmic_bytes_per_launch": int(alg_bytes / max(n_launch, 1)),
+                "algorithmic_flops_per_frame": tot_fl,
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_step": n_launch, "per_net": per_net}
 
     def extra(self):
