@@ -130,3 +130,82 @@ def test_isnet_hip_vs_oracle_and_reference(tag):
     thr = np.log(0.3 / 0.7)
     assert np.array_equal(yo > thr, yd > thr)                      # bit-exact masks after threshold vs the oracle
     assert ((yd > thr) != (g['d1'] > thr)).mean() < 1e-3           # IoU-level agreement with torch's own kernels
+
+
+FULL_SIZE_LAYERS = [
+    # n, h, w, cin, cout, k, stride, dil, groups -- BASELINE-size layers of the three nets (too large for the CPU oracle in a test)
+    (1, 160, 160, 256, 256, 3, 1, 1, 1),     # LeReS decoder 3x3
+    (2, 40, 40, 1024, 1024, 1, 1, 1, 1),     # ResNeXt 1x1
+    (1, 40, 40, 1024, 1024, 3, 1, 1, 32),    # ResNeXt grouped 3x3
+    (2, 90, 90, 128, 256, 3, 1, 1, 1),       # ISNet
+    (1, 45, 45, 256, 256, 3, 1, 4, 1),       # ISNet RSU4F dilated
+    (1, 160, 160, 128, 256, 3, 2, 1, 1),     # CSPNeXt stride-2 stage conv
+]
+
+
+@pytest.mark.parametrize("layer", FULL_SIZE_LAYERS, ids=[str(i) for i in range(len(FULL_SIZE_LAYERS))])
+def test_full_size_all_tile_configurations_agree_bitwise(layer):
+    """size-independent property at BASELINE sizes: every tile configuration of the two independent conv kernels (register-staged
+    k_conv_mfma, LDS-DMA k_conv_dma) must produce identical bits -- they share nothing but the fmaf-chain contract -- and one
+    sampled output row block is checked against the chain evaluated in numpy float32."""
+    from cartoonsegmentation_amd import _lib
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    n, h, w, cin, cout, k, stride, dil, groups = layer
+    p = Program("full")
+    x = p.buffer(n, h, w, cin)
+    W = rnd('fw%s' % (layer,), (cout, cin // groups, k, k), 1.0 / np.sqrt(cin // groups * k * k))
+    b = rnd('fb%s' % (layer,), (cout,), 0.1)
+    y = p.conv(x, W, b, stride=stride, pad=dil * (k // 2), dil=dil, groups=groups, act=None)
+    y.buf.keep = True
+    x.buf.first = 0
+    p.plan()
+    os.environ["CSM_AUTOTUNE"] = "0"
+    try:
+        cp = CompiledProgram(p, 'cuda')
+    finally:
+        os.environ.pop("CSM_AUTOTUNE", None)
+    xin = torch.from_numpy(rnd('fx%s' % (layer,), (n, h, w, cin))).cuda()
+    xb = x.buf
+    cp.workspace[xb.offset:xb.offset + xin.numel()] = xin.reshape(-1)
+    L = _lib.load()
+    ref, names = None, {}
+    try:
+        for cfg in range(18):
+            L.csm_debug_force_conv_cfg(cfg)
+            cp.run()
+            out = cp.read_view(y).cpu().numpy()
+            assert np.isfinite(out).all()
+            if ref is None:
+                ref = out
+            assert np.array_equal(ref, out), "tile configuration %d differs from configuration 0 (max %g)" % (cfg, np.abs(ref - out).max())
+    finally:
+        L.csm_debug_force_conv_cfg(-1)
+    if groups == 1:
+        # the contract (include/csm355.h) evaluated in numpy for 3 output pixels x all channels: chunks = (tap row-major, 32-channel
+        # block); run s of `ksplit` owns chunks [s*T/S, (s+1)*T/S), starts at the bias (run 0) or 0 and is one fmaf chain with the
+        # 8-channel blocks in the order 0,4,1,5,2,6,3,7; runs are added ((p0+p1)+p2)...  fmaf = exact product, one rounding.
+        xn = xin.cpu().numpy()
+        ho, wo = ref.shape[1], ref.shape[2]
+        perm = [0, 4, 1, 5, 2, 6, 3, 7]
+        S, ncb = p.ops[0]['ksplit'], (cin + 31) // 32
+        T = k * k * ncb
+        for (oy, ox) in ((0, 0), (ho // 2, wo // 3), (ho - 1, wo - 1)):
+            parts = []
+            for srun in range(S):
+                acc = b.astype(np.float32).copy() if srun == 0 else np.zeros(cout, np.float32)
+                for chunk in range(srun * T // S, (srun + 1) * T // S):
+                    tap, cb = divmod(chunk, ncb)
+                    kh, kw = divmod(tap, k)
+                    iy, ix = oy * stride - dil * (k // 2) + kh * dil, ox * stride - dil * (k // 2) + kw * dil
+                    if not (0 <= iy < h and 0 <= ix < w):
+                        continue
+                    for c8 in range(cb * 32, min(cb * 32 + 32, cin), 8):
+                        for j in perm:
+                            c = c8 + j
+                            prod = xn[0, iy, ix, c].astype(np.float64) * W[:, c, kh, kw].astype(np.float64)
+                            acc = (acc.astype(np.float64) + prod).astype(np.float32)
+                parts.append(acc)
+            tot = parts[0]
+            for q in parts[1:]:
+                tot = (tot + q).astype(np.float32)
+            assert np.array_equal(tot, ref[0, oy, ox]), "fmaf chain mismatch at (%d,%d): %g" % (oy, ox, np.abs(tot - ref[0, oy, ox]).max())
