@@ -154,8 +154,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
     }
     const int Tall = a.kh * a.kw * a.ncb;
     const int c_begin = (int)(((int64_t)ks * Tall) / a.ksplit), T = (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
-    // loader state = the NEXT chunk to fetch (block-uniform -> SGPRs)
-    int l_tap = c_begin / a.ncb, l_cb = c_begin - l_tap * a.ncb;
+    // loader state = the NEXT chunk to fetch (block-uniform -> SGPRs).  Chunk order = the chain order: 32-channel block outer,
+    // taps row-major inner (so that a 3x3 kernel can keep one block's input patch in LDS for all its taps, k_conv_patch).
+    const int ntaps = a.kh * a.kw;
+    int l_cb = c_begin / ntaps, l_tap = c_begin - l_cb * ntaps;
     int l_kh = l_tap / a.kw, l_kw = l_tap - l_kh * a.kw;
     const float *wp[B_IT];
 #pragma unroll
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
             wp[it] += (int64_t)a.npad * 32;
         }
         vbits[set] = vb;
-        if (++l_cb == a.ncb) { l_cb = 0; ++l_tap; if (++l_kw == a.kw) { l_kw = 0; ++l_kh; } }
+        ++l_tap;
+        if (++l_kw == a.kw) { l_kw = 0; if (++l_kh == a.kh) { l_kh = 0; l_tap = 0; ++l_cb; } }
     };
     auto put = [&](float *dst, float4 v) {
         if (MT == 32) *reinterpret_cast<float4 *>(dst + c4) = v;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
         }
     };
 
-    int cb = c_begin % a.ncb;
+    int cb = c_begin / ntaps, ctap = c_begin - cb * ntaps;      // position of the chunk being multiplied
     auto compute = [&](int chunk) {
         const int buf = chunk & 1;
         const float *A = lds + buf * kStage + (MT * wm + li) * kLdsLd + (MT == 32 ? 4 : 2) * lh;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
             for (int kb = 0; kb < 4; ++kb) kblock(A, B, kb);
         } else {
             int rem = a.cin_g - cb * 32;
-            if (++cb == a.ncb) cb = 0;
+            if (++ctap == ntaps) { ctap = 0; ++cb; }
             int nkb = rem >= 32 ? 4 : (rem + 7) >> 3;
 #pragma unroll 1
             for (int kb = 0; kb < nkb; ++kb) kblock(A, B, kb);
@@ -401,8 +404,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const unsigned ldsA = lds0 + (unsigned)(wave * GA * 8) * 128u, ldsB = lds0 + (unsigned)(BM + wave * GB * 8) * 128u;
 
-    // loader position = the NEXT chunk to fetch (block-uniform)
-    int l_tap = c_begin / a.ncb, l_cb = c_begin - l_tap * a.ncb;
+    // loader position = the NEXT chunk to fetch (block-uniform); chunk order = 32-channel block outer, taps row-major inner
+    const int ntaps = a.kh * a.kw;
+    int l_cb = c_begin / ntaps, l_tap = c_begin - l_cb * ntaps;
     int l_kh = l_tap / a.kw, l_kw = l_tap - l_kh * a.kw;
     unsigned l_w = (unsigned)(((int64_t)g * Tall + c_begin) * a.npad * 128);     // byte offset of the chunk's weight tile
     auto issue = [&](int stage) {
@@ -415,7 +419,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         for (int p = 0; p < GB; ++p)
             dma16(offB[p] == kOob ? kOob : offB[p] + l_w, rb, ldsB + sb + (unsigned)p * 1024u);
         l_w += (unsigned)a.npad * 128u;
-        if (++l_cb == a.ncb) { l_cb = 0; ++l_tap; if (++l_kw == a.kw) { l_kw = 0; ++l_kh; } }
+        ++l_tap;
+        if (++l_kw == a.kw) { l_kw = 0; if (++l_kh == a.kh) { l_kh = 0; l_tap = 0; ++l_cb; } }
     };
 
     f32x16 acc[TM][TN];
@@ -487,8 +492,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 
 
 // ---- narrow-output convolution (cout <= 4, groups == 1, no split-K): ISNet side outputs / LeReS last conv -------------------
-// An N = 1 output wastes 31/32 of an MFMA tile; this is the same fmaf chain (taps row-major, 8-channel blocks in the order
-// 0,4,1,5,2,6,3,7; out-of-image taps contribute exact zeros) evaluated one output pixel per lane on the VALU.  A lane's chain
+// An N = 1 output wastes 31/32 of an MFMA tile; this is the same fmaf chain (32-channel blocks, taps row-major, 8-channel
+// sub-blocks in the order 0,4,1,5,2,6,3,7; out-of-image taps contribute exact zeros) evaluated one output pixel per lane on the VALU.  A lane's chain
 // cannot be shared between lanes, so a lane reads whole pixels: straight from global that is 64 scattered 16-B pieces per
 // load instruction (TA-bound, measured no faster than the MFMA path); instead the block stages its input region
 // (TH x 32 outputs + halo, all channels) into LDS with coalesced loads -- pixel pitch cin+4 floats makes the per-lane
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(32 * TH) void k_conv_narrow(ConvArgs a, int tiles_x
     constexpr int TW = 32, NT = 32 * TH;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int T = a.kh * a.kw * a.ncb, pitch = a.cin_g + 4;
-    float *wl = sm;                                   // [tap][cb][NOUT][32]
+    float *wl = sm;                                   // [cb][tap][NOUT][32] (= chunk order of the packed weights)
     float *xl = sm + ((T * NOUT * 32 + 3) & ~3);      // [rh][rw][pitch]
     const int tid = threadIdx.x;
     for (int i = tid; i < T * NOUT * 32; i += NT) {
@@ -538,27 +543,28 @@ __global__ __launch_bounds__(32 * TH) void k_conv_narrow(ConvArgs a, int tiles_x
     float acc[NOUT];
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) acc[j] = (a.bias && j < a.cout_g) ? a.bias[j] : 0.0f;
-    for (int kh = 0; kh < a.kh; ++kh)
-        for (int kw = 0; kw < a.kw; ++kw) {
-            const float *P = xl + ((ly * a.stride + kh * a.dil) * rw + lx * a.stride + kw * a.dil) * pitch;
-            const float *W = wl + (kh * a.kw + kw) * a.ncb * NOUT * 32;
+    for (int cb = 0; cb < a.ncb; ++cb)
+        for (int kh = 0; kh < a.kh; ++kh)
+            for (int kw = 0; kw < a.kw; ++kw) {
+                const float *P = xl + ((ly * a.stride + kh * a.dil) * rw + lx * a.stride + kw * a.dil) * pitch;
+                const float *W = wl + (cb * a.kh * a.kw + kh * a.kw + kw) * NOUT * 32;
 #pragma unroll 4
-            for (int c8 = 0; c8 < a.cin_g; c8 += 8) {                // cin_g % 4 == 0; a trailing half block is 4 channels
-                const float4 lo = *reinterpret_cast<const float4 *>(P + c8);
-                const float4 hi = c8 + 4 < a.cin_g ? *reinterpret_cast<const float4 *>(P + c8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float *w8 = W + (c8 >> 5) * NOUT * 32 + (c8 & 31);
+                for (int c8 = cb * 32; c8 < cb * 32 + 32 && c8 < a.cin_g; c8 += 8) {   // cin_g % 4 == 0; a trailing half block is 4 channels
+                    const float4 lo = *reinterpret_cast<const float4 *>(P + c8);
+                    const float4 hi = c8 + 4 < a.cin_g ? *reinterpret_cast<const float4 *>(P + c8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float *w8 = W + (c8 & 31);
 #pragma unroll
-                for (int j = 0; j < NOUT; ++j) {
-                    const float *w = w8 + j * 32;
-                    float v = acc[j];
-                    v = fmaf(lo.x, w[0], v); v = fmaf(hi.x, w[4], v);
-                    v = fmaf(lo.y, w[1], v); v = fmaf(hi.y, w[5], v);
-                    v = fmaf(lo.z, w[2], v); v = fmaf(hi.z, w[6], v);
-                    v = fmaf(lo.w, w[3], v); v = fmaf(hi.w, w[7], v);
-                    acc[j] = v;
+                    for (int j = 0; j < NOUT; ++j) {
+                        const float *w = w8 + j * 32;
+                        float v = acc[j];
+                        v = fmaf(lo.x, w[0], v); v = fmaf(hi.x, w[4], v);
+                        v = fmaf(lo.y, w[1], v); v = fmaf(hi.y, w[5], v);
+                        v = fmaf(lo.z, w[2], v); v = fmaf(hi.z, w[6], v);
+                        v = fmaf(lo.w, w[3], v); v = fmaf(hi.w, w[7], v);
+                        acc[j] = v;
+                    }
                 }
             }
-        }
     const int64_t m = ((int64_t)n * a.out.h + oy) * a.out.w + ox;
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) {

@@ -43,7 +43,7 @@ def fold_bn(w, b, gamma, beta, mean, var, eps):
 
 def pack_conv_weights(w, groups):
     """w [cout, cin_g, kh, kw] (fp32, folded) -> (packed fp32 1-D, super_groups, cin_sg, cout_sg)
-    packed layout: [sg][tap][cb][npad][32]  (npad = cout_sg rounded to 32; zero padded)"""
+    packed layout: [sg][cb][tap][npad][32]  (cb = 32-channel block, OUTER = the chain order; npad = cout_sg rounded to 32; zero padded)"""
     cout, cin_g, kh, kw = w.shape
     if groups == 1:
         sg, cin_sg, cout_sg = 1, cin_g, cout
@@ -62,7 +62,7 @@ def pack_conv_weights(w, groups):
     ncb, npad = (cin_sg + 31) // 32, (cout_sg + 31) // 32 * 32
     full = np.zeros((sg, npad, ncb * 32, kh, kw), np.float32)
     full[:, :cout_sg, :cin_sg] = wsg
-    packed = full.reshape(sg, npad, ncb, 32, kh, kw).transpose(0, 4, 5, 2, 1, 3)     # sg,kh,kw,cb,npad,32
+    packed = full.reshape(sg, npad, ncb, 32, kh, kw).transpose(0, 2, 4, 5, 1, 3)     # sg,cb,kh,kw,npad,32
     return np.ascontiguousarray(packed).reshape(-1), sg, cin_sg, cout_sg
 
 

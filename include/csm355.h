@@ -111,8 +111,9 @@ int csm_warp_frame(const float *pts, const float *rgb, const float *depth, int64
  * is how torch.cat is realised without copies.
  *
  * Numerical contract (so the CPU oracle can be bit-exact): every convolution output is ONE fp32
- * fmaf chain  acc = bias; for tap (kh,kw) row-major; for each aligned block of 8 input channels,
- * channel order 0,4,1,5,2,6,3,7 (the v_mfma_f32_32x32x2_f32 lane order): acc = fmaf(x, w, acc)
+ * fmaf chain  acc = bias; for each aligned block of 32 input channels (outer); for tap (kh,kw) row-major; for each
+ * aligned sub-block of 8 channels, channel order 0,4,1,5,2,6,3,7 (the v_mfma_f32_32x32x2_f32 lane order):
+ * acc = fmaf(x, w, acc)
  * -- or `ksplit` such chains over consecutive K runs, summed in order (see csm_op.ksplit; the host picks
  * ksplit > 1 for small feature maps so that all 256 CUs get work).
  * Epilogue order: (+residual if res_mode==1) -> activation -> (+residual if res_mode==2).
@@ -151,7 +152,7 @@ typedef struct csm_op {
     int32_t act, res_mode;   /* res_mode: 0 none, 1 add before act, 2 add after act */
     int64_t w_off, b_off, aux_off;   /* float offsets into the weight buffer (aux = PReLU slopes); -1 = none */
     int32_t flags;
-    int32_t ksplit;          /* CONV: K is cut into `ksplit` runs of (tap, 32-channel) chunks, run s = chunks
+    int32_t ksplit;          /* CONV: K is cut into `ksplit` runs of (32-channel block, tap) chunks (block-major), run s = chunks
                                 [s*T/ksplit, (s+1)*T/ksplit); each run is its own fmaf chain (run 0 starts at the bias,
                                 the others at 0) and the runs are added in order ((p0+p1)+p2)...  1 = single chain */
     int32_t scratch;         /* tensor id of the [n,h,w,ksplit*cout] partial-sum buffer when ksplit > 1, else -1 */

@@ -82,31 +82,32 @@ static void orc_conv(const csm_op *op, view_t in, view_t res, view_t out, const 
         for (int g = 0; g < G; ++g)
             for (int co = 0; co < cout; ++co) {
                 int oc = g * cout + co;
-                /* K runs (csm_op.ksplit): chunk = (tap, 32-channel block); run s = chunks [s*T/S, (s+1)*T/S) */
+                /* K runs (csm_op.ksplit): chunk = (32-channel block, tap), block-major; run s = chunks [s*T/S, (s+1)*T/S) */
                 const int S = op->ksplit > 1 ? op->ksplit : 1, ncb = (cin + 31) / 32, Tall = kh * kw * ncb;
                 float part[16];
                 for (int s_ = 0; s_ < S; ++s_) part[s_] = 0.0f;
                 part[0] = bias ? bias[oc] : 0.0f;
-                for (int ky = 0; ky < kh; ++ky) {
-                    int iy = oy * op->stride - op->pad + ky * op->dil;
-                    for (int kx = 0; kx < kw; ++kx) {
-                        int ix = ox * op->stride - op->pad + kx * op->dil;
-                        if (iy < 0 || iy >= in.h || ix < 0 || ix >= in.w) continue;
-                        const float *x = in.p + ((int64_t)(n * in.h + iy) * in.w + ix) * in.ld + g * cin;
-                        const float *w = W + ((int64_t)oc * cin) * kh * kw + ky * kw + kx;
-                        for (int kb = 0; kb < cin; kb += 8) {
-                            int chunk = (ky * kw + kx) * ncb + kb / 32, run = 0;
+                /* chain order: 32-channel block (outer), taps row-major, 8-channel sub-blocks, channels 0,4,1,5,2,6,3,7 */
+                for (int cb = 0; cb < ncb; ++cb)
+                    for (int ky = 0; ky < kh; ++ky) {
+                        int iy = oy * op->stride - op->pad + ky * op->dil;
+                        for (int kx = 0; kx < kw; ++kx) {
+                            int ix = ox * op->stride - op->pad + kx * op->dil;
+                            if (iy < 0 || iy >= in.h || ix < 0 || ix >= in.w) continue;
+                            const float *x = in.p + ((int64_t)(n * in.h + iy) * in.w + ix) * in.ld + g * cin;
+                            const float *w = W + ((int64_t)oc * cin) * kh * kw + ky * kw + kx;
+                            int chunk = cb * kh * kw + ky * kw + kx, run = 0;
                             if (S > 1) { run = (int)(((int64_t)(chunk + 1) * S - 1) / Tall); while ((int64_t)run * Tall / S > chunk) --run; while ((int64_t)(run + 1) * Tall / S <= chunk) ++run; }
                             float a_ = part[run];
-                            for (int t = 0; t < 4; ++t)
-                                for (int h = 0; h < 2; ++h) {
-                                    int c = kb + 4 * h + t;
-                                    if (c < cin) a_ = fmaf(x[c], w[(int64_t)c * kh * kw], a_);
-                                }
+                            for (int kb = cb * 32; kb < cb * 32 + 32 && kb < cin; kb += 8)
+                                for (int t = 0; t < 4; ++t)
+                                    for (int h = 0; h < 2; ++h) {
+                                        int c = kb + 4 * h + t;
+                                        if (c < cin) a_ = fmaf(x[c], w[(int64_t)c * kh * kw], a_);
+                                    }
                             part[run] = a_;
                         }
                     }
-                }
                 float acc = part[0];
                 for (int s_ = 1; s_ < S; ++s_) acc += part[s_];
                 if (op->res_mode == 1 && res.p) acc += res.p[m * res.ld + oc];

@@ -181,8 +181,8 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
     finally:
         L.csm_debug_force_conv_cfg(-1)
     if groups == 1:
-        # the contract (include/csm355.h) evaluated in numpy for 3 output pixels x all channels: chunks = (tap row-major, 32-channel
-        # block); run s of `ksplit` owns chunks [s*T/S, (s+1)*T/S), starts at the bias (run 0) or 0 and is one fmaf chain with the
+        # the contract (include/csm355.h) evaluated in numpy for 3 output pixels x all channels: chunks = (32-channel block outer, tap
+        # row-major inner); run s of `ksplit` owns chunks [s*T/S, (s+1)*T/S), starts at the bias (run 0) or 0 and is one fmaf chain with the
         # 8-channel blocks in the order 0,4,1,5,2,6,3,7; runs are added ((p0+p1)+p2)...  fmaf = exact product, one rounding.
         xn = xin.cpu().numpy()
         ho, wo = ref.shape[1], ref.shape[2]
@@ -194,7 +194,7 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
             for srun in range(S):
                 acc = b.astype(np.float32).copy() if srun == 0 else np.zeros(cout, np.float32)
                 for chunk in range(srun * T // S, (srun + 1) * T // S):
-                    tap, cb = divmod(chunk, ncb)
+                    cb, tap = divmod(chunk, k * k)
                     kh, kw = divmod(tap, k)
                     iy, ix = oy * stride - dil * (k // 2) + kh * dil, ox * stride - dil * (k // 2) + kw * dil
                     if not (0 <= iy < h and 0 <= ix < w):

@@ -6,7 +6,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int WM, int WN, int TM, int TN, int NSTAGE, int PIPE>
-__global__ __launch_bounds__(64 * WM * WN) void k_glds(const float *__restrict__ src, float *out, int chunks, int64_t stride,
+__global__ __launch_bounds__(64 * WM * WN + ((PIPE & 8) ? 64 : 0)) void k_glds(const float *__restrict__ src, float *out, int chunks, int64_t stride,
                                                          int footprint_blocks) {
     constexpr int NT = 64 * WM * WN, NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN;
@@ -27,9 +27,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_glds(const float *__restrict__
         int slot = (lane & 7) ^ ((row >> 1) & 7);
         gp[g] = src + ((int64_t)(blockIdx.x % footprint_blocks) * ROWS + row) * stride + slot * 4;
     }
+    int issue_count = 0;
     auto issue = [&](int stage) {
+        const bool a_too = !(PIPE & 16) || (issue_count++ % 5) == 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            if (!a_too && 8 * (wave * G + g) < BM) continue;       // this piece is A rows: only every 5th chunk
             // asm, not the builtin: hipcc would otherwise put s_waitcnt vmcnt(0) in front of every later ds_read (it cannot tell the
             // DMA's LDS target from the stage being read) and serialise the prefetch.  vmcnt is counted by hand below.
             unsigned ldsaddr = __builtin_amdgcn_readfirstlane(lds_base + (stage * kStage + 8 * (wave * G + g) * 32) * 4), keep;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_glds(const float *__restrict__
     };
     auto compute = [&](int stage) {
         const float *S = lds + stage * kStage;
-        if (PIPE) {   // fragments of kb+1 are requested before the MFMAs of kb are issued
+        if (PIPE & 1) {   // fragments of kb+1 are requested before the MFMAs of kb are issued
             float4 a0[TM], b0[TN], a1[TM], b1[TN];
             frags(S, 0, a0, b0);
             frags(S, 1, a1, b1); __builtin_amdgcn_sched_barrier(0); mfmas(a0, b0); __builtin_amdgcn_sched_barrier(0);
@@ -81,12 +84,45 @@ __global__ __launch_bounds__(64 * WM * WN) void k_glds(const float *__restrict__
             }
         }
     };
-    if (NSTAGE == 2) {
+    if (PIPE & 8) {
+        // wave specialisation: wave NW only moves data (all ROWS/8 pieces of a chunk), waves 0..NW-1 only compute
+        constexpr int NP = ROWS / 8;
+        if (wave == NW) {
+            const float *lp[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                int row = 8 * p + (lane >> 3);
+                int slot = (lane & 7) ^ ((row >> 1) & 7);
+                lp[p] = src + ((int64_t)(blockIdx.x % footprint_blocks) * ROWS + row) * stride + slot * 4;
+            }
+            auto issue_all = [&](int stage) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    unsigned ldsaddr = __builtin_amdgcn_readfirstlane(lds_base + (stage * kStage + 8 * p * 32) * 4), keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(lp[p]), "s"(ldsaddr) : "memory");
+                    lp[p] += 32;
+                }
+            };
+            issue_all(0);
+            for (int c = 0; c < chunks; ++c) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue_all((c + 1) & 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        for (int c = 0; c < chunks; ++c) {
+            __builtin_amdgcn_s_barrier();
+            compute(c & 1);
+        }
+    } else if (NSTAGE == 2) {
         issue(0);
         for (int c = 0; c < chunks; ++c) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue((c + 1) & 1);           // (dead on the last chunk in a real kernel)
+            if (!(PIPE & 4)) __builtin_amdgcn_s_barrier();
+            if (!(PIPE & 2)) issue((c + 1) & 1);           // (dead on the last chunk in a real kernel)
             compute(c & 1);
         }
     } else {
@@ -118,12 +154,12 @@ void run(const char *name, const float *src, float *out, int tiles64, int chunks
     int grid = (int)((int64_t)tiles64 * 64 * 64 / (BM * BN));
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_glds<WM, WN, TM, TN, NSTAGE, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN, ldsb>>>(src, out, chunks, 2304, footprint);
+    k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN + ((PIPE & 8) ? 64 : 0), ldsb>>>(src, out, chunks, 2304, footprint);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return; }
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN, ldsb>>>(src, out, chunks, 2304, footprint);
+        k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN + ((PIPE & 8) ? 64 : 0), ldsb>>>(src, out, chunks, 2304, footprint);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -138,17 +174,15 @@ int main() {
     size_t n = (size_t)4 * 256 * 2304 + 4096;
     hipMalloc(&src, n * 4); hipMemset(src, 0, n * 4); hipMalloc(&out, 4);
     for (int tiles : {1024, 4096}) {
-        printf("-- work = %d 64x64 tiles x 72 chunks\n", tiles);
-        run<2, 2, 1, 1, 2, 0>("64x64 4w(32x32)", src, out, tiles, 72, 2);
-        run<2, 2, 1, 1, 2, 1>("64x64 4w(32x32) frag-pipelined", src, out, tiles, 72, 2);
-        run<2, 2, 2, 1, 2, 0>("128x64 4w(64x32)", src, out, tiles, 72, 2);
-        run<2, 2, 2, 1, 2, 1>("128x64 4w(64x32) frag-pipelined", src, out, tiles, 72, 2);
-        run<2, 2, 2, 2, 2, 0>("128x128 4w(64x64)", src, out, tiles, 72, 2);
-        run<2, 2, 2, 2, 2, 1>("128x128 4w(64x64) frag-pipelined", src, out, tiles, 72, 2);
-        run<2, 4, 2, 1, 2, 0>("128x128 8w(64x32)", src, out, tiles, 72, 2);
-        run<2, 4, 2, 1, 2, 1>("128x128 8w(64x32) frag-pipelined", src, out, tiles, 72, 2);
-        run<4, 2, 2, 2, 2, 0>("256x128 8w(64x64)", src, out, tiles, 72, 2);
-        run<4, 2, 2, 2, 2, 1>("256x128 8w(64x64) frag-pipelined", src, out, tiles, 72, 2);
+        printf("-- work = %d 64x64 tiles x 72 chunks (A tile DMA only every 5th chunk = 3x3 patch re-use emulation)\n", tiles);
+        run<2, 2, 1, 1, 2, 0>("64x64 full", src, out, tiles, 72, 2);
+        run<2, 2, 1, 1, 2, 16>("64x64 A/5", src, out, tiles, 72, 2);
+        run<2, 2, 2, 1, 2, 0>("128x64 full", src, out, tiles, 72, 2);
+        run<2, 2, 2, 1, 2, 16>("128x64 A/5", src, out, tiles, 72, 2);
+        run<2, 2, 2, 2, 2, 0>("128x128 full", src, out, tiles, 72, 2);
+        run<2, 2, 2, 2, 2, 16>("128x128 A/5", src, out, tiles, 72, 2);
+        run<4, 2, 2, 2, 2, 0>("256x128 8w full", src, out, tiles, 72, 2);
+        run<4, 2, 2, 2, 2, 16>("256x128 8w A/5", src, out, tiles, 72, 2);
     }
     return 0;
 }
