@@ -491,6 +491,186 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 }
 
 
+// ---- 3x3 (stride 1, dilation 1) convolution with input-patch re-use -------------------------------------------------------
+// k_conv_dma moves the A tile (BM pixels x 32 channels) once per (32-channel block, tap): nine times per block for a 3x3.
+// The micro-benchmark (tools/ubench/glds_loop.hip, "A/5") shows that LDS-DMA volume is what costs MFMA rate (64x64 tile:
+// 74 % -> 81 %, 128x128: 83 % -> 87 % when the A moves drop five-fold), so here the output tile is a TH x TW pixel rectangle
+// and the block keeps the (TH+2) x (TW+2) x 32-channel input PATCH of the current channel block in LDS for all nine taps
+// (the chain order is block-major for exactly this reason): the A fragment of output pixel (y, x) under tap (kh, kw) is patch
+// pixel (y+kh, x+kw).  Patch: 2 stages (the next block's patch is fetched during the first tap of the current one); weights:
+// 2 stages, one tile per tap.  Same 128-B rows / XOR swizzle / buffer-range-check zero fill / raw barrier as k_conv_dma.
+template <int WM, int WN, int TM, int TN, int TW>
+__global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
+    constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+    constexpr int NPP = (NPIX + 7) / 8;                         // patch DMA pieces (8 pixels each)
+    constexpr int QP = (NPP + NW - 1) / NW;                     // per wave
+    constexpr int GB = BN / 8 / NW;
+    static_assert(GB * 8 * NW == BN && TH * TW == BM && (TW == 16 || TW == 8), "tile shape");
+    constexpr int kPatchF = QP * NW * 8 * 32, kBF = BN * 32;    // floats per patch stage (every wave's QP pieces have a home) / weight stage
+    constexpr unsigned kOob = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [patch 0][patch 1][B 0][B 1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    int mt, ntile, zz;
+    block_to_tile(mt, ntile, zz);
+    const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, n = mt / (tiles_x * tiles_y);
+    const int n0 = ntile * BN;
+    const int g = zz / a.ksplit, ks = zz - g * a.ksplit;
+    const int ho = a.out.h, wo = a.out.w;
+    const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
+    const int Tall = 9 * a.ncb;
+    const int c_begin = (int)(((int64_t)ks * Tall) / a.ksplit), T = (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
+
+    i32x4 ra, rb;
+    {
+        uint64_t pa = (uint64_t)a.in.p, pb = (uint64_t)a.w;
+        unsigned na = (unsigned)((((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4);
+        unsigned nb = (unsigned)((int64_t)a.groups * Tall * a.npad * 128);
+        ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
+        rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
+    }
+    // patch loader: wave w owns pieces w, w+NW, ...; lane -> patch pixel 8*piece + lane/8, physical slot lane%8
+    unsigned offP[QP], offB[GB];
+    const int iy0 = ty * TH - a.pad, ix0 = tx * TW - a.pad;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        int pp = 8 * (wave + q * NW) + (lane >> 3);
+        int slot = (lane & 7) ^ ((pp >> 1) & 7);
+        int py = pp / PW, px = pp - py * PW;
+        int iy = iy0 + py, ix = ix0 + px;
+        bool v = pp < NPIX && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+        offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + cin_off + slot * 4) * 4u : kOob;
+    }
+#pragma unroll
+    for (int p = 0; p < GB; ++p) {
+        int row = 8 * (wave * GB + p) + (lane >> 3);
+        int slot = (lane & 7) ^ ((row >> 1) & 7);
+        offB[p] = n0 + row < a.npad ? (unsigned)((n0 + row) * 32 + slot * 4) * 4u : kOob;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned ldsB = lds0 + (unsigned)(2 * kPatchF * 4) + (unsigned)(wave * GB * 8) * 128u;
+
+    // all 32-channel rows of block cb -> patch stage cb & 1.  Branch-free (a branch around the asm makes hipcc shuffle the
+    // accumulators): `live` false turns every lane out of range, the DMA then writes zeros into a stage nobody reads any more.
+    auto issue_patch = [&](int cb, bool live) {
+        const unsigned sb = lds0 + (unsigned)(cb & 1) * (unsigned)(kPatchF * 4);
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+            dma16((offP[q] == kOob || !live) ? kOob : offP[q] + (unsigned)cb * 128u, ra, sb + (unsigned)(wave + q * NW) * 1024u);
+    };
+    unsigned l_w = (unsigned)(((int64_t)g * Tall + c_begin) * a.npad * 128);
+    auto issue_b = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < GB; ++p)
+            dma16(offB[p] == kOob ? kOob : offB[p] + l_w, rb, ldsB + (unsigned)stage * (unsigned)(kBF * 4) + (unsigned)p * 1024u);
+        l_w += (unsigned)a.npad * 128u;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int nn = n0 + 32 * (TN * wn + j) + li;
+        float b = (a.bias && ks == 0 && nn < a.cout_g) ? a.bias[cout_off + nn] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+    }
+    // MFMA row li of sub-tile t = TM*wm + i is tile pixel 32 t + li = (py, px); its patch pixel under tap (kh, kw) is
+    // ppb[i] + kh*PW + kw
+    int ppb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int rr = 32 * (TM * wm + i) + li;
+        ppb[i] = (rr / TW) * PW + (rr % TW);
+    }
+    int swb[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) swb[kb] = ((2 * kb + lh) ^ ((li >> 1) & 7)) * 4;
+    const int rowB = (32 * TN * wn + li) * 32;
+    auto compute = [&](int cb, int tap, int bstage) {
+        const float *SP = lds + (cb & 1) * kPatchF;
+        const float *SB = lds + 2 * kPatchF + bstage * kBF;
+        const int kh = tap / 3, toff = kh * PW + (tap - 3 * kh);
+        int arow[TM], asw[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { int pp = ppb[i] + toff; arow[i] = pp * 32; asw[i] = (pp >> 1) & 7; }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(SP + arow[i] + (((2 * kb + lh) ^ asw[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(SB + rowB + j * 1024 + swb[kb]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = t == 0 ? af[i].x : (t == 1 ? af[i].y : (t == 2 ? af[i].z : af[i].w));
+                        const float bv = t == 0 ? bf[j].x : (t == 1 ? bf[j].y : (t == 2 ? bf[j].z : bf[j].w));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+        }
+    };
+
+    int cb = c_begin / 9, tap = c_begin - 9 * cb;
+    issue_patch(cb, true);
+    issue_b(0);
+    for (int chunk = c_begin, st = 0; chunk < T;) {
+        const int tap_end = min(9, tap + (T - chunk));
+        // first chunk of this channel block: the weights of the next chunk AND the next block's patch go out behind the barrier
+        // (the weight fetch is unconditional: past the end of this K run it lands in a stage nobody reads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_b(st ^ 1);
+        issue_patch(cb + 1, (cb + 1) * 9 < T);
+        compute(cb, tap, st);
+        ++chunk; st ^= 1;
+        for (++tap; tap < tap_end; ++tap, ++chunk, st ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_b(st ^ 1);
+            compute(cb, tap, st);
+        }
+        tap = 0; ++cb;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetches must land before the block's LDS is released
+
+    // epilogue: the pixel index is computed once per accumulator row and shared by the TN column tiles
+    float slope[TN]; int ncol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        ncol[j] = n0 + 32 * (TN * wn + j) + li;
+        slope[j] = (a.slope && ncol[j] < a.cout_g) ? a.slope[cout_off + ncol[j]] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int oy = ty * TH + rr / TW, ox = tx * TW + rr % TW;
+            if (oy >= ho || ox >= wo) continue;
+            const int64_t m = ((int64_t)n * ho + oy) * wo + ox;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nn = ncol[j];
+                if (nn >= a.cout_g) continue;
+                float v = acc[i][j][r];
+                if (a.ksplit > 1) { a.partial[(m * a.ksplit + ks) * a.cout_g + nn] = v; continue; }
+                if (a.res_mode == 1) v += a.res.p[m * a.res.ld + cout_off + nn];
+                v = apply_act(v, a.act, slope[j]);
+                if (a.res_mode == 2) v += a.res.p[m * a.res.ld + cout_off + nn];
+                a.out.p[m * a.out.ld + cout_off + nn] = v;
+            }
+        }
+}
+
 // ---- narrow-output convolution (cout <= 4, groups == 1, no split-K): ISNet side outputs / LeReS last conv -------------------
 // An N = 1 output wastes 31/32 of an MFMA tile; this is the same fmaf chain (32-channel blocks, taps row-major, 8-channel
 // sub-blocks in the order 0,4,1,5,2,6,3,7; out-of-image taps contribute exact zeros) evaluated one output pixel per lane on the VALU.  A lane's chain
@@ -923,8 +1103,35 @@ int launch_conv_dma(const ConvArgs &a0, hipStream_t st) {
     return csm::check_launch("k_splitk_reduce");
 }
 
+template <int WM, int WN, int TM, int TN, int TW>
+int launch_conv_patch(const ConvArgs &a0, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
+    constexpr int NW = WM * WN, NPP = ((((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW) * NW;   // pieces, padded to the wave count
+    ConvArgs a = a0;
+    const int tiles_x = (a.out.w + TW - 1) / TW, tiles_y = (a.out.h + TH - 1) / TH;
+    a.m_tiles = tiles_x * tiles_y * a.out.n;
+    size_t lds = ((size_t)2 * NPP * 8 * 32 + (size_t)2 * BN * 32) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch<WM, WN, TM, TN, TW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * a.ksplit);
+    k_conv_patch<WM, WN, TM, TN, TW><<<grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y);
+    int rc = csm::check_launch("k_conv_patch");
+    if (rc || a.ksplit <= 1) return rc;
+    k_splitk_reduce<<<(unsigned)(((int64_t)a.M * a.cout_g + 255) / 256), 256, 0, st>>>(a);
+    return csm::check_launch("k_splitk_reduce");
+}
+
 static bool narrow_eligible(const ConvArgs &a) {
     return a.cout_g <= 4 && a.groups == 1 && a.ksplit == 1 && !(a.cin_g & 3) && !(a.in.ld & 3) && narrow_lds(a, 4, nullptr, nullptr) != 0;
+}
+
+static bool dma_eligible(const ConvArgs &a);
+static bool patch_eligible(const ConvArgs &a) {
+    return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil == 1 && dma_eligible(a);
 }
 
 static bool dma_eligible(const ConvArgs &a) {
@@ -943,7 +1150,10 @@ enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CF
        CFG_NARROW = 13,   // k_conv_narrow (cout <= 4)
        // odd tile heights (1x4 waves, wave tile 32*TM x 32): more block counts for the tuner to dodge grid quantisation with
        CFG_D96x128 = 14, CFG_D160x128 = 15, CFG_D224x128 = 16, CFG_D192x128 = 17,
-       CFG_COUNT = 18 };
+       // 3x3 patch re-use kernel (k_conv_patch); _w8 = 8-pixel-wide output tiles for small maps
+       CFG_P64x64 = 18, CFG_P128x64 = 19, CFG_P64x128 = 20, CFG_P128x128 = 21, CFG_P256x128 = 22, CFG_P128x32 = 23,
+       CFG_P64x64_w8 = 24, CFG_P128x128_w8 = 25, CFG_P128x32_w8 = 26, CFG_P128x128_8w = 27,
+       CFG_COUNT = 28 };
 static int g_force_cfg = -1;
 static int g_dbg = 0;
 
@@ -984,6 +1194,16 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_D160x128: return launch_conv_dma<1, 4, 5, 1>(a, st);
         case CFG_D224x128: return launch_conv_dma<1, 4, 7, 1>(a, st);
         case CFG_D192x128: return launch_conv_dma<1, 4, 6, 1>(a, st);
+        case CFG_P64x64: return launch_conv_patch<2, 2, 1, 1, 16>(a, st);
+        case CFG_P128x64: return launch_conv_patch<2, 2, 2, 1, 16>(a, st);
+        case CFG_P64x128: return launch_conv_patch<2, 2, 1, 2, 16>(a, st);
+        case CFG_P128x128: return launch_conv_patch<2, 2, 2, 2, 16>(a, st);
+        case CFG_P256x128: return launch_conv_patch<4, 2, 2, 2, 16>(a, st);
+        case CFG_P128x32: return launch_conv_patch<4, 1, 1, 1, 16>(a, st);
+        case CFG_P64x64_w8: return launch_conv_patch<2, 2, 1, 1, 8>(a, st);
+        case CFG_P128x128_w8: return launch_conv_patch<2, 2, 2, 2, 8>(a, st);
+        case CFG_P128x32_w8: return launch_conv_patch<4, 1, 1, 1, 8>(a, st);
+        case CFG_P128x128_8w: return launch_conv_patch<2, 4, 2, 1, 16>(a, st);
         default: return launch_conv<32, 2, 2, 1>(a, st);
     }
 }
@@ -1036,6 +1256,7 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 }
                 a.dbg = g_dbg;
                 int cfg = (op.tile > 0 && op.tile <= CFG_COUNT && g_force_cfg < 0) ? op.tile - 1 : choose_cfg(a, op.cout_g);
+                if (cfg >= CFG_P64x64 && !patch_eligible(a)) cfg = CFG_D64x64;
                 if (cfg == CFG_NARROW && !narrow_eligible(a)) cfg = CFG_64x16;
                 if (cfg >= CFG_D64x64 && cfg != CFG_NARROW && !dma_eligible(a)) cfg = op.cout_g <= 16 ? CFG_64x16 : (op.cout_g <= 32 ? CFG_128x32 : CFG_64x64);
                 rc = launch_conv_cfg(cfg, a, st);
@@ -1147,8 +1368,10 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         const int npad = (op.cout_g + 31) / 32 * 32;
         static const int cand_all[] = {CFG_64x64, CFG_128x32, CFG_64x16, CFG_D64x64, CFG_D128x64, CFG_D64x128, CFG_D128x128,
                                        CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32, CFG_NARROW, CFG_D96x128, CFG_D160x128,
-                                       CFG_D224x128, CFG_D192x128};
-        static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32, 4, 128, 128, 128, 128};
+                                       CFG_D224x128, CFG_D192x128, CFG_P64x64, CFG_P128x64, CFG_P64x128, CFG_P128x128, CFG_P256x128,
+                                       CFG_P128x32, CFG_P64x64_w8, CFG_P128x128_w8, CFG_P128x32_w8, CFG_P128x128_8w};
+        static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32, 4, 128, 128, 128, 128,
+                                      64, 64, 128, 128, 128, 32, 64, 128, 32, 128};
         // identical layers (same shapes / strides / split) share one measurement, also across programs
         View vin{}, vout{};
         rc = make_view(tensors, n_tensors, op.in0, workspace, ext, n_ext, vin); if (rc) break;
@@ -1160,6 +1383,7 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         float best = 1e30f; int best_cfg = -1;
         for (size_t c = 0; c < sizeof(cand_all) / sizeof(int); ++c) {
             if (cand_bn[c] >= 2 * npad && cand_bn[c] > 32) continue;      // tile much wider than the output: never wins
+            if (cand_all[c] >= CFG_P64x64 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
             if (cand_bn[c] == 4 && (op.cout_g > 4 || op.groups != 1 || op.ksplit > 1)) continue;
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
             if (cand_bn[c] == 32 && op.cout_g > 64) continue;

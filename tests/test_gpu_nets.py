@@ -170,7 +170,7 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
     L = _lib.load()
     ref, names = None, {}
     try:
-        for cfg in range(18):
+        for cfg in range(28):
             L.csm_debug_force_conv_cfg(cfg)
             cp.run()
             out = cp.read_view(y).cpu().numpy()

@@ -43,7 +43,7 @@ def main():
         from cartoonsegmentation_amd import _lib
         L = _lib.load()
         per = []
-        for cfg in ([-1] + (list(range(12)) if SWEEP else [])):
+        for cfg in ([-1] + (list(range(28)) if SWEEP else [])):
             L.csm_debug_force_conv_cfg(cfg)
             cp.run()
             per.append(min(cp.profile()[0] for _ in range(4)))

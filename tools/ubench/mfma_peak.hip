@@ -9,7 +9,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int NACC, bool LDS>
 __global__ __launch_bounds__(256) void k_mfma(float *out, int iters, float seed) {
     __shared__ __attribute__((aligned(16))) float lds[128 * 36];
-    for (int i = threadIdx.x; i < 128 * 36; i += 256) lds[i] = seed * (float)(i & 7);
+    for (int i = threadIdx.x; i < 128 * 36; i += 256) {
+        // seed < 0: pseudo-random operands in (-1, 1) (realistic bit toggling -> realistic power / clock); else small integers
+        unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        lds[i] = seed < 0.f ? ((float)(h & 0xffffff) / 8388608.0f - 1.0f) : seed * (float)(i & 7);
+    }
     __syncthreads();
     f32x16 acc[NACC];
     for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
@@ -45,16 +49,16 @@ __global__ __launch_bounds__(256) void k_mfma(float *out, int iters, float seed)
 }
 
 template <int NACC, bool LDS>
-void run(const char *name, int blocks_per_cu, int wg) {
+void run(const char *name, int blocks_per_cu, int wg, float seed = 1.0f) {
     float *out; hipMalloc(&out, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int iters = 2000, grid = 256 * blocks_per_cu;
+    const int iters = 6000, grid = 256 * blocks_per_cu;
     k_mfma<NACC, LDS><<<grid, wg>>>(out, 10, 1.0f);
     hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        k_mfma<NACC, LDS><<<grid, wg>>>(out, iters, 1.0f);
+        k_mfma<NACC, LDS><<<grid, wg>>>(out, iters, seed);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -71,5 +75,7 @@ int main() {
     for (int b = 1; b <= 4; ++b) run<1, true>("1 acc chain + ds_read_b128", b, 256);
     for (int b = 1; b <= 4; b *= 2) run<2, true>("2 acc (A shared) + ds_read_b128", b, 256);
     for (int b = 1; b <= 2; ++b) run<4, true>("4 acc + ds_read_b128", b, 256);
+    for (int b = 1; b <= 4; b *= 2) run<1, true>("1 acc + ds_read_b128, RANDOM operands", b, 256, -1.0f);
+    for (int b = 1; b <= 2; ++b) run<4, true>("4 acc + ds_read_b128, RANDOM operands", b, 256, -1.0f);
     return 0;
 }
