@@ -162,8 +162,8 @@ class FrameWorkload(Workload):
     def __init__(self, size, rank, device, batch=8):
         self.frames_per_step = batch
         os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"          # no checkpoints exist offline: closed-form weights
-        if rank != 0:
-            os.environ["CSM_WEIGHTS_PLACEHOLDER"] = "1"    # shapes only; real values arrive by RCCL broadcast from rank 0
+        # every rank builds the same closed-form weights (a rank with placeholder zeros finds no instance, builds no ISNet and
+        # would take part in fewer broadcasts); the RCCL broadcast from rank 0 then overwrites them, as it would real checkpoints
         from cartoonsegmentation_amd import ops, synth
         from cartoonsegmentation_amd.kenburns import KenBurnsConfig, KenBurnsPipeline
         self.ops, self.H, self.W, self.device = ops, size, size, device
@@ -197,8 +197,19 @@ class FrameWorkload(Workload):
         return self.out
 
     def weight_buffers(self):
-        a = self.pipe.animeinsseg
-        bufs = [a._det_weights, a._refine_weights, self.pipe._leres_weights]
+        """the three packed weight buffers, created if this rank's first step did not need them (e.g. no instance -> no ISNet run):
+        every rank must take part in the same three broadcasts"""
+        import math
+        a, pipe = self.pipe.animeinsseg, self.pipe
+        nb, S = self.frames_per_step, a.default_det_size
+        a._detector(S, nb)
+        if a.refine_method == 'refinenet_isnet':
+            a._refiner(min(8, nb * self.INSTANCES), a.refine_size)
+        from cartoonsegmentation_amd.segmentation import scaledown_size
+        h, w = scaledown_size(self.H, self.W, pipe.cfg.depth_est_size)
+        pipe._leres_prog(int(math.ceil(h / 32) * 32), int(math.ceil(w / 32) * 32), nb)
+        bufs = [a._det_weights, a._refine_weights, pipe._leres_weights]
+        assert all(b is not None for b in bufs[:1] + bufs[2:]), "weight buffers missing"
         return [b for b in bufs if b is not None]
 
     def broadcast_weights(self):
@@ -293,18 +304,28 @@ def load_traffic(kernel_key):
 
 def main():
     a = parse()
+    if os.environ.get("CSM_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CSM_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # CSM_BENCH_BACKEND=gloo + fewer GPUs than ranks is a logic check of the multi-rank path on a 1-GPU box (ranks share a GPU);
+    # the measured configuration is always one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("CSM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = make_workload(a.workload, a.size, rank, device, world, dist, a.batch)
 
