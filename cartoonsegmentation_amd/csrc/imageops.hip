@@ -116,6 +116,92 @@ __global__ __launch_bounds__(256) void k_crop_resize(const uint8_t *__restrict__
     }
 }
 
+// ---- small fused reductions of the per-frame depth glue (replace ~25 torch kernels per frame; min/max are order-free) ---------
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+// out[0] = min, out[1] = max of x[0..n) -- one block (n is at most a few million: LeReS output / one frame)
+__global__ __launch_bounds__(1024) void k_minmax(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    __shared__ float smn[1024], smx[1024];
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) { float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int st = 512; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            smn[threadIdx.x] = fminf(smn[threadIdx.x], smn[threadIdx.x + st]);
+            smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + st]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = smn[0]; out[1] = smx[0]; }
+}
+
+// leres/__init__.py:143-145 `depth[depth == 0] = depth[depth > 0].min()`: pass 1 finds the smallest positive value (as ordered
+// uint, atomicMin) and whether a zero exists; pass 2 rewrites only if both hold.  st[0] = ordered min positive, st[1] = zero seen.
+__global__ __launch_bounds__(256) void k_minpos_scan(const float *__restrict__ x, int64_t n, unsigned *__restrict__ st) {
+    __shared__ unsigned smn[256]; __shared__ int sz[256];
+    unsigned mn = 0xffffffffu; int z = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = x[i];
+        if (v > 0.0f) mn = min(mn, __float_as_uint(v));      // positive floats order like their bit patterns
+        z |= v == 0.0f;
+    }
+    smn[threadIdx.x] = mn; sz[threadIdx.x] = z;
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) { smn[threadIdx.x] = min(smn[threadIdx.x], smn[threadIdx.x + s2]); sz[threadIdx.x] |= sz[threadIdx.x + s2]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicMin(&st[0], smn[0]); if (sz[0]) atomicOr(&st[1], 1u); }
+}
+__global__ __launch_bounds__(256) void k_minpos_apply(float *__restrict__ x, int64_t n, const unsigned *__restrict__ st) {
+    if (st[1] == 0u || st[0] == 0xffffffffu) return;         // no zero, or nothing positive: unchanged
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && x[i] == 0.0f) x[i] = __uint_as_float(st[0]);
+}
+
+// kenburns_effect.py:928 `disparity / disparity.max() * baseline` (two roundings, like torch) with the maximum read on the device
+__global__ __launch_bounds__(256) void k_normalise(const float *__restrict__ x, int64_t n, const float *__restrict__ minmax, float scale,
+                                                    float *__restrict__ out, float *__restrict__ norm_max) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (x[i] / minmax[1]) * scale;
+    if (i == 0 && norm_max) norm_max[0] = (minmax[1] / minmax[1]) * scale;     // = max of `out` (the map is monotonic)
+}
+
+// cv2.minMaxLoc(depth[y0:y1, x0:x1]) (kenburns_effect.py:935): value and FIRST row-major position of the minimum and of the
+// maximum.  Keys = (ordered value << 32) | index (min) and (ordered value << 32) | ~index (max) through 64-bit atomics.
+__global__ __launch_bounds__(256) void k_crop_minmaxloc(const float *__restrict__ d, int W, int y0, int x0, int ch, int cw,
+                                                         unsigned long long *__restrict__ keys) {
+    __shared__ unsigned long long kmn[256], kmx[256];
+    unsigned long long mn = ~0ull, mx = 0ull;
+    const int64_t n = (int64_t)ch * cw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int y = (int)(i / cw), x = (int)(i - (int64_t)y * cw);
+        unsigned o = f2ord(d[(int64_t)(y0 + y) * W + x0 + x]);
+        unsigned long long a = ((unsigned long long)o << 32) | (unsigned)i, b = ((unsigned long long)o << 32) | (unsigned)(~(unsigned)i);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+    }
+    kmn[threadIdx.x] = mn; kmx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) {
+            kmn[threadIdx.x] = kmn[threadIdx.x + s2] < kmn[threadIdx.x] ? kmn[threadIdx.x + s2] : kmn[threadIdx.x];
+            kmx[threadIdx.x] = kmx[threadIdx.x + s2] > kmx[threadIdx.x] ? kmx[threadIdx.x + s2] : kmx[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicMin(&keys[0], kmn[0]); atomicMax(&keys[1], kmx[0]); }
+}
+// out[0..5] (float64) = {raw_min_normalised, raw_max_normalised, crop min, crop max, crop argmin, crop argmax}
+__global__ void k_stats_pack(const float *__restrict__ minmax_raw, float scale, const unsigned long long *__restrict__ keys,
+                             double *__restrict__ out) {
+    out[0] = (double)((minmax_raw[0] / minmax_raw[1]) * scale);     // min / max of the normalised map: x -> (x/m)*s is monotonic
+    out[1] = (double)((minmax_raw[1] / minmax_raw[1]) * scale);
+    out[2] = (double)ord2f((unsigned)(keys[0] >> 32)); out[3] = (double)ord2f((unsigned)(keys[1] >> 32));
+    out[4] = (double)(unsigned)(keys[0] & 0xffffffffull); out[5] = (double)(unsigned)(~(unsigned)(keys[1] & 0xffffffffull));
+}
+
 }  // namespace
 
 extern "C" int csm_leres_input(const uint8_t *img_hwc, int H, int W, int h, int w, float *out, void *stream) {
@@ -209,6 +295,41 @@ extern "C" int csm_depth_adjust_instance(float *disp, const uint8_t *mask, int H
     k_adjust_pick<<<1, 256, 0, st>>>(scratch, scratch + H, H, scratch + 2 * H);
     k_adjust_apply<<<csm::cdiv((int64_t)H * W, 256), 256, 0, st>>>(disp, mask, (int64_t)H * W, scratch + 2 * H);
     return csm::check_launch("k_adjust_*");
+}
+
+extern "C" int csm_minmax(const float *x, int64_t n, float *out2, void *stream) {
+    CSM_REQUIRE(x && out2 && n > 0);
+    k_minmax<<<1, 1024, 0, (hipStream_t)stream>>>(x, n, out2);
+    return csm::check_launch("k_minmax");
+}
+
+extern "C" int csm_fill_zero_min_positive(float *x, int64_t n, unsigned *scratch2, void *stream) {
+    CSM_REQUIRE(x && scratch2 && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    CSM_HIP(hipMemsetAsync(scratch2, 0xff, 4, st));
+    CSM_HIP(hipMemsetAsync(scratch2 + 1, 0, 4, st));
+    k_minpos_scan<<<512, 256, 0, st>>>(x, n, scratch2);
+    k_minpos_apply<<<csm::cdiv(n, 256), 256, 0, st>>>(x, n, scratch2);
+    return csm::check_launch("k_minpos_*");
+}
+
+extern "C" int csm_normalise_disparity(const float *x, int64_t n, const float *minmax_dev, float scale, float *out, float *norm_max_out,
+                                       void *stream) {
+    CSM_REQUIRE(x && minmax_dev && out && n > 0);
+    k_normalise<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(x, n, minmax_dev, scale, out, norm_max_out);
+    return csm::check_launch("k_normalise");
+}
+
+extern "C" int csm_depth_range_stats(const float *minmax_raw_dev, float scale, const float *depth, int H, int W, int y0, int x0,
+                                     int crop_h, int crop_w, unsigned long long *scratch2, double *out6, void *stream) {
+    CSM_REQUIRE(minmax_raw_dev && depth && scratch2 && out6 && crop_h > 0 && crop_w > 0 && y0 >= 0 && x0 >= 0 &&
+                y0 + crop_h <= H && x0 + crop_w <= W && (int64_t)crop_h * crop_w < (1ll << 32));
+    hipStream_t st = (hipStream_t)stream;
+    CSM_HIP(hipMemsetAsync(scratch2, 0xff, 8, st));
+    CSM_HIP(hipMemsetAsync(scratch2 + 1, 0, 8, st));
+    k_crop_minmaxloc<<<256, 256, 0, st>>>(depth, W, y0, x0, crop_h, crop_w, scratch2);
+    k_stats_pack<<<1, 1, 0, st>>>(minmax_raw_dev, scale, scratch2, out6);
+    return csm::check_launch("k_crop_minmaxloc");
 }
 
 extern "C" int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream) {

@@ -134,10 +134,11 @@ def colorize_depth(depth, inverse=False, rgb2bgr=False, cmap='magma_r'):
 
 
 def _fill_zero_with_min_positive(depth):
-    """`depth[depth == 0] = depth[depth > 0].min()` (leres/__init__.py:143-145 semantics: skipped when nothing is positive)
-    without the boolean-index host sync"""
-    mn = torch.where(depth > 0, depth, depth.new_full((), float('inf'))).min()
-    return torch.where((depth == 0) & torch.isfinite(mn), mn, depth)
+    """`depth[depth == 0] = depth[depth > 0].min()` (leres/__init__.py:143-145 semantics: skipped when nothing is positive),
+    in place on the device, no host sync"""
+    scratch = torch.empty(2, dtype=torch.int32, device=depth.device)
+    check(_lib.load().csm_fill_zero_min_positive(ptr(depth), i64(depth.numel()), ptr(scratch), stream_ptr()), "fill_zero")
+    return depth
 
 
 def depth_adjustment_animesseg(instances, tenDisparity, tenImage, use_medium=False):
@@ -361,7 +362,8 @@ class KenBurnsPipeline:
         outs = []
         for bi in range(nb):
             yb = y[bi]
-            mnmx = torch.stack([yb.min(), yb.max()])
+            mnmx = torch.empty(2, dtype=torch.float32, device=self.device)
+            check(L.csm_minmax(ptr(yb), i64(h * w), ptr(mnmx), stream_ptr()), "minmax")
             q = torch.empty((h, w), dtype=torch.uint8, device=self.device)
             check(L.csm_leres_quantize(ptr(yb), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
             depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
@@ -381,7 +383,8 @@ class KenBurnsPipeline:
         check(L.csm_leres_input(ptr(img_d), i32(H), i32(W), i32(h), i32(w), ptr(x), stream_ptr()), "leres_input")
         y = torch.empty((1, 1, h, w), dtype=torch.float32, device=self.device)
         self._leres_prog(h, w).run(x, y)
-        mnmx = torch.stack([y.min(), y.max()])
+        mnmx = torch.empty(2, dtype=torch.float32, device=self.device)
+        check(L.csm_minmax(ptr(y), i64(h * w), ptr(mnmx), stream_ptr()), "minmax")
         q = torch.empty((h, w), dtype=torch.uint8, device=self.device)
         check(L.csm_leres_quantize(ptr(y), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
         depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
@@ -503,11 +506,24 @@ class KenBurnsPipeline:
 
     def _finish_config(self, cfg, img, img_tensor, instances, disparity):
         """kenburns_effect.py:928-951"""
-        disparity = disparity / disparity.max() * self.cfg.baseline
-        depth, valid, pts, unaltered = ops.disparity_to_points(disparity, cfg.focal, cfg.baseline)
+        # kenburns_effect.py:928-935 with the reductions on the device: raw {min,max} -> normalise -> points -> minMaxLoc of the
+        # depth crop; ONE host read of six scalars (the reference syncs per scalar)
+        L, dev = _lib.load(), disparity.device
+        raw = disparity.contiguous()
+        H, W = int(raw.shape[2]), int(raw.shape[3])
+        mm = torch.empty(2, dtype=torch.float32, device=dev)
+        nmax = torch.empty(1, dtype=torch.float32, device=dev)
+        check(L.csm_minmax(ptr(raw), i64(raw.numel()), ptr(mm), stream_ptr()), "minmax")
+        disparity = torch.empty_like(raw)
+        check(L.csm_normalise_disparity(ptr(raw), i64(raw.numel()), ptr(mm), f32(self.cfg.baseline), ptr(disparity), ptr(nmax),
+                                        stream_ptr()), "normalise")
+        depth, valid, pts, unaltered = ops.disparity_to_points(disparity, cfg.focal, cfg.baseline, dmax=nmax)
         crop = depth[0, 0, 128:-128, 128:-128]                      # cv2.minMaxLoc(depth[128:-128,128:-128])
-        st = torch.stack([disparity.min().double(), disparity.max().double(), crop.min().double(), crop.max().double(),
-                          crop.argmin().double(), crop.argmax().double()]).tolist()          # one host sync for all six scalars
+        keys = torch.empty(2, dtype=torch.int64, device=dev)
+        out6 = torch.empty(6, dtype=torch.float64, device=dev)
+        check(L.csm_depth_range_stats(ptr(mm), f32(self.cfg.baseline), ptr(depth), i32(H), i32(W), i32(128), i32(128),
+                                      i32(H - 256), i32(W - 256), ptr(keys), ptr(out6), stream_ptr()), "depth_range_stats")
+        st = out6.tolist()                                          # the one host sync of this stage
         cfg['fltDispmin'], cfg['fltDispmax'] = st[0], st[1]
         amin, amax, cw = int(st[4]), int(st[5]), crop.shape[1]
         cfg['objDepthrange'] = (st[2], st[3], (amin % cw, amin // cw), (amax % cw, amax // cw))

@@ -102,13 +102,15 @@ def depth_to_points(tenDepth, fltFocal):
     return pts
 
 
-def disparity_to_points(tenDisparity, fltFocal, fltBaseline, eps=0.00001):
-    """kenburns_effect.py:929-933 fused: normalised disparity -> depth, valid, points, unaltered"""
+def disparity_to_points(tenDisparity, fltFocal, fltBaseline, eps=0.00001, dmax=None):
+    """kenburns_effect.py:929-933 fused: normalised disparity -> depth, valid, points, unaltered.
+    dmax: optional 1-element device tensor holding max(tenDisparity) when the caller already has it"""
     d = _dev(tenDisparity, "tenDisparity")
     H, W = d.shape[-2:]
     depth, valid = torch.empty_like(d), torch.empty_like(d)
     pts, un = d.new_empty([1, 3, H, W]), d.new_empty([1, 3, H, W])
-    dmax = d.max().reshape(1)                                                  # stays on the device: no host sync
+    if dmax is None:
+        dmax = d.max().reshape(1)                                              # stays on the device: no host sync
     check(_lib.load().csm_disparity_to_points(ptr(d), ptr(dmax), i32(H), i32(W), f64(fltFocal),
                                               f64(fltBaseline), f32(eps), ptr(depth), ptr(valid), ptr(pts), ptr(un), stream_ptr()),
           "disparity_to_points")
