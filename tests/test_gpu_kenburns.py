@@ -214,3 +214,68 @@ def test_batched_configs_match_single_frame_path():
         assert inter / max(union, 1) > 0.999
         a, b = ks['tenRawDepth'], kb['tenRawDepth']
         assert ((a - b).abs() <= 1e-3 * b.abs() + 1e-6).float().mean().item() > 0.999
+
+
+def test_depth_glue_ops_vs_numpy():
+    """csm_minmax / csm_fill_zero_min_positive / csm_depth_adjust_instance / csm_normalise_disparity / csm_depth_range_stats
+    against numpy restatements of the reference lines (leres/__init__.py:143-145, kenburns_effect.py:68-78, :928, :935),
+    including the branches the pipeline tests do not reach: zeros present, empty mask, ties in the depth crop."""
+    import ctypes
+    from cartoonsegmentation_amd import _lib
+    from cartoonsegmentation_amd._lib import check, f32, i32, i64, ptr, stream_ptr
+    from oracle import kenburns as okb
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    H, W = 300, 333
+    # -- min/max
+    x = rng.normal(0, 3, (H, W)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda(); mm = torch.empty(2, device='cuda')
+    check(L.csm_minmax(ptr(xd), i64(x.size), ptr(mm), stream_ptr()))
+    assert mm.cpu().numpy().tolist() == [float(x.min()), float(x.max())]
+    # -- zero fill: zeros + positives, no zeros, nothing positive
+    for case in ("zeros", "nozero", "nopos"):
+        d = np.floor(rng.uniform(0, 255, (H, W))).astype(np.float32)
+        if case == "zeros":
+            d[rng.uniform(size=d.shape) < 0.05] = 0
+        elif case == "nozero":
+            d[d == 0] = 7
+        else:
+            d[:] = 0
+        ref = d.copy()
+        if (ref > 0).any():
+            ref[ref == 0] = ref[ref > 0].min()
+        dd = torch.from_numpy(d).cuda(); sc = torch.empty(2, dtype=torch.int32, device='cuda')
+        check(L.csm_fill_zero_min_positive(ptr(dd), i64(d.size), ptr(sc), stream_ptr()))
+        assert np.array_equal(dd.cpu().numpy(), ref), case
+    # -- depth adjustment: two overlapping instances, one empty mask, one touching the bottom row
+    disp = rng.uniform(1, 255, (1, 1, H, W)).astype(np.float32)
+    masks = np.zeros((4, H, W), bool)
+    masks[0, 40:200, 50:180] = True
+    masks[1, 150:H, 100:300] = True            # reaches the last row, overlaps instance 0
+    masks[3, 10:13, 5:9] = True                # tiny: top == r0 region
+    ref = okb.depth_adjustment(list(masks), disp)
+    dd = torch.from_numpy(disp.copy()).cuda()
+    sc = torch.empty(2 * H + 2, device='cuda')
+    for m in masks:
+        md = torch.from_numpy(m).cuda()
+        check(L.csm_depth_adjust_instance(ptr(dd), ptr(md.view(torch.uint8)), i32(H), i32(W), ptr(sc), stream_ptr()))
+    assert np.array_equal(dd.cpu().numpy(), ref)
+    # -- normalise + depth-range statistics with ties (a constant plateau inside the crop)
+    raw = ref.astype(np.float32)
+    raw[0, 0, 140:160, 140:170] = raw.max()           # many equal maxima of the disparity -> equal minima of the depth
+    base = np.float32(40.0)
+    norm = (raw / raw.max() * base).astype(np.float32)
+    rd = torch.from_numpy(raw).cuda(); mm = torch.empty(2, device='cuda'); nd = torch.empty_like(rd); nmax = torch.empty(1, device='cuda')
+    check(L.csm_minmax(ptr(rd), i64(raw.size), ptr(mm), stream_ptr()))
+    check(L.csm_normalise_disparity(ptr(rd), i64(raw.size), ptr(mm), f32(float(base)), ptr(nd), ptr(nmax), stream_ptr()))
+    assert np.array_equal(nd.cpu().numpy(), norm) and float(nmax.item()) == float(norm.max())
+    depth = ((np.float32(1.0) / (norm + np.float32(1e-5))) * np.float32(100.0)).astype(np.float32)
+    dd = torch.from_numpy(depth).cuda()
+    keys = torch.empty(2, dtype=torch.int64, device='cuda'); out6 = torch.empty(6, dtype=torch.float64, device='cuda')
+    check(L.csm_depth_range_stats(ptr(mm), f32(float(base)), ptr(dd), i32(H), i32(W), i32(128), i32(128), i32(H - 256), i32(W - 256),
+                                  ptr(keys), ptr(out6), stream_ptr()))
+    crop = depth[0, 0, 128:-128, 128:-128]
+    got = out6.cpu().numpy()
+    assert got[0] == float(norm.min()) and got[1] == float(norm.max())
+    assert got[2] == float(crop.min()) and got[3] == float(crop.max())
+    assert int(got[4]) == int(crop.argmin()) and int(got[5]) == int(crop.argmax())      # first row-major occurrence, like numpy / cv2
