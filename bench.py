@@ -204,7 +204,7 @@ class FrameWorkload(Workload):
         nb, S = self.frames_per_step, a.default_det_size
         a._detector(S, nb)
         if a.refine_method == 'refinenet_isnet':
-            a._refiner(min(8, nb * self.INSTANCES), a.refine_size)
+            a._refiner(min(a.refine_batch, nb * self.INSTANCES), a.refine_size)
         from cartoonsegmentation_amd.segmentation import scaledown_size
         h, w = scaledown_size(self.H, self.W, pipe.cfg.depth_est_size)
         pipe._leres_prog(int(math.ceil(h / 32) * 32), int(math.ceil(w / 32) * 32), nb)

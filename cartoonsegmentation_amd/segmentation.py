@@ -96,6 +96,7 @@ class AnimeInsSeg:
         self._det_programs, self._det_weights, self._prior_cache = {}, None, {}
         self._refine_programs, self._refine_weights, self._refine_ws = {}, None, None
         self.refine_method = None
+        self.refine_batch = int(os.environ.get('CSM_REFINE_BATCH', '16'))   # instances per ISNet run when frames are batched
         self.set_refine_method(**(refine_kwargs or {'refine_method': 'none'}))
 
     # ---- configuration (reference :395-399, :623-636, :704-708) --------------------------------
@@ -369,7 +370,7 @@ class AnimeInsSeg:
             self._postprocess_refine(inst, img, refine_size=self.refine_size)
         return inst
 
-    def _refine_many(self, pairs, refine_size=720, max_batch=8):
+    def _refine_many(self, pairs, refine_size=720, max_batch=None):
         """ISNet refine of several (instances, image) pairs of equal image size with shared batches (per-sample results are
         those of _postprocess_refine; the reference's per-image limit of 4 only bounds its memory use)."""
         L = _lib.load()
@@ -387,6 +388,7 @@ class AnimeInsSeg:
         rh, rw = scaledown_size(H, W, T)
         flat = [(j, k) for j, (_, _, segs) in enumerate(jobs) for k in range(segs.shape[0])]
         outs = [torch.empty((segs.shape[0], H, W), dtype=torch.uint8, device=self.device) for _, _, segs in jobs]
+        max_batch = max_batch or self.refine_batch
         for c0 in range(0, len(flat), max_batch):
             chunk = flat[c0:c0 + max_batch]
             b = len(chunk)
