@@ -148,18 +148,18 @@ __global__ __launch_bounds__(64 * WM * WN + ((PIPE & 8) ? 64 : 0)) void k_glds(c
 }
 
 template <int WM, int WN, int TM, int TN, int NSTAGE, int PIPE>
-void run(const char *name, const float *src, float *out, int tiles64, int chunks, int footprint) {
+void run(const char *name, const float *src, float *out, int tiles64, int chunks, int footprint, int stride = 2304) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     size_t ldsb = (size_t)NSTAGE * (BM + BN) * 32 * sizeof(float);
     int grid = (int)((int64_t)tiles64 * 64 * 64 / (BM * BN));
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_glds<WM, WN, TM, TN, NSTAGE, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN + ((PIPE & 8) ? 64 : 0), ldsb>>>(src, out, chunks, 2304, footprint);
+    k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN + ((PIPE & 8) ? 64 : 0), ldsb>>>(src, out, chunks, stride, footprint);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return; }
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN + ((PIPE & 8) ? 64 : 0), ldsb>>>(src, out, chunks, 2304, footprint);
+        k_glds<WM, WN, TM, TN, NSTAGE, PIPE><<<grid, 64 * WM * WN + ((PIPE & 8) ? 64 : 0), ldsb>>>(src, out, chunks, stride, footprint);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -171,18 +171,17 @@ void run(const char *name, const float *src, float *out, int tiles64, int chunks
 
 int main() {
     float *src, *out;
-    size_t n = (size_t)4 * 256 * 2304 + 4096;
+    size_t n = (size_t)400 * 256 * 1024 + (size_t)4 * 256 * 2304 + 4096;
     hipMalloc(&src, n * 4); hipMemset(src, 0, n * 4); hipMalloc(&out, 4);
-    for (int tiles : {1024, 4096}) {
-        printf("-- work = %d 64x64 tiles x 72 chunks (A tile DMA only every 5th chunk = 3x3 patch re-use emulation)\n", tiles);
-        run<2, 2, 1, 1, 2, 0>("64x64 full", src, out, tiles, 72, 2);
-        run<2, 2, 1, 1, 2, 16>("64x64 A/5", src, out, tiles, 72, 2);
-        run<2, 2, 2, 1, 2, 0>("128x64 full", src, out, tiles, 72, 2);
-        run<2, 2, 2, 1, 2, 16>("128x64 A/5", src, out, tiles, 72, 2);
-        run<2, 2, 2, 2, 2, 0>("128x128 full", src, out, tiles, 72, 2);
-        run<2, 2, 2, 2, 2, 16>("128x128 A/5", src, out, tiles, 72, 2);
-        run<4, 2, 2, 2, 2, 0>("256x128 8w full", src, out, tiles, 72, 2);
-        run<4, 2, 2, 2, 2, 16>("256x128 8w A/5", src, out, tiles, 72, 2);
+    for (int tiles : {3072}) {
+        printf("-- work = %d 64x64 tiles x 32 chunks, rows 4 KB apart, footprint 400 tile-rows (1x1 conv, K = 1024, partly L2-missing)\n", tiles);
+        run<2, 2, 1, 1, 2, 0>("64x64 2-stage", src, out, tiles, 32, 400, 1024);
+        run<2, 2, 1, 1, 3, 0>("64x64 3-stage", src, out, tiles, 32, 400, 1024);
+        run<2, 2, 2, 1, 2, 0>("128x64 2-stage", src, out, tiles, 32, 400, 1024);
+        run<2, 2, 2, 1, 3, 0>("128x64 3-stage", src, out, tiles, 32, 400, 1024);
+        run<2, 2, 2, 2, 2, 0>("128x128 2-stage", src, out, tiles, 32, 200, 1024);
+        run<2, 2, 2, 2, 3, 0>("128x128 3-stage", src, out, tiles, 32, 200, 1024);
+        run<2, 2, 2, 2, 2, 0>("128x128 2-stage, L2-resident", src, out, tiles, 32, 2, 1024);
     }
     return 0;
 }
