@@ -145,25 +145,67 @@ __global__ __launch_bounds__(kBlock) void k_update_output(const float *__restric
                                                            const float *__restrict__ zee,
                                                            float *__restrict__ accum) {
     int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= total) return;
-    int64_t b = idx / N, p = idx - b * N;
-    float x, y, z;
-    load_point<SHIFT>(pts + b * 3 * N, N, p, s, x, y, z);
-    float fx, fy, err, w[4];
-    if (!project(x, y, z, pc, fx, fy, err)) return;
-    int x0, y0;
-    corner_weights(fx, fy, x0, y0, w);
+    const bool live = idx < total;
+    const int64_t b = live ? idx / N : 0, p = live ? idx - b * N : 0;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (live) load_point<SHIFT>(pts + b * 3 * N, N, p, s, x, y, z);
+    float fx = 0.f, fy = 0.f, err = 0.f, w[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool proj = live && project(x, y, z, pc, fx, fy, err);
+    int x0 = 0, y0 = 0;
+    if (proj) corner_weights(fx, fy, x0, y0, w);
     const int C = CT > 0 ? CT : (C0 + C1n);
     const int64_t plane = (int64_t)pc.H * pc.W;
     const float *D0 = d0 + b * C0 * N;
     const float *D1 = d1 ? d1 + b * C1n * N : nullptr;
     float *A = accum + b * (C + 1) * plane;
     const float *Z = zee + b * plane;
-    float v[CT > 0 ? CT : 1];
-    if (CT > 0) {
+    if constexpr (CT > 0) {
+        // Fixed channel count (frame loop, C = 4; autozoom, C = 3).  The float atomics bound this kernel (20 per point at
+        // C = 4), and a wave's 64 lanes are 64 consecutive source pixels: after the camera shift lane i's east corners are
+        // very often lane i+1's west corners.  Merge them in registers (two cross-lane moves per channel) and issue one
+        // atomic instead of two -- the sum of a pixel is order-free up to fp32 rounding either way.
+        float v[CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) v[c] = c < C0 ? D0[(int64_t)c * N + p] : D1[(int64_t)(c - C0) * N + p];
+        for (int c = 0; c < CT; ++c) v[c] = proj ? (c < C0 ? D0[(int64_t)c * N + p] : D1[(int64_t)(c - C0) * N + p]) : 0.f;
+        int o[4]; bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+            bool in = proj && cx >= 0 && cx < pc.W && cy >= 0 && cy < pc.H;
+            o[k] = in ? cy * pc.W + cx : -1;
+            ok[k] = in && ((double)err <= (double)Z[o[k]] + 1.0);
+        }
+        float cw[4][CT + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) cw[k][c] = v[c] * w[k];
+            cw[k][CT] = 1.0f * w[k];
+        }
+        const int lane = threadIdx.x & 63;
+        const int bl = (int)b, b_left = __shfl_up(bl, 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                            // h = 0: north pair (NE -> NW), h = 1: south pair (SE -> SW)
+            const int dst = 2 * h, src = 2 * h + 1;
+            const int o_left = __shfl_up(ok[src] ? o[src] : -2, 1);
+            const bool merge = lane > 0 && ok[dst] && o_left == o[dst] && b_left == bl;
+#pragma unroll
+            for (int c = 0; c <= CT; ++c) {
+                float t = __shfl_up(cw[src][c], 1);
+                if (merge) cw[dst][c] += t;
+            }
+            const int absorbed = __shfl_down(merge ? 1 : 0, 1);
+            if (lane < 63 && absorbed) ok[src] = false;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+#pragma unroll
+            for (int c = 0; c <= CT; ++c) atomicAdd(A + (int64_t)c * plane + o[k], cw[k][c]);
+        }
+        return;
     }
+    if (!proj) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int cx = x0 + (k & 1), cy = y0 + (k >> 1);
@@ -171,13 +213,8 @@ __global__ __launch_bounds__(kBlock) void k_update_output(const float *__restric
         int64_t o = (int64_t)cy * pc.W + cx;
         if (!((double)err <= (double)Z[o] + 1.0)) continue;
         float wk = w[k];
-        if (CT > 0) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c) atomicAdd(A + c * plane + o, v[c] * wk);
-        } else {
-            for (int c = 0; c < C0; ++c) atomicAdd(A + c * plane + o, D0[(int64_t)c * N + p] * wk);
-            for (int c = 0; c < C1n; ++c) atomicAdd(A + (C0 + c) * plane + o, D1[(int64_t)c * N + p] * wk);
-        }
+        for (int c = 0; c < C0; ++c) atomicAdd(A + c * plane + o, D0[(int64_t)c * N + p] * wk);
+        for (int c = 0; c < C1n; ++c) atomicAdd(A + (C0 + c) * plane + o, D1[(int64_t)c * N + p] * wk);
         atomicAdd(A + (int64_t)C * plane + o, 1.0f * wk);
     }
 }
