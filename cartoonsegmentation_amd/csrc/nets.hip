@@ -320,7 +320,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
 
 
 // ---- LDS-DMA implicit-GEMM convolution (the main kernel) ------------------------------------------------------------
-// Same arithmetic as k_conv_mfma (one fmaf chain per output, chunk = (tap, 32 channels), 8-block order 0,4,1,5,2,6,3,7) --
+// Same arithmetic as k_conv_mfma (one fmaf chain per output, chunk = (32-channel block, tap) block-major, 8-block order
+// 0,4,1,5,2,6,3,7) --
 // what changes is how operands reach the matrix pipe:
 //  * tiles go global -> LDS by `buffer_load_dwordx4 ... lds` (no staging VGPRs, no ds_write, no per-element zero select):
 //    one wave-instruction moves 8 rows x 128 B.  Out-of-image taps, M / N tails use the buffer range check: their lanes

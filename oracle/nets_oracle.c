@@ -3,7 +3,7 @@
  *
  * CPU interpreter of the layer program (csm_op records, include/csm355.h) that the product
  * executes with HIP kernels.  It is the bit-exact checker of the dense nets: every convolution
- * output is one fp32 fmaf chain in the contract's order (bias first; taps row-major; aligned
+ * output is one fp32 fmaf chain in the contract's order (bias first; 32-channel blocks outer, taps row-major inner; aligned
  * blocks of 8 input channels in the order 0,4,1,5,2,6,3,7), activations use the same polynomial
  * expf, pooling / resize follow aten's index rules.
  *
