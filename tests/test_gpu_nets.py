@@ -209,3 +209,39 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
             for q in parts[1:]:
                 tot = (tot + q).astype(np.float32)
             assert np.array_equal(tot, ref[0, oy, ox]), "fmaf chain mismatch at (%d,%d): %g" % (oy, ox, np.abs(tot - ref[0, oy, ox]).max())
+
+
+def test_program_run_is_hipgraph_capturable():
+    """CompiledProgram.run enqueues only kernels on torch's current stream (no allocation, no sync after the first, tuning, call):
+    capture a small net into a hipGraph, replay it on new input, compare with the eager run bit for bit."""
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    p = Program("graph")
+    x_ext = p.ext_nchw(1, 32, 24, 40); y_ext = p.ext_nchw(1, 64, 24, 40)
+    x = p.to_nhwc(x_ext)
+    t = p.conv(x, rnd('gw1', (64, 32, 3, 3), 0.1), rnd('gb1', (64,), 0.1), pad=1, act='silu')
+    t = p.conv(t, rnd('gw2', (64, 64, 1, 1), 0.1), rnd('gb2', (64,), 0.1), act='relu')
+    t = p.conv(t, rnd('gw3', (64, 64, 3, 3), 0.05), rnd('gb3', (64,), 0.1), pad=1, act=None, res=t, res_mode=1)
+    p.to_nchw(t, y_ext)
+    p.plan()
+    cp = CompiledProgram(p, 'cuda')
+    xin = torch.from_numpy(rnd('gx', (1, 32, 24, 40))).cuda()
+    y = torch.empty((1, 64, 24, 40), device='cuda')
+    cp.run(xin, y)                                  # first call tunes the tiles (not capturable), later calls only launch
+    torch.cuda.synchronize()
+    eager = y.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        cp.run(xin, y)                              # warm the side stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            cp.run(xin, y)
+    y.zero_()
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(y, eager)
+    xin.copy_(torch.from_numpy(rnd('gx2', (1, 32, 24, 40))).cuda())      # new input in the same buffer -> replay computes it
+    g.replay(); torch.cuda.synchronize()
+    y2 = y.clone()
+    cp.run(xin, y); torch.cuda.synchronize()
+    assert torch.equal(y, y2) and not torch.equal(y2, eager)
