@@ -672,6 +672,98 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
         }
 }
 
+// ---- stem convolution (cin padded to 4: RTMDet / ISNet / LeReS first layers) -----------------------------------------------
+// The generic kernels spend one 32-channel chunk per tap with 4 channels in use.  Here K is packed (tap, channel): a chunk holds
+// 8 taps x 4 channels (weights packed to match on the host, program.py::pack_stem_weights), 7 chunks instead of 49 for the
+// 7x7.  Each loader thread fetches one pixel's 4 channels for one tap (one float4) and scatters them into the 8-block positions
+// that make the MFMA lane order 0,4,1,5,2,6,3,7 walk tap 2j's channels 0..3 and then tap 2j+1's -- the contract's chain.
+// 64x64 tile, 2x2 waves, register-staged (the permutation rules out LDS-DMA), one LDS buffer; HBM-bound for the 3x3 stems.
+__global__ __launch_bounds__(256) void k_conv_stem(ConvArgs a) {
+    constexpr int BM = 64, BN = 64;
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * kLdsLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    int mt, ntile, zz;
+    block_to_tile(mt, ntile, zz);
+    const int m0 = mt * BM, n0 = ntile * BN;
+    const int ho = a.out.h, wo = a.out.w, ntaps = a.kh * a.kw, nck = (ntaps + 7) >> 3;
+    // A loader: thread -> rows (tid>>3) and (tid>>3)+32, tap slot j = tid&7 of the chunk
+    const int j = tid & 7;
+    const float *rowp[2]; int iy0[2], ix0[2]; bool rv[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int m = m0 + (tid >> 3) + 32 * it;
+        rv[it] = m < a.M;
+        int mm = rv[it] ? m : 0;
+        int n = mm / (ho * wo), rem = mm - n * ho * wo;
+        int oy = rem / wo, ox = rem - oy * wo;
+        iy0[it] = oy * a.stride - a.pad; ix0[it] = ox * a.stride - a.pad;
+        rowp[it] = a.in.p + (int64_t)n * a.in.h * a.in.w * a.in.ld;
+    }
+    const float *wp[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) wp[it] = a.w + (int64_t)(n0 + (tid >> 3) + 32 * it) * 32 + j * 4;
+    float4 ra[2], rb[2];
+    auto gload = [&](int c) {
+        const int t = 8 * c + j, kh = t / a.kw, kw = t - kh * a.kw;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            int iy = iy0[it] + kh * a.dil, ix = ix0[it] + kw * a.dil;
+            bool v = rv[it] && t < ntaps && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+            ra[it] = v ? *reinterpret_cast<const float4 *>(rowp[it] + ((int64_t)iy * a.in.w + ix) * a.in.ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bool vb = n0 + (tid >> 3) + 32 * it < a.npad;
+            rb[it] = vb ? *reinterpret_cast<const float4 *>(wp[it] + (int64_t)c * a.npad * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            float *row = lds + ((tid >> 3) + 32 * it) * kLdsLd + 8 * (j >> 1) + 2 * (j & 1);
+            *reinterpret_cast<float2 *>(row) = make_float2(ra[it].x, ra[it].z);          // (c0, c2) of this tap
+            *reinterpret_cast<float2 *>(row + 4) = make_float2(ra[it].y, ra[it].w);      // (c1, c3)
+            *reinterpret_cast<float4 *>(lds + (BM + (tid >> 3) + 32 * it) * kLdsLd + j * 4) = rb[it];
+        }
+    };
+    f32x16 acc;
+    {
+        int n = n0 + 32 * wn + li;
+        float b = (a.bias && n < a.cout_g) ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b;
+    }
+    const float *A = lds + (32 * wm + li) * kLdsLd + 4 * lh;
+    const float *B = lds + (BM + 32 * wn + li) * kLdsLd + 4 * lh;
+    gload(0);
+    for (int c = 0; c < nck; ++c) {
+        lstore();
+        __syncthreads();
+        if (c + 1 < nck) gload(c + 1);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const float4 af = *reinterpret_cast<const float4 *>(A + kb * 8);
+            const float4 bf = *reinterpret_cast<const float4 *>(B + kb * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + 32 * wn + li;
+    if (n >= a.cout_g) return;
+    const float slope = a.slope ? a.slope[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= a.M) continue;
+        float v = acc[r];
+        if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + n];
+        v = apply_act(v, a.act, slope);
+        if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + n];
+        a.out.p[(int64_t)m * a.out.ld + n] = v;
+    }
+}
+
 // ---- narrow-output convolution (cout <= 4, groups == 1, no split-K): ISNet side outputs / LeReS last conv -------------------
 // An N = 1 output wastes 31/32 of an MFMA tile; this is the same fmaf chain (32-channel blocks, taps row-major, 8-channel
 // sub-blocks in the order 0,4,1,5,2,6,3,7; out-of-image taps contribute exact zeros) evaluated one output pixel per lane on the VALU.  A lane's chain
@@ -1256,6 +1348,14 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                     csm::set_error("op %d: conv input must be 16-byte aligned with channels %% 4 == 0", i); return CSM_ERR_ARG;
                 }
                 a.dbg = g_dbg;
+                if (op.flags & 2) {      // stem: (tap, channel)-packed K (weights packed by the host for exactly this kernel)
+                    if (op.groups != 1 || op.cin_g != 4 || a.ksplit != 1) { csm::set_error("op %d: stem flag needs groups 1, cin 4, ksplit 1", i); return CSM_ERR_ARG; }
+                    dim3 grid((a.M + 63) / 64, (op.cout_g + 63) / 64, 1);
+                    k_conv_stem<<<grid, 256, 0, st>>>(a);
+                    rc = csm::check_launch("k_conv_stem");
+                    if (rc) return rc;
+                    break;
+                }
                 int cfg = (op.tile > 0 && op.tile <= CFG_COUNT && g_force_cfg < 0) ? op.tile - 1 : choose_cfg(a, op.cout_g);
                 if (cfg >= CFG_P64x64 && !patch_eligible(a)) cfg = CFG_D64x64;
                 if (cfg == CFG_NARROW && !narrow_eligible(a)) cfg = CFG_64x16;
@@ -1365,7 +1465,7 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
     int tuned = 0, rc = CSM_OK;
     for (int i = 0; i < n_ops && rc == CSM_OK; ++i) {
         csm_op &op = ops[i];
-        if (op.kind != CSM_OP_CONV) continue;
+        if (op.kind != CSM_OP_CONV || (op.flags & 2)) continue;          // stems have one dedicated kernel
         const int npad = (op.cout_g + 31) / 32 * 32;
         static const int cand_all[] = {CFG_64x64, CFG_128x32, CFG_64x16, CFG_D64x64, CFG_D128x64, CFG_D64x128, CFG_D128x128,
                                        CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32, CFG_NARROW, CFG_D96x128, CFG_D160x128,

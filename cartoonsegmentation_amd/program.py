@@ -72,6 +72,27 @@ KSPLIT_BELOW = int(os.environ.get('CSM_KSPLIT_BELOW', '512'))
 KSPLIT_TARGET = int(os.environ.get('CSM_KSPLIT_TARGET', '768'))
 
 
+def pack_stem_weights(w):
+    """stem convs (cin padded to 4, groups 1): K is packed as (tap, channel) -- 8 taps x 4 channels per 32-wide chunk instead of
+    one chunk per tap with 4 of 32 channels used.  w [cout, 4, kh, kw] -> packed [chunk][npad][32]; within each 8-block the positions
+    hold (tap 2j: c0, c2 | tap 2j+1: c0, c2 | tap 2j: c1, c3 | tap 2j+1: c1, c3), so that the MFMA lane order 0,4,1,5,2,6,3,7
+    multiplies tap 2j's channels 0..3, then tap 2j+1's: the contract's chain (taps row-major, channels ascending)."""
+    cout, cin, kh, kw = w.shape
+    assert cin == 4
+    ntaps = kh * kw
+    nck, npad = (ntaps + 7) // 8, (cout + 31) // 32 * 32
+    wt = w.reshape(cout, 4, ntaps)
+    packed = np.zeros((nck, npad, 32), np.float32)
+    pos = ((0, 0), (0, 2), (1, 0), (1, 2), (0, 1), (0, 3), (1, 1), (1, 3))        # position in the 8-block -> (tap parity, channel)
+    for c in range(nck):
+        for jb in range(4):
+            for r, (s_, ch) in enumerate(pos):
+                tap = 8 * c + 2 * jb + s_
+                if tap < ntaps:
+                    packed[c, :cout, 8 * jb + r] = wt[:, ch, tap]
+    return packed.reshape(-1)
+
+
 class Buf:
     def __init__(self, n, h, w, c, ext=-1, nchw=False):
         self.n, self.h, self.w, self.c, self.ext, self.nchw = n, h, w, c, ext, nchw
@@ -176,7 +197,11 @@ class Program:
         if out is None:
             out = self.buffer(x.n, ho, wo, cout)
         assert out.shape == (x.n, ho, wo, cout), (out.shape, (x.n, ho, wo, cout))
-        packed, sg, cin_sg, cout_sg = pack_conv_weights(w, groups)
+        stem = groups == 1 and cin_g == 4 and cout > 4        # k_conv_stem: (tap, channel)-packed K, csm_op.flags bit 1
+        if stem:
+            packed, sg, cin_sg, cout_sg = pack_stem_weights(w), 1, 4, cout
+        else:
+            packed, sg, cin_sg, cout_sg = pack_conv_weights(w, groups)
         w_h, w_n = self._w(packed, w)
         b_h = b_n = a_h = a_n = -1
         if b is not None:
@@ -185,12 +210,12 @@ class Program:
             a_h, a_n = self._w(slope, slope)
         self.flops += 2 * x.n * ho * wo * cout * cin_g * kh * kw
         self.conv_bytes += 4 * (x.n * x.h * x.w * x.c + x.n * ho * wo * cout + w.size)
-        ksplit, scr = self.choose_ksplit(x.n * ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups), None
+        ksplit, scr = (1 if stem else self.choose_ksplit(x.n * ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups)), None
         if ksplit > 1:
             scr = self.buffer(x.n, ho, wo, ksplit * cout)
         return self._emit(OP_CONV, x, res, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, groups=sg, cin_g=cin_sg,
                           cout_g=cout_sg, act=ACT[act], res_mode=res_mode if res is not None else 0, w_off=w_h, b_off=b_h,
-                          aux_off=a_h, ksplit=ksplit, scratch=-1 if scr is None else scr.id, scratch_view=scr,
+                          aux_off=a_h, ksplit=ksplit, scratch=-1 if scr is None else scr.id, scratch_view=scr, flags=2 if stem else 0,
                           nat=dict(groups=groups, cin_g=cin_g, cout_g=cout // groups, w_off=w_n, b_off=b_n, aux_off=a_n))
 
     split_k = True

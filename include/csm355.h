@@ -151,7 +151,8 @@ typedef struct csm_op {
     int32_t cin_g, cout_g;
     int32_t act, res_mode;   /* res_mode: 0 none, 1 add before act, 2 add after act */
     int64_t w_off, b_off, aux_off;   /* float offsets into the weight buffer (aux = PReLU slopes); -1 = none */
-    int32_t flags;
+    int32_t flags;           /* BILINEAR: bit 0 = align_corners.  CONV: bit 1 = stem (cin padded to 4): weights are packed with K =
+                                (tap, channel), 8 taps x 4 channels per 32-wide chunk, for k_conv_stem; the chain is unchanged */
     int32_t ksplit;          /* CONV: K is cut into `ksplit` runs of (32-channel block, tap) chunks (block-major), run s = chunks
                                 [s*T/ksplit, (s+1)*T/ksplit); each run is its own fmaf chain (run 0 starts at the bias,
                                 the others at 0) and the runs are added in order ((p0+p1)+p2)...  1 = single chain */
