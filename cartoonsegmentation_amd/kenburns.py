@@ -133,6 +133,11 @@ def colorize_depth(depth, inverse=False, rgb2bgr=False, cmap='magma_r'):
     return col[..., ::-1].copy() if rgb2bgr else col
 
 
+def _mm_scratch(t):
+    """512 floats of block partials for csm_minmax"""
+    return torch.empty(512, dtype=torch.float32, device=t.device)
+
+
 def _fill_zero_with_min_positive(depth):
     """`depth[depth == 0] = depth[depth > 0].min()` (leres/__init__.py:143-145 semantics: skipped when nothing is positive),
     in place on the device, no host sync"""
@@ -363,7 +368,7 @@ class KenBurnsPipeline:
         for bi in range(nb):
             yb = y[bi]
             mnmx = torch.empty(2, dtype=torch.float32, device=self.device)
-            check(L.csm_minmax(ptr(yb), i64(h * w), ptr(mnmx), stream_ptr()), "minmax")
+            check(L.csm_minmax(ptr(yb), i64(h * w), ptr(mnmx), ptr(_mm_scratch(yb)), stream_ptr()), "minmax")
             q = torch.empty((h, w), dtype=torch.uint8, device=self.device)
             check(L.csm_leres_quantize(ptr(yb), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
             depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
@@ -384,7 +389,7 @@ class KenBurnsPipeline:
         y = torch.empty((1, 1, h, w), dtype=torch.float32, device=self.device)
         self._leres_prog(h, w).run(x, y)
         mnmx = torch.empty(2, dtype=torch.float32, device=self.device)
-        check(L.csm_minmax(ptr(y), i64(h * w), ptr(mnmx), stream_ptr()), "minmax")
+        check(L.csm_minmax(ptr(y), i64(h * w), ptr(mnmx), ptr(_mm_scratch(y)), stream_ptr()), "minmax")
         q = torch.empty((h, w), dtype=torch.uint8, device=self.device)
         check(L.csm_leres_quantize(ptr(y), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
         depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
@@ -513,7 +518,7 @@ class KenBurnsPipeline:
         H, W = int(raw.shape[2]), int(raw.shape[3])
         mm = torch.empty(2, dtype=torch.float32, device=dev)
         nmax = torch.empty(1, dtype=torch.float32, device=dev)
-        check(L.csm_minmax(ptr(raw), i64(raw.numel()), ptr(mm), stream_ptr()), "minmax")
+        check(L.csm_minmax(ptr(raw), i64(raw.numel()), ptr(mm), ptr(_mm_scratch(raw)), stream_ptr()), "minmax")
         disparity = torch.empty_like(raw)
         check(L.csm_normalise_disparity(ptr(raw), i64(raw.numel()), ptr(mm), f32(self.cfg.baseline), ptr(disparity), ptr(nmax),
                                         stream_ptr()), "normalise")

@@ -235,14 +235,14 @@ int csm_leres_input(const uint8_t *img_hwc, int H, int W, int h, int w, float *o
  * min_max_dev: DEVICE pointer to {min, max} of depth. */
 int csm_leres_quantize(const float *depth, int64_t n, const float *min_max_dev, uint8_t *out, void *stream);
 /* Small device-side reductions of the per-frame depth glue (no host sync; min / max are order-free, so results equal torch's).
- * csm_minmax: out2 = {min, max} of x[0..n).
+ * csm_minmax: out2 = {min, max} of x[0..n) (x 16-byte aligned); scratch512 = 512 device floats (block partials).
  * csm_fill_zero_min_positive: leres/__init__.py:143-145 `depth[depth == 0] = depth[depth > 0].min()` in place (unchanged when
  *   there is no zero or no positive value); scratch2 = 2 uint32.
  * csm_normalise_disparity: out = (x / minmax[1]) * scale   (kenburns_effect.py:928: disparity / disparity.max() * baseline);
  *   norm_max_out (1 device float, may be NULL) receives max(out).
  * csm_depth_range_stats: out6 (float64, device) = {min, max of the NORMALISED disparity (from the raw {min,max} and scale),
  *   cv2.minMaxLoc(depth[y0:y0+crop_h, x0:x0+crop_w]) = min, max, first row-major argmin, argmax}; scratch2 = 2 uint64. */
-int csm_minmax(const float *x, int64_t n, float *out2, void *stream);
+int csm_minmax(const float *x, int64_t n, float *out2, float *scratch512, void *stream);
 int csm_fill_zero_min_positive(float *x, int64_t n, unsigned *scratch2, void *stream);
 int csm_normalise_disparity(const float *x, int64_t n, const float *minmax_dev, float scale, float *out, float *norm_max_out,
                             void *stream);

@@ -225,12 +225,13 @@ def test_depth_glue_ops_vs_numpy():
     from cartoonsegmentation_amd._lib import check, f32, i32, i64, ptr, stream_ptr
     from oracle import kenburns as okb
     L = _lib.load()
+    _mm_scratch = lambda t: torch.empty(512, dtype=torch.float32, device=t.device)
     rng = np.random.default_rng(5)
     H, W = 300, 333
     # -- min/max
     x = rng.normal(0, 3, (H, W)).astype(np.float32)
     xd = torch.from_numpy(x).cuda(); mm = torch.empty(2, device='cuda')
-    check(L.csm_minmax(ptr(xd), i64(x.size), ptr(mm), stream_ptr()))
+    check(L.csm_minmax(ptr(xd), i64(x.size), ptr(mm), ptr(_mm_scratch(xd)), stream_ptr()))
     assert mm.cpu().numpy().tolist() == [float(x.min()), float(x.max())]
     # -- zero fill: zeros + positives, no zeros, nothing positive
     for case in ("zeros", "nozero", "nopos"):
@@ -266,7 +267,7 @@ def test_depth_glue_ops_vs_numpy():
     base = np.float32(40.0)
     norm = (raw / raw.max() * base).astype(np.float32)
     rd = torch.from_numpy(raw).cuda(); mm = torch.empty(2, device='cuda'); nd = torch.empty_like(rd); nmax = torch.empty(1, device='cuda')
-    check(L.csm_minmax(ptr(rd), i64(raw.size), ptr(mm), stream_ptr()))
+    check(L.csm_minmax(ptr(rd), i64(raw.size), ptr(mm), ptr(_mm_scratch(rd)), stream_ptr()))
     check(L.csm_normalise_disparity(ptr(rd), i64(raw.size), ptr(mm), f32(float(base)), ptr(nd), ptr(nmax), stream_ptr()))
     assert np.array_equal(nd.cpu().numpy(), norm) and float(nmax.item()) == float(norm.max())
     depth = ((np.float32(1.0) / (norm + np.float32(1e-5))) * np.float32(100.0)).astype(np.float32)
