@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--workload", default="auto", help="auto | warp | frame")
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (frame workload)")
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step (frame workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -159,7 +159,7 @@ class FrameWorkload(Workload):
     name = "seg+depth+warp"
     INSTANCES = 2
 
-    def __init__(self, size, rank, device, batch=8):
+    def __init__(self, size, rank, device, batch=16):
         self.frames_per_step = batch
         os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"          # no checkpoints exist offline: closed-form weights
         # every rank builds the same closed-form weights (a rank with placeholder zeros finds no instance, builds no ISNet and
@@ -280,7 +280,7 @@ class FrameWorkload(Workload):
         return oframe.cpu_baseline(seconds)
 
 
-def make_workload(kind, size, rank, device, world, dist, batch=8):
+def make_workload(kind, size, rank, device, world, dist, batch=16):
     if kind in ("auto", "frame"):
         wl = FrameWorkload(size, rank, device, batch)
     elif kind == "warp":
