@@ -202,34 +202,41 @@ __device__ __forceinline__ void cv_src(int d, int in_size, double scale, int &i0
 // prepare_refine_batch (animeinsseg/__init__.py:37-55): img u8 HWC [H,W,3] -> resize_pad to T (keep ratio, pad
 // bottom/right with 0) -> /255 -> channels 0..2 ; mask u8 [n,H,W] -> float -> resize (float bilinear) -> channel 3.
 // out: [n,4,T,T] NCHW fp32.  rh, rw = resized size (<= T).  uint8 path = cv2's 11-bit fixed point.
+// The mask plane has its OWN size (Hm,Wm) and resized extent (rhm,rwm): mmdet's `[..., :ori_h, :ori_w]` slice can leave the
+// detector masks 1-2 px smaller than the image, and the reference resize_pad()s each seg by its own shape.
 __global__ __launch_bounds__(256) void k_refine_batch(const uint8_t *__restrict__ img, const uint8_t *__restrict__ masks,
-                                                       int H, int W, int rh, int rw, int T, float *__restrict__ out) {
+                                                       int H, int W, int rh, int rw, int Hm, int Wm, int rhm, int rwm, int T,
+                                                       float *__restrict__ out) {
     const int inst = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
     if (x >= T) return;
     float *O = out + (int64_t)inst * 4 * T * T + (int64_t)y * T + x;
     const int64_t plane = (int64_t)T * T;
-    if (y >= rh || x >= rw) { O[0] = 0.0f; O[plane] = 0.0f; O[2 * plane] = 0.0f; O[3 * plane] = 0.0f; return; }
-    const uint8_t *M = masks + (int64_t)inst * H * W;
-    if (rh == H && rw == W) {
+    if (y >= rh || x >= rw) { O[0] = 0.0f; O[plane] = 0.0f; O[2 * plane] = 0.0f; }
+    else if (rh == H && rw == W) {
         for (int c = 0; c < 3; ++c) O[c * plane] = (float)img[((int64_t)y * W + x) * 3 + c] / 255.0f;
-        O[3 * plane] = (float)M[(int64_t)y * W + x];
-        return;
+    } else {
+        double sy = (double)H / rh, sx = (double)W / rw;
+        int y0, y1, x0, x1; float fy, fx;
+        cv_src(y, H, sy, y0, y1, fy); cv_src(x, W, sx, x0, x1, fx);
+        // 8-bit: coefficients in Q11, horizontal pass to int, vertical pass with the >>4 / >>16 / +2 >>2 rounding
+        const int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
+        const int b0 = (int)rintf((1.0f - fy) * 2048.0f), b1 = (int)rintf(fy * 2048.0f);
+        for (int c = 0; c < 3; ++c) {
+            int r0 = img[((int64_t)y0 * W + x0) * 3 + c] * a0 + img[((int64_t)y0 * W + x1) * 3 + c] * a1;
+            int r1 = img[((int64_t)y1 * W + x0) * 3 + c] * a0 + img[((int64_t)y1 * W + x1) * 3 + c] * a1;
+            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            O[c * plane] = (float)v / 255.0f;
+        }
     }
-    double sy = (double)H / rh, sx = (double)W / rw;
-    int y0, y1, x0, x1; float fy, fx;
-    cv_src(y, H, sy, y0, y1, fy); cv_src(x, W, sx, x0, x1, fx);
-    // 8-bit: coefficients in Q11, horizontal pass to int, vertical pass with the >>4 / >>16 / +2 >>2 rounding
-    const int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
-    const int b0 = (int)rintf((1.0f - fy) * 2048.0f), b1 = (int)rintf(fy * 2048.0f);
-    for (int c = 0; c < 3; ++c) {
-        int r0 = img[((int64_t)y0 * W + x0) * 3 + c] * a0 + img[((int64_t)y0 * W + x1) * 3 + c] * a1;
-        int r1 = img[((int64_t)y1 * W + x0) * 3 + c] * a0 + img[((int64_t)y1 * W + x1) * 3 + c] * a1;
-        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        O[c * plane] = (float)v / 255.0f;
-    }
+    const uint8_t *M = masks + (int64_t)inst * Hm * Wm;
+    if (y >= rhm || x >= rwm) { O[3 * plane] = 0.0f; return; }
+    if (rhm == Hm && rwm == Wm) { O[3 * plane] = (float)M[(int64_t)y * Wm + x]; return; }
     // float32 path: plain fp32 bilinear
-    float m00 = M[(int64_t)y0 * W + x0], m01 = M[(int64_t)y0 * W + x1], m10 = M[(int64_t)y1 * W + x0], m11 = M[(int64_t)y1 * W + x1];
+    double sy = (double)Hm / rhm, sx = (double)Wm / rwm;
+    int y0, y1, x0, x1; float fy, fx;
+    cv_src(y, Hm, sy, y0, y1, fy); cv_src(x, Wm, sx, x0, x1, fx);
+    float m00 = M[(int64_t)y0 * Wm + x0], m01 = M[(int64_t)y0 * Wm + x1], m10 = M[(int64_t)y1 * Wm + x0], m11 = M[(int64_t)y1 * Wm + x1];
     float r0 = m00 * (1.0f - fx) + m01 * fx, r1 = m10 * (1.0f - fx) + m11 * fx;
     O[3 * plane] = r0 * (1.0f - fy) + r1 * fy;
 }
@@ -295,6 +302,8 @@ extern "C" int csm_maskhead_logits(const float *mask_feat, int ld, int h, int w,
 
 extern "C" int csm_mask_resize_threshold(const float *logits, int n, int h, int w, int up, int rh, int rw, int oh, int ow,
                                          float thr, uint8_t *masks, void *stream) {
+    // oh/ow = min(resized, original): mmdet's `[..., :ori_h, :ori_w]` is a slice, so when ceil(S/scale) lands 1-2 px below the
+    // original size the mask is simply that much smaller (the caller clips; ISNet refine resizes it back)
     CSM_REQUIRE(masks && n >= 0 && h > 0 && w > 0 && up > 0 && rh >= oh && rw >= ow && oh > 0 && ow > 0);
     if (n == 0) return CSM_OK;
     CSM_REQUIRE(logits);
@@ -304,9 +313,11 @@ extern "C" int csm_mask_resize_threshold(const float *logits, int n, int h, int 
 }
 
 extern "C" int csm_refine_prepare_batch(const uint8_t *img_hwc, const uint8_t *masks, int n, int H, int W, int rh, int rw,
-                                        int T, float *batch, void *stream) {
+                                        int Hm, int Wm, int rhm, int rwm, int T, float *batch, void *stream) {
     CSM_REQUIRE(img_hwc && masks && batch && n > 0 && H > 0 && W > 0 && rh <= T && rw <= T);
-    k_refine_batch<<<dim3(csm::cdiv(T, 256), T, n), 256, 0, (hipStream_t)stream>>>(img_hwc, masks, H, W, rh, rw, T, batch);
+    CSM_REQUIRE(Hm > 0 && Wm > 0 && rhm > 0 && rwm > 0 && rhm <= T && rwm <= T && rh > 0 && rw > 0);
+    k_refine_batch<<<dim3(csm::cdiv(T, 256), T, n), 256, 0, (hipStream_t)stream>>>(img_hwc, masks, H, W, rh, rw, Hm, Wm, rhm,
+                                                                                     rwm, T, batch);
     return csm::check_launch("k_refine_batch");
 }
 

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -1432,6 +1433,24 @@ extern "C" int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_de
     return run_ops(ops, n_ops, tensors, n_tensors, weights, workspace, ext, n_ext, (hipStream_t)stream, nullptr);
 }
 
+// HIP events released on every exit path (the CSM_HIP early returns inside the timing loops used to leak them)
+struct EventSet {
+    std::vector<hipEvent_t> ev;
+    bool ok = true;
+    explicit EventSet(size_t n) {
+        ev.reserve(n);
+        for (size_t i = 0; i < n; ++i) {
+            hipEvent_t e;
+            hipError_t r = hipEventCreate(&e);
+            if (r != hipSuccess) { csm::set_error("hipEventCreate: %s", hipGetErrorString(r)); ok = false; return; }
+            ev.push_back(e);
+        }
+    }
+    ~EventSet() { for (auto e : ev) (void)hipEventDestroy(e); }
+    EventSet(const EventSet &) = delete;
+    EventSet &operator=(const EventSet &) = delete;
+};
+
 // Same as csm_run_program, but brackets every op with HIP events on `stream`, synchronises the stream and returns
 // the per-op durations (ms) in op_ms[n_ops].  Measurement aid for bench.py's roofline (not graph-capturable).
 extern "C" int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
@@ -1439,19 +1458,21 @@ extern "C" int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_t
                                        float *op_ms) {
     CSM_REQUIRE(ops && tensors && op_ms && n_ops >= 0 && n_tensors > 0);
     hipStream_t st = (hipStream_t)stream;
-    std::vector<hipEvent_t> ev(n_ops + 1);
-    for (auto &e : ev) CSM_HIP(hipEventCreate(&e));
-    int rc = run_ops(ops, n_ops, tensors, n_tensors, weights, workspace, ext, n_ext, st, ev.data());
+    EventSet evs(n_ops + 1);
+    if (!evs.ok) return CSM_ERR_HIP;
+    int rc = run_ops(ops, n_ops, tensors, n_tensors, weights, workspace, ext, n_ext, st, evs.ev.data());
     if (rc == CSM_OK) {
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) { csm::set_error("profile sync: %s", hipGetErrorString(e)); rc = CSM_ERR_HIP; }
-        else for (int i = 0; i < n_ops; ++i) (void)hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]);
+        else for (int i = 0; i < n_ops; ++i) (void)hipEventElapsedTime(&op_ms[i], evs.ev[i], evs.ev[i + 1]);
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 
+// layer signature -> tuned tile; process-global, shared by every program and (through the mutex) by host threads that drive
+// different GPUs / streams
 static std::map<std::array<int, 16>, int> g_tile_cache;
+static std::mutex g_tile_mutex;
 
 extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors, const float *weights,
                                  float *workspace, void *const *ext, int n_ext, void *stream, int reps) {
@@ -1460,8 +1481,9 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
     if (g_force_cfg >= 0) return 0;
     if (reps < 1) reps = 3;
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t ev[2];
-    CSM_HIP(hipEventCreate(&ev[0])); CSM_HIP(hipEventCreate(&ev[1]));
+    EventSet evs(2);
+    if (!evs.ok) return -CSM_ERR_HIP;
+    hipEvent_t *ev = evs.ev.data();
     int tuned = 0, rc = CSM_OK;
     for (int i = 0; i < n_ops && rc == CSM_OK; ++i) {
         csm_op &op = ops[i];
@@ -1479,8 +1501,11 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         rc = make_view(tensors, n_tensors, op.out, workspace, ext, n_ext, vout); if (rc) break;
         const std::array<int, 16> key = {vin.n, vin.h, vin.w, vin.ld, vout.h, vout.w, vout.ld, op.kh, op.kw, op.stride, op.dil,
                                          op.groups, op.cin_g, op.cout_g, op.ksplit, op.pad};
-        auto hit = g_tile_cache.find(key);
-        if (hit != g_tile_cache.end()) { op.tile = hit->second; ++tuned; continue; }
+        {
+            std::lock_guard<std::mutex> lk(g_tile_mutex);
+            auto hit = g_tile_cache.find(key);
+            if (hit != g_tile_cache.end()) { op.tile = hit->second; ++tuned; continue; }
+        }
         float best = 1e30f; int best_cfg = -1;
         for (size_t c = 0; c < sizeof(cand_all) / sizeof(int); ++c) {
             if (cand_bn[c] >= 2 * npad && cand_bn[c] > 32) continue;      // tile much wider than the output: never wins
@@ -1491,11 +1516,12 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
             op.tile = cand_all[c] + 1;
             float tmin = 1e30f;
             for (int r = 0; r <= reps; ++r) {                              // r == 0 warms up (and sets the LDS attribute)
-                CSM_HIP(hipEventRecord(ev[0], st));
-                rc = run_ops(&op, 1, tensors, n_tensors, weights, workspace, ext, n_ext, st, nullptr);
+                hipError_t he = hipEventRecord(ev[0], st);
+                if (he == hipSuccess) rc = run_ops(&op, 1, tensors, n_tensors, weights, workspace, ext, n_ext, st, nullptr);
                 if (rc) break;
-                CSM_HIP(hipEventRecord(ev[1], st));
-                CSM_HIP(hipEventSynchronize(ev[1]));
+                if (he == hipSuccess) he = hipEventRecord(ev[1], st);
+                if (he == hipSuccess) he = hipEventSynchronize(ev[1]);
+                if (he != hipSuccess) { csm::set_error("conv_autotune timing: %s", hipGetErrorString(he)); rc = CSM_ERR_HIP; break; }
                 float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
                 if (r > 0 && ms < tmin) tmin = ms;
             }
@@ -1503,10 +1529,9 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
             if (tmin < best) { best = tmin; best_cfg = cand_all[c]; }
         }
         op.tile = best_cfg >= 0 ? best_cfg + 1 : 0;
-        g_tile_cache[key] = op.tile;
+        { std::lock_guard<std::mutex> lk(g_tile_mutex); g_tile_cache[key] = op.tile; }
         ++tuned;
     }
-    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
     return rc == CSM_OK ? tuned : -rc;
 }
 
@@ -1516,6 +1541,7 @@ extern "C" int csm_conv_tile_cache_save(const char *path) {
     CSM_REQUIRE(path);
     FILE *f = fopen(path, "w");
     if (!f) { csm::set_error("cannot write %s", path); return CSM_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(g_tile_mutex);
     for (const auto &kv : g_tile_cache) {
         for (int v : kv.first) fprintf(f, "%d ", v);
         fprintf(f, "%d\n", kv.second);
@@ -1533,7 +1559,7 @@ extern "C" int csm_conv_tile_cache_load(const char *path) {
         std::array<int, 16> key; int tile = 0; bool ok = true;
         for (int &v : key) ok = ok && fscanf(f, "%d", &v) == 1;
         if (!ok || fscanf(f, "%d", &tile) != 1) break;
-        if (tile >= 0 && tile <= CFG_COUNT) { g_tile_cache[key] = tile; ++n; }
+        if (tile >= 0 && tile <= CFG_COUNT) { std::lock_guard<std::mutex> lk(g_tile_mutex); g_tile_cache[key] = tile; ++n; }
     }
     fclose(f);
     return n;

@@ -15,6 +15,8 @@ Parameter names follow mmdet's state_dict so a real rtmdetl_e60.ckpt imports unc
 from dataclasses import dataclass, field
 from typing import Tuple
 
+import numpy as np
+
 from ..program import Program
 from ..weights import conv_bn, conv_plain
 
@@ -32,7 +34,13 @@ class RTMDetConfig:
     num_dyconvs: int = 3
     strides: Tuple[int, ...] = (8, 16, 32)
     share_conv: bool = True
+    # BatchNorm eps per sub-module: the rtmdet configs pass norm_cfg=dict(type='SyncBN') to backbone / neck / head, i.e. torch's
+    # 1e-5; a cfg that leaves norm_cfg out gets the class defaults of CSPNeXt / CSPNeXtPAFPN (eps=1e-3) -- config_from_ckpt_cfg
+    # reads them from the checkpoint's cfg text
     bn_eps: float = 1e-5
+    bn_eps_backbone: float = None
+    bn_eps_neck: float = None
+    bn_eps_head: float = None
     # DetDataPreprocessor (BGR kept: bgr_to_rgb=False)
     mean: Tuple[float, ...] = (103.53, 116.28, 123.675)
     std: Tuple[float, ...] = (57.375, 57.12, 58.395)
@@ -57,9 +65,18 @@ class _B:
     def __init__(self, p, ws, cfg):
         self.p, self.ws, self.cfg = p, ws, cfg
 
-    def cm(self, name, x, cout, k, stride=1, act='silu', out=None, res=None, res_mode=0, wname=None):
+    def eps(self, name):
+        c = self.cfg
+        v = c.bn_eps_backbone if name.startswith('backbone.') else (c.bn_eps_neck if name.startswith('neck.') else c.bn_eps_head)
+        return c.bn_eps if v is None else v
+
+    def cm_params(self, name, cin, cout, k, wname=None, bnname=None):
+        """folded (w, b) of an mmcv ConvModule conv(bias=False) + BN; wname / bnname: parameter-name aliases (shared modules)"""
+        return conv_bn(_Alias(self.ws, name, wname, bnname), name + '.conv', name + '.bn', cout, cin, k, eps=self.eps(name))
+
+    def cm(self, name, x, cout, k, stride=1, act='silu', out=None, res=None, res_mode=0, wname=None, bnname=None, params=None):
         """mmcv ConvModule: conv(bias=False) + BN + act"""
-        w, b = conv_bn(_Alias(self.ws, name, wname), name + '.conv', name + '.bn', cout, x.c, k, eps=self.cfg.bn_eps)
+        w, b = params if params is not None else self.cm_params(name, x.c, cout, k, wname, bnname)
         return self.p.conv(x, w, b, stride=stride, pad=k // 2, act=act, out=out, res=res, res_mode=res_mode)
 
     def dwcm(self, name, x, k, act='silu'):
@@ -68,7 +85,7 @@ class _B:
         w = ws.get(name + '.conv.weight', (c, 1, k, k), 'conv_w')
         g = ws.get(name + '.bn.weight', (c,), 'bn_gamma'); be = ws.get(name + '.bn.bias', (c,), 'bn_beta')
         m = ws.get(name + '.bn.running_mean', (c,), 'bn_mean'); v = ws.get(name + '.bn.running_var', (c,), 'bn_var')
-        wf, bf = fold_bn(w, None, g, be, m, v, self.cfg.bn_eps)
+        wf, bf = fold_bn(w, None, g, be, m, v, self.eps(name))
         return self.p.dwconv(x, wf, bf, pad=k // 2, act=act)
 
     def cspnext_block(self, name, x, add_identity, out=None):
@@ -99,13 +116,15 @@ class _B:
 
 
 class _Alias:
-    """share_conv: conv weights of level n alias level 0; BN stays per level"""
-    def __init__(self, ws, name, wname):
-        self.ws, self.name, self.wname = ws, name, wname
+    """parameter-name aliases of shared modules: conv weights under `wname`, BN parameters under `bnname`"""
+    def __init__(self, ws, name, wname, bnname=None):
+        self.ws, self.name, self.wname, self.bnname = ws, name, wname, bnname
 
     def get(self, n, shape, kind):
         if self.wname is not None and kind == 'conv_w':
             n = self.wname + n[len(self.name):]
+        elif self.bnname is not None and kind.startswith('bn_'):
+            n = self.bnname + n[len(self.name):]
         return self.ws.get(n, shape, kind)
 
 
@@ -178,17 +197,45 @@ def build_rtmdet(ws, n, h, w, cfg=None):
         m = B.cm('%smask_head.stacked_convs.%d' % (H, i), m, oc, 3)
     wpj, bpj = conv_plain(ws, H + 'mask_head.projection', cfg.num_prototypes, oc, 1)
     mask_feat = p.keep(p.conv(m, wpj, bpj))
+    # RTMDetInsSepBNHead._init_layers (mmdet 3.x), as the published parameter counts of all five model sizes pin it down
+    # (tools/rtmdet_params.py: tiny 5.6 / s 10.18 / m 27.58 / l 57.37 / x 102.7 M are reproduced exactly by this rule and by no
+    # simpler one):
+    #   * `self.reg_convs.append(cls_convs)`: the reg tower IS the cls tower (the same ConvModule objects, so the state_dict
+    #     holds bbox_head.reg_convs.* as aliases of bbox_head.cls_convs.*);
+    #   * share_conv ties only cls_convs[n][i].conv (= reg_convs) to level 0; kernel_convs stay per level.
+    # A state_dict is always read by its per-level names (aliases included), so either structure imports correctly; the
+    # closed-form weights follow the rule above through name aliases.  When the reg tower's folded parameters equal the cls
+    # tower's (always, under the rule) its convolutions are the same computation on the same input and are issued once.
+    synth = not hasattr(ws, 'sd')
     cls, reg, kern = [], [], []
     for lvl, f in enumerate((P3, P4, P5)):
-        def tower(kind, head, cout, act=None):
-            t_ = f
+        def tower_params(kind):
+            out = []
             for i in range(cfg.stacked_convs):
-                nm = '%s%s.%d.%d' % (H, kind, lvl, i)
-                t_ = B.cm(nm, t_, oc, 3, wname=('%s%s.0.%d' % (H, kind, i)) if cfg.share_conv else None)
-            wh, bh = conv_plain(ws, '%s%s.%d' % (H, head, lvl), cout, oc, 1)
+                nm, wname, bnname = '%s%s.%d.%d' % (H, kind, lvl, i), None, None
+                if synth:
+                    if kind == 'reg_convs':
+                        wname, bnname = '%scls_convs.%d.%d' % (H, 0 if cfg.share_conv else lvl, i), '%scls_convs.%d.%d' % (H, lvl, i)
+                    elif kind == 'cls_convs' and cfg.share_conv:
+                        wname = '%scls_convs.0.%d' % (H, i)
+                out.append(B.cm_params(nm, oc, oc, 3, wname, bnname))
+            return out
+
+        def run_tower(kind, params):
+            t_ = f
+            for i, wb in enumerate(params):
+                t_ = B.cm('%s%s.%d.%d' % (H, kind, lvl, i), t_, oc, 3, params=wb)
+            return t_
+
+        def head(t_, name, cout, act=None):
+            wh, bh = conv_plain(ws, '%s%s.%d' % (H, name, lvl), cout, oc, 1)
             return p.keep(p.conv(t_, wh, bh, act=act))
-        cls.append(tower('cls_convs', 'rtm_cls', cfg.num_classes, act='sigmoid'))   # cls_score.sigmoid() fused
-        kern.append(tower('kernel_convs', 'rtm_kernel', cfg.num_gen_params))
-        reg.append(tower('reg_convs', 'rtm_reg', 4, act='relu'))          # F.relu(rtm_reg(.)) * stride  (x stride in decode)
+        pc, pr = tower_params('cls_convs'), tower_params('reg_convs')
+        cls_feat = run_tower('cls_convs', pc)
+        cls.append(head(cls_feat, 'rtm_cls', cfg.num_classes, act='sigmoid'))        # cls_score.sigmoid() fused
+        kern.append(head(run_tower('kernel_convs', tower_params('kernel_convs')), 'rtm_kernel', cfg.num_gen_params))
+        same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(pc, pr))
+        reg_feat = cls_feat if same else run_tower('reg_convs', pr)
+        reg.append(head(reg_feat, 'rtm_reg', 4, act='relu'))              # F.relu(rtm_reg(.)) * stride  (x stride in decode)
     p.plan()
     return RTMDetProgram(p, cfg, n, h, w, (cls, reg, kern, mask_feat)), cfg

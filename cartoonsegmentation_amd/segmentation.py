@@ -62,9 +62,22 @@ def config_from_ckpt_cfg(cfg_text):
     c = RTMDetConfig()
     bb, head = m.get('backbone', {}), m.get('bbox_head', {})
     c.deepen_factor, c.widen_factor = bb.get('deepen_factor', 1.0), bb.get('widen_factor', 1.0)
+    c.expand_ratio = bb.get('expand_ratio', c.expand_ratio)
     c.num_classes = head.get('num_classes', 1)
     c.feat_channels = head.get('feat_channels', 256)
     c.stacked_convs = head.get('stacked_convs', 2)
+    c.share_conv = head.get('share_conv', True)
+    c.num_prototypes = head.get('num_prototypes', c.num_prototypes)
+    c.dyconv_channels = head.get('dyconv_channels', c.dyconv_channels)
+    c.num_dyconvs = head.get('num_dyconvs', c.num_dyconvs)
+    ag = head.get('anchor_generator', {})
+    c.strides = tuple(ag.get('strides', c.strides))
+    # BatchNorm eps: a norm_cfg without `eps` means torch's default 1e-5; no norm_cfg at all means the mmdet class default
+    # (CSPNeXt / CSPNeXtPAFPN: dict(type='BN', momentum=0.03, eps=0.001); RTMDetHead: dict(type='BN') -> 1e-5)
+    c.bn_eps_backbone = bb['norm_cfg'].get('eps', 1e-5) if 'norm_cfg' in bb else 1e-3
+    nk = m.get('neck', {})
+    c.bn_eps_neck = nk['norm_cfg'].get('eps', 1e-5) if 'norm_cfg' in nk else 1e-3
+    c.bn_eps_head = head['norm_cfg'].get('eps', 1e-5) if 'norm_cfg' in head else 1e-5
     dp = m.get('data_preprocessor', {})
     c.mean, c.std = tuple(dp.get('mean', c.mean)), tuple(dp.get('std', c.std))
     t = m.get('test_cfg', {})
@@ -97,6 +110,7 @@ class AnimeInsSeg:
         self._refine_programs, self._refine_weights, self._refine_ws = {}, None, None
         self.refine_method = None
         self.refine_batch = int(os.environ.get('CSM_REFINE_BATCH', '16'))   # instances per ISNet run when frames are batched
+        self.det_batch = max(1, int(os.environ.get('CSM_DET_BATCH', '16')))  # frames per detector run (longer lists are chunked)
         self.set_refine_method(**(refine_kwargs or {'refine_method': 'none'}))
 
     # ---- configuration (reference :395-399, :623-636, :704-708) --------------------------------
@@ -207,6 +221,18 @@ class AnimeInsSeg:
         imgs_d = [self._upload(im) for im in imgs]
         H, W = int(imgs_d[0].shape[0]), int(imgs_d[0].shape[1])
         assert all(tuple(t.shape) == (H, W, 3) for t in imgs_d), "detect_raw_batch needs equally sized images"
+        if len(imgs_d) > self.det_batch:
+            # bounded workspace and a bounded set of compiled programs: full chunks of det_batch frames plus one remainder
+            # program.  The prototype maps of earlier chunks are copied out (the next chunk overwrites the workspace).
+            outs = []
+            for c0 in range(0, len(imgs_d), self.det_batch):
+                part = self.detect_raw_batch(imgs_d[c0:c0 + self.det_batch])
+                if c0 + self.det_batch < len(imgs_d):
+                    for d in part:
+                        if d['n']:
+                            d['mask_feat'] = d['cp'].view(d['rp'].mask_feat)[d['bi']][..., :cfg.num_prototypes].clone()
+                outs += part
+            return outs
         nb = len(imgs_d)
         S = self.default_det_size
         rh, rw = rescale_size(H, W, (S, S))
@@ -286,20 +312,32 @@ class AnimeInsSeg:
         L, cfg = _lib.load(), self.cfg
         pri, ker = (d['priors'], d['kernels']) if sel is None else (d['priors'][sel].contiguous(), d['kernels'][sel].contiguous())
         n = int(pri.shape[0])
-        mf_view = d['rp'].mask_feat
-        b = mf_view.buf
-        h, w = mf_view.h, mf_view.w
-        mf = d['cp'].workspace[b.offset + d.get('bi', 0) * h * w * b.c:]
+        mf, ld, h, w = self._mask_feat_of(d)
         logits = torch.empty((n, h, w), dtype=torch.float32, device=self.device)
-        check(L.csm_maskhead_logits(ptr(mf), i32(b.c), i32(h), i32(w), i32(cfg.num_prototypes), i32(cfg.dyconv_channels),
+        check(L.csm_maskhead_logits(ptr(mf), i32(ld), i32(h), i32(w), i32(cfg.num_prototypes), i32(cfg.dyconv_channels),
                                     ptr(ker), ptr(pri), i32(n), i32(cfg.strides[0]), ptr(logits), stream_ptr()), "maskhead")
         up = cfg.strides[0]
         # mmdet quirk kept: scale_factor = [1/w_scale, 1/h_scale] is applied as (height, width)
         rh2 = math.ceil(h * up * (1 / d['w_scale'])); rw2 = math.ceil(w * up * (1 / d['h_scale']))
-        masks = torch.empty((n, d['H'], d['W']), dtype=torch.uint8, device=self.device)
-        check(L.csm_mask_resize_threshold(ptr(logits), i32(n), i32(h), i32(w), i32(up), i32(rh2), i32(rw2), i32(d['H']),
-                                          i32(d['W']), f32(cfg.mask_thr_binary), ptr(masks), stream_ptr()), "mask_resize")
+        # `[..., :ori_h, :ori_w]` is a slice: for ~20 % of image shapes ceil(S / scale) is 1-2 px short of the original size and
+        # mmdet returns masks that much smaller (the ISNet refine brings them back to (H, W); AnimeInstances.resize handles the rest)
+        oh, ow = min(rh2, d['H']), min(rw2, d['W'])
+        masks = torch.empty((n, oh, ow), dtype=torch.uint8, device=self.device)
+        check(L.csm_mask_resize_threshold(ptr(logits), i32(n), i32(h), i32(w), i32(up), i32(rh2), i32(rw2), i32(oh),
+                                          i32(ow), f32(cfg.mask_thr_binary), ptr(masks), stream_ptr()), "mask_resize")
         return masks
+
+    @staticmethod
+    def _mask_feat_of(d, mask_feat=None):
+        """(tensor, channel pitch, h, w) of the prototype map a detection dict refers to: an owned NHWC copy when one was taken
+        (infer_embeddings / chunked batches), else the live view inside the detector workspace (valid until the next run)"""
+        mf = mask_feat if mask_feat is not None else d.get('mask_feat')
+        if mf is not None:
+            mf = mf.contiguous()
+            return mf, int(mf.shape[2]), int(mf.shape[0]), int(mf.shape[1])
+        v = d['rp'].mask_feat
+        b = v.buf
+        return d['cp'].workspace[b.offset + d.get('bi', 0) * v.h * v.w * b.c:], b.c, v.h, v.w
 
     def _det_forward(self, img, pred_score_thr: float = 0.3) -> AnimeInstances:
         return self._instances_from(self.detect_raw(img), pred_score_thr)
@@ -334,7 +372,10 @@ class AnimeInsSeg:
             d.update(boxes=torch.zeros((0, 4), device=self.device), scores=torch.zeros(0, device=self.device),
                      priors=torch.zeros((0, 4), device=self.device), kernels=torch.zeros((0, self.cfg.num_gen_params), device=self.device))
         d['bboxes'] = d['boxes']
-        mask_feat = d['cp'].view(d['rp'].mask_feat)[d.get('bi', 0)]
+        # an OWNED copy (the reference returns an owned tensor, animeinsseg/__init__.py:339-360): the detector workspace is
+        # overwritten by the next infer()/detect_raw() of any image
+        mask_feat = d['cp'].view(d['rp'].mask_feat)[d.get('bi', 0)][..., :self.cfg.num_prototypes].clone()
+        d['mask_feat'] = mask_feat
         return img, d, mask_feat
 
     def segment_with_bboxes(self, img, bboxes, instance_data, mask_feat=None):
@@ -352,16 +393,14 @@ class AnimeInsSeg:
         idx = iou.argmax(1)
         H, W = d['H'], d['W']
         long_side = max(H, W)
-        mf = d['rp'].mask_feat
-        b = mf.buf
-        feat = d['cp'].workspace[b.offset + d.get('bi', 0) * mf.h * mf.w * b.c:]
+        feat, ld, fh, fw = self._mask_feat_of(d, mask_feat)          # the caller's tensor, as in the reference
         n = int(idx.numel())
-        logits = torch.empty((n, mf.h, mf.w), dtype=torch.float32, device=self.device)
-        check(L.csm_maskhead_logits(ptr(feat), i32(b.c), i32(mf.h), i32(mf.w), i32(cfg.num_prototypes), i32(cfg.dyconv_channels),
+        logits = torch.empty((n, fh, fw), dtype=torch.float32, device=self.device)
+        check(L.csm_maskhead_logits(ptr(feat), i32(ld), i32(fh), i32(fw), i32(cfg.num_prototypes), i32(cfg.dyconv_channels),
                                     ptr(d['kernels'][idx].contiguous()), ptr(d['priors'][idx].contiguous()), i32(n),
                                     i32(cfg.strides[0]), ptr(logits), stream_ptr()), "maskhead")
         masks = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
-        check(L.csm_mask_resize_threshold(ptr(logits), i32(n), i32(mf.h), i32(mf.w), i32(cfg.strides[0]), i32(long_side),
+        check(L.csm_mask_resize_threshold(ptr(logits), i32(n), i32(fh), i32(fw), i32(cfg.strides[0]), i32(long_side),
                                           i32(long_side), i32(H), i32(W), f32(0.5), ptr(masks), stream_ptr()), "mask_resize")
         bb = t[idx].to(torch.int32)
         bb[:, 2:] -= bb[:, :2]
@@ -386,6 +425,8 @@ class AnimeInsSeg:
         H, W = int(jobs[0][1].shape[0]), int(jobs[0][1].shape[1])
         T = refine_size
         rh, rw = scaledown_size(H, W, T)
+        Hm, Wm = int(jobs[0][2].shape[1]), int(jobs[0][2].shape[2])       # equal image sizes => equal detector mask sizes
+        rhm, rwm = scaledown_size(Hm, Wm, T)
         flat = [(j, k) for j, (_, _, segs) in enumerate(jobs) for k in range(segs.shape[0])]
         outs = [torch.empty((segs.shape[0], H, W), dtype=torch.uint8, device=self.device) for _, _, segs in jobs]
         max_batch = max_batch or self.refine_batch
@@ -396,7 +437,8 @@ class AnimeInsSeg:
             batch = torch.empty((b, 4, T, T), dtype=torch.float32, device=self.device)
             for i, (j, k) in enumerate(chunk):
                 check(L.csm_refine_prepare_batch(ptr(jobs[j][1]), ptr(jobs[j][2][k:k + 1]), i32(1), i32(H), i32(W), i32(rh), i32(rw),
-                                                 i32(T), ptr(batch[i:i + 1]), stream_ptr()), "refine_prepare")
+                                                 i32(Hm), i32(Wm), i32(rhm), i32(rwm), i32(T), ptr(batch[i:i + 1]), stream_ptr()),
+                      "refine_prepare")
             logits = torch.empty((b, 1, T, T), dtype=torch.float32, device=self.device)
             cp.run(batch, logits)
             for i, (j, k) in enumerate(chunk):
@@ -416,13 +458,15 @@ class AnimeInsSeg:
         segs = (torch.from_numpy(instances.masks) if was_numpy else instances.masks).to(self.device).to(torch.uint8).contiguous()
         n, T = int(segs.shape[0]), refine_size
         rh, rw = scaledown_size(H, W, T)
+        Hm, Wm = int(segs.shape[1]), int(segs.shape[2])
+        rhm, rwm = scaledown_size(Hm, Wm, T)                       # resize_pad(seg): the seg's own shape (reference :47)
         out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
         for k0 in range(0, n, max_refine_batch):
             b = min(max_refine_batch, n - k0)
             cp = self._refiner(b, T)
             batch = torch.empty((b, 4, T, T), dtype=torch.float32, device=self.device)
-            check(L.csm_refine_prepare_batch(ptr(img_d), ptr(segs[k0:k0 + b]), i32(b), i32(H), i32(W), i32(rh), i32(rw), i32(T),
-                                             ptr(batch), stream_ptr()), "refine_prepare")
+            check(L.csm_refine_prepare_batch(ptr(img_d), ptr(segs[k0:k0 + b]), i32(b), i32(H), i32(W), i32(rh), i32(rw), i32(Hm),
+                                             i32(Wm), i32(rhm), i32(rwm), i32(T), ptr(batch), stream_ptr()), "refine_prepare")
             logits = torch.empty((b, 1, T, T), dtype=torch.float32, device=self.device)
             cp.run(batch, logits)
             check(L.csm_refine_threshold(ptr(logits), i32(b), i32(T), i32(T), i32(rh), i32(rw), i32(H), i32(W),

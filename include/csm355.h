@@ -204,14 +204,17 @@ int csm_maskhead_logits(const float *mask_feat, int ld, int h, int w, int num_pr
 
 /* mmdet _bbox_mask_post_process tail (mirrored at animeinsseg/__init__.py:361-370), fused:
  * interpolate(scale_factor=up) -> interpolate(size=(rh,rw)) -> [..., :oh, :ow] -> sigmoid() > thr.
- * masks: uint8 [n,oh,ow] (0/1). */
+ * masks: uint8 [n,oh,ow] (0/1).  The slice cannot enlarge: the caller passes oh = min(rh, ori_h), ow = min(rw, ori_w)
+ * (mmdet's ceil(S / scale) lands 1-2 px under the original size for ~20 % of image shapes). */
 int csm_mask_resize_threshold(const float *logits, int n, int h, int w, int up, int rh, int rw, int oh, int ow,
                               float thr, uint8_t *masks, void *stream);
 
 /* prepare_refine_batch   animeinsseg/__init__.py:37-55 (+ utils/io_utils.py:254-292 resize_pad):
- * img u8 HWC [H,W,3], masks u8 [n,H,W] -> batch fp32 NCHW [n,4,T,T]; (rh,rw) = keep-ratio size inside T x T. */
-int csm_refine_prepare_batch(const uint8_t *img_hwc, const uint8_t *masks, int n, int H, int W, int rh, int rw, int T,
-                             float *batch, void *stream);
+ * img u8 HWC [H,W,3], masks u8 [n,Hm,Wm] -> batch fp32 NCHW [n,4,T,T]; (rh,rw) = keep-ratio size of the image inside T x T,
+ * (rhm,rwm) = the same rule applied to the mask's own shape (the reference resize_pad()s every seg by its own size; detector
+ * masks can be 1-2 px smaller than the image, see csm_mask_resize_threshold). */
+int csm_refine_prepare_batch(const uint8_t *img_hwc, const uint8_t *masks, int n, int H, int W, int rh, int rw, int Hm, int Wm,
+                             int rhm, int rwm, int T, float *batch, void *stream);
 
 /* _postprocess_refine tail   animeinsseg/__init__.py:653-662:
  * sigmoid -> crop [:crop_h,:crop_w] -> bilinear(align_corners=True) to (oh,ow) -> > thr ; masks u8 [n,oh,ow]. */

@@ -154,33 +154,38 @@ static void cv_src(int d, int in_size, double scale, int *i0, int *i1, float *f)
     *i0 = sx; *i1 = sx + 1 < in_size - 1 ? sx + 1 : in_size - 1; *f = fx;
 }
 
-void orc_refine_prepare_batch(const uint8_t *img, const uint8_t *masks, int n, int H, int W, int rh, int rw, int T, float *out)
+void orc_refine_prepare_batch(const uint8_t *img, const uint8_t *masks, int n, int H, int W, int rh, int rw, int Hm, int Wm,
+                              int rhm, int rwm, int T, float *out)
 {
+    /* image channels: resize_pad(img) ; mask channel: resize_pad(seg) with the seg's own shape (animeinsseg/__init__.py:39,47) */
     int64_t plane = (int64_t)T * T;
     double sy = (double)H / rh, sx = (double)W / rw;
+    double sym = (double)Hm / rhm, sxm = (double)Wm / rwm;
     for (int inst = 0; inst < n; ++inst)
         for (int y = 0; y < T; ++y)
             for (int x = 0; x < T; ++x) {
                 float *O = out + (int64_t)inst * 4 * plane + (int64_t)y * T + x;
-                const uint8_t *M = masks + (int64_t)inst * H * W;
-                if (y >= rh || x >= rw) { O[0] = O[plane] = O[2 * plane] = O[3 * plane] = 0.0f; continue; }
-                if (rh == H && rw == W) {
-                    for (int c = 0; c < 3; ++c) O[c * plane] = (float)img[((int64_t)y * W + x) * 3 + c] / 255.0f;
-                    O[3 * plane] = (float)M[(int64_t)y * W + x];
-                    continue;
-                }
+                const uint8_t *M = masks + (int64_t)inst * Hm * Wm;
                 int y0, y1, x0, x1; float fy, fx;
-                cv_src(y, H, sy, &y0, &y1, &fy); cv_src(x, W, sx, &x0, &x1, &fx);
-                int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
-                int b0 = (int)rintf((1.0f - fy) * 2048.0f), b1 = (int)rintf(fy * 2048.0f);
-                for (int c = 0; c < 3; ++c) {
-                    int r0 = img[((int64_t)y0 * W + x0) * 3 + c] * a0 + img[((int64_t)y0 * W + x1) * 3 + c] * a1;
-                    int r1 = img[((int64_t)y1 * W + x0) * 3 + c] * a0 + img[((int64_t)y1 * W + x1) * 3 + c] * a1;
-                    int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-                    O[c * plane] = (float)v / 255.0f;
+                if (y >= rh || x >= rw) { O[0] = O[plane] = O[2 * plane] = 0.0f; }
+                else if (rh == H && rw == W) {
+                    for (int c = 0; c < 3; ++c) O[c * plane] = (float)img[((int64_t)y * W + x) * 3 + c] / 255.0f;
+                } else {
+                    cv_src(y, H, sy, &y0, &y1, &fy); cv_src(x, W, sx, &x0, &x1, &fx);
+                    int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
+                    int b0 = (int)rintf((1.0f - fy) * 2048.0f), b1 = (int)rintf(fy * 2048.0f);
+                    for (int c = 0; c < 3; ++c) {
+                        int r0 = img[((int64_t)y0 * W + x0) * 3 + c] * a0 + img[((int64_t)y0 * W + x1) * 3 + c] * a1;
+                        int r1 = img[((int64_t)y1 * W + x0) * 3 + c] * a0 + img[((int64_t)y1 * W + x1) * 3 + c] * a1;
+                        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                        O[c * plane] = (float)v / 255.0f;
+                    }
                 }
-                float m00 = M[(int64_t)y0 * W + x0], m01 = M[(int64_t)y0 * W + x1], m10 = M[(int64_t)y1 * W + x0], m11 = M[(int64_t)y1 * W + x1];
+                if (y >= rhm || x >= rwm) { O[3 * plane] = 0.0f; continue; }
+                if (rhm == Hm && rwm == Wm) { O[3 * plane] = (float)M[(int64_t)y * Wm + x]; continue; }
+                cv_src(y, Hm, sym, &y0, &y1, &fy); cv_src(x, Wm, sxm, &x0, &x1, &fx);
+                float m00 = M[(int64_t)y0 * Wm + x0], m01 = M[(int64_t)y0 * Wm + x1], m10 = M[(int64_t)y1 * Wm + x0], m11 = M[(int64_t)y1 * Wm + x1];
                 float r0 = m00 * (1.0f - fx) + m01 * fx, r1 = m10 * (1.0f - fx) + m11 * fx;
                 O[3 * plane] = r0 * (1.0f - fy) + r1 * fy;
             }

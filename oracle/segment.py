@@ -66,11 +66,24 @@ def mask_resize_threshold(logits, up, rh, rw, oh, ow, thr):
     return out
 
 
+def scaledown_size(h, w, max_size):
+    """utils/io_utils.py:254-266"""
+    r = max_size / max(h, w)
+    if r < 1:
+        if h > w:
+            h, w = max_size, max(1, int(round(w * r)))
+        else:
+            w, h = max_size, max(1, int(round(h * r)))
+    return h, w
+
+
 def refine_prepare_batch(img, masks_u8, rh, rw, T):
-    n, H, W = masks_u8.shape
+    n, Hm, Wm = masks_u8.shape
+    H, W = img.shape[:2]
+    rhm, rwm = scaledown_size(Hm, Wm, T)
     out = np.empty((n, 4, T, T), np.float32)
     lib().orc_refine_prepare_batch(_p(np.ascontiguousarray(img)), _p(np.ascontiguousarray(masks_u8)), ci(n), ci(H), ci(W), ci(rh),
-                                   ci(rw), ci(T), _p(out))
+                                   ci(rw), ci(Hm), ci(Wm), ci(rhm), ci(rwm), ci(T), _p(out))
     return out
 
 
@@ -125,7 +138,7 @@ def detect(img, rp, cfg, S, pred_score_thr=0.3):
     logits = maskhead_logits(mf, kernels[sel], priors[sel], cfg.strides[0])
     up = cfg.strides[0]
     rh2 = math.ceil(mf.shape[0] * up * (1 / w_scale)); rw2 = math.ceil(mf.shape[1] * up * (1 / h_scale))
-    masks = mask_resize_threshold(logits, up, rh2, rw2, H, W, cfg.mask_thr_binary)
+    masks = mask_resize_threshold(logits, up, rh2, rw2, min(rh2, H), min(rw2, W), cfg.mask_thr_binary)   # [..., :ori_h, :ori_w] is a slice
     bb = boxes[sel].astype(np.int32)
     bb[:, 2:] -= bb[:, :2]
     return dict(n=len(sel), H=H, W=W, masks=masks, bboxes=bb, scores=scores[sel], logits=logits, boxes_f=boxes[sel])
@@ -133,14 +146,9 @@ def detect(img, rp, cfg, S, pred_score_thr=0.3):
 
 def refine(img, masks_u8, isnet_prog_for, T, mask_thr, max_batch=4):
     """_postprocess_refine (reference :638-665); isnet_prog_for(b) -> oracle-runnable Program for batch b"""
-    n, H, W = masks_u8.shape
-    r = T / max(H, W)
-    rh, rw = H, W
-    if r < 1:
-        if H > W:
-            rh, rw = T, max(1, int(round(W * r)))
-        else:
-            rw, rh = T, max(1, int(round(H * r)))
+    n = masks_u8.shape[0]
+    H, W = img.shape[:2]
+    rh, rw = scaledown_size(H, W, T)
     out = np.empty((n, H, W), np.uint8)
     for k0 in range(0, n, max_batch):
         b = min(max_batch, n - k0)
