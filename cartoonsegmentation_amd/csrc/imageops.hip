@@ -227,6 +227,28 @@ __global__ void k_stats_pack(const float *__restrict__ minmax_raw, float scale, 
 
 }  // namespace
 
+// cv2.resize(u8 HWC [H,W,C], (w,h), INTER_LINEAR): utils/io_utils.py:254-274 scaledown_maxsize (frame: kenburns_effect.py:917)
+__global__ __launch_bounds__(256) void k_resize_u8_linear(const uint8_t *__restrict__ src, int H, int W, int C, int h, int w,
+                                                           uint8_t *__restrict__ dst) {
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    int y0, y1, x0, x1; float fy, fx;
+    cv_src(y, H, (double)H / h, y0, y1, fy); cv_src(x, W, (double)W / w, x0, x1, fx);
+    for (int c = 0; c < C; ++c)
+        dst[((int64_t)y * w + x) * C + c] = (uint8_t)cv_lin_u8(src[((int64_t)y0 * W + x0) * C + c], src[((int64_t)y0 * W + x1) * C + c],
+                                                              src[((int64_t)y1 * W + x0) * C + c], src[((int64_t)y1 * W + x1) * C + c], fx, fy);
+}
+
+extern "C" int csm_resize_u8_linear(const uint8_t *src_hwc, int H, int W, int C, int h, int w, uint8_t *dst_hwc, void *stream) {
+    CSM_REQUIRE(src_hwc && dst_hwc && H > 0 && W > 0 && h > 0 && w > 0 && C > 0 && C <= 4);
+    if (h == H && w == W) {
+        CSM_HIP(hipMemcpyAsync(dst_hwc, src_hwc, (size_t)H * W * C, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return CSM_OK;
+    }
+    k_resize_u8_linear<<<dim3(csm::cdiv(w, 256), h), 256, 0, (hipStream_t)stream>>>(src_hwc, H, W, C, h, w, dst_hwc);
+    return csm::check_launch("k_resize_u8_linear");
+}
+
 extern "C" int csm_leres_input(const uint8_t *img_hwc, int H, int W, int h, int w, float *out, void *stream) {
     CSM_REQUIRE(img_hwc && out && H > 0 && W > 0 && h > 0 && w > 0);
     Norm3 nm{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}};

@@ -13,63 +13,12 @@
 //
 // Built with -ffp-contract=off: every fp32/fp64 operation rounds exactly once, as written, so
 // integer/decision results are bit-identical to oracle/warp_oracle.c.
-#include "csm_common.h"
+#include "warp_device.h"
 
 namespace {
+using namespace csmwarp;
 
 constexpr int kBlock = 256;
-
-struct ProjConst {
-    double focal_baseline;  // focal*baseline, folded in double like the literal in the CUDA text
-    double half_w, half_h;  // 0.5*W, 0.5*H
-    float focal_f;          // make_float3(0,0,focal).z
-    int W, H;
-};
-struct Shift { float x, y, z; };
-
-template <bool SHIFT>
-__device__ __forceinline__ void load_point(const float *__restrict__ P, int64_t N, int64_t p, Shift s,
-                                           float &x, float &y, float &z) {
-    x = P[p]; y = P[N + p]; z = P[2 * N + p];
-    if (SHIFT) {  // common.py:78-81
-        float r = z / (z + 0.0000001f);
-        x = x * r + s.x; y = y * r + s.y; z = z + s.z;
-    }
-}
-
-// models/utils.py:76-99  (mixed fp32/fp64 exactly as the untyped CUDA literals evaluate)
-__device__ __forceinline__ bool project(float x, float y, float z, const ProjConst &pc, float &fx, float &fy,
-                                        float &err) {
-    if ((double)z < 0.001) return false;
-    float lvx = 0.0f - x, lvy = 0.0f - y, lvz = 0.0f - z;
-    float ax = 0.0f - x, ay = 0.0f - y, az = pc.focal_f - z;
-    float num = ax * 0.0f + ay * 0.0f + az * 1.0f;
-    float den = lvx * 0.0f + lvy * 0.0f + lvz * 1.0f;
-    float dist = num / den;
-    if ((double)fabsf(den) < 0.001) return false;
-    float ix = x + dist * lvx;
-    float iy = y + dist * lvy;
-    fx = (float)(((double)ix + pc.half_w) - 0.5);
-    fy = (float)(((double)iy + pc.half_h) - 0.5);
-    err = (float)(1000000.0 - (pc.focal_baseline / ((double)z + 0.0000001)));
-    return true;
-}
-
-__device__ __forceinline__ void corner_weights(float fx, float fy, int &x0, int &y0, float w[4]) {
-    x0 = (int)floorf(fx); y0 = (int)floorf(fy);
-    float x1 = (float)(x0 + 1), y1 = (float)(y0 + 1), xf = (float)x0, yf = (float)y0;
-    w[0] = (x1 - fx) * (y1 - fy);  // NW
-    w[1] = (fx - xf) * (y1 - fy);  // NE
-    w[2] = (x1 - fx) * (fy - yf);  // SW
-    w[3] = (fx - xf) * (fy - yf);  // SE
-}
-
-// float min through native integer atomics (replaces the CAS loop of utils/cupy_utils.py:21-29).
-// Non-negative floats order like signed ints; negative floats order inversely like unsigned ints.
-__device__ __forceinline__ void atomic_min_f32(float *addr, float v) {
-    if (v >= 0.0f) atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
-    else atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
-}
 
 __global__ __launch_bounds__(kBlock) void k_fill(float *__restrict__ a, int64_t na, float va,
                                                   float *__restrict__ b, int64_t nb, float vb) {
@@ -232,11 +181,6 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float *__restrict__ a
     existing[(int64_t)b * plane + i] = e;
 }
 
-__device__ __forceinline__ uint8_t to_u8(float v) {  // (x*255).clip(0,255).astype(uint8)  kenburns_effect.py:1040
-    float u = v * 255.0f;
-    u = u < 0.0f ? 0.0f : (u > 255.0f ? 255.0f : u);
-    return (uint8_t)u;
-}
 
 // ---- disocclusion fill (common.py:145-248), restructured for CDNA4 ---------------------------
 // The reference runs one thread per pixel and lets hole pixels march 32 rays sequentially; on a
@@ -482,13 +426,6 @@ __global__ __launch_bounds__(kBlock) void k_process_shift(const float *__restric
     O[p] = x; O[N + p] = y; O[2 * N + p] = z;
 }
 
-ProjConst make_proj(int H, int W, double focal, double baseline) {
-    ProjConst pc;
-    pc.focal_baseline = focal * baseline;
-    pc.half_w = 0.5 * W; pc.half_h = 0.5 * H;
-    pc.focal_f = (float)focal; pc.W = W; pc.H = H;
-    return pc;
-}
 
 inline dim3 grid2d(int W, int H, int B, int bx, int by) { return dim3(csm::cdiv(W, bx), csm::cdiv(H, by), B); }
 

@@ -6,8 +6,8 @@ cartoonsegmentation_amd.ops (render_pointcloud, fill_disocclusion, process_shift
 
 MI355X-first differences (results unchanged):
   * LeReS runs as one layer program; its uint8 pre/post-processing stays on the device (imageops.hip);
-  * process_autozoom (common.py:86-142) evaluates the <=256 candidate shifts without a host sync per candidate:
-    coverage counts are accumulated on the device and read back once;
+  * process_autozoom (common.py:86-142) evaluates the <=256 candidate shifts in batched launches that only compute what
+    coverage needs (z-buffer, degrid, z-test: autozoom.hip); the counts are read back once;
   * the 75-frame loop (kenburns_effect.py:1015-1072) is the fused csm_warp_frame + csm_crop_resize_u8; frames are
     copied to the host once at the end (the reference does a 12 MB D2H per frame).
 Point-cloud inpainting (Inpaint GridNet, :441-512) is built; bokeh depth-of-field (depth_field=True, :1042-1067) is built;
@@ -397,6 +397,9 @@ class KenBurnsPipeline:
         return _fill_zero_with_min_positive(depth)
 
     def run_instance_segmentation(self, img, scale_down_to_maxsize=True):
+        if scale_down_to_maxsize:                                                                                    # :862-863
+            from utils.io_utils import scaledown_maxsize
+            img = scaledown_maxsize(img, self.cfg.max_size)
         inst = self.animeinsseg.infer(img, self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None, output_type='tensor',
                                       max_instances=self.max_instances)                                              # :869-872
         return inst, img
@@ -423,10 +426,20 @@ class KenBurnsPipeline:
         return disparity
 
     # ---- generate_kenburns_config (kenburns_effect.py:898-951) -----------------------------------------------
+    def _scaled_frame(self, img_d):
+        """kenburns_effect.py:917 `img = scaledown_maxsize(img, self.cfg.max_size)` on the device (cv2 INTER_LINEAR u8 restated)"""
+        H, W = int(img_d.shape[0]), int(img_d.shape[1])
+        h, w = scaledown_size(H, W, self.cfg.max_size)
+        return img_d if (h, w) == (H, W) else ops.resize_u8_linear(img_d, h, w)
+
     def generate_kenburns_config(self, img, instances: AnimeInstances = None, verbose: bool = False, savep=None):
-        if isinstance(img, str):
-            raise NotImplementedError("pass a uint8 BGR ndarray (image decoding is not on the hot path)")
+        if isinstance(img, str):                                   # kenburns_effect.py:909-910 mmcv.imread(img)
+            from utils.io_utils import imread
+            img = imread(img)
         with torch.no_grad():
+            img_dev = self.animeinsseg._upload(img)
+            # the frame the depth / warp stages work on (reference :917); the detector sees the full-size image (:914-915)
+            frame_dev = self._scaled_frame(img_dev)
             coarse = None
             if instances is None and self.overlap_depth:
                 # Segmentation (RTMDet + ISNet) and the depth CNN only share the input image: run LeReS on a second HIP stream
@@ -436,33 +449,22 @@ class KenBurnsPipeline:
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(self.device)
                 side = self._side_stream
-                img_dev = self.animeinsseg._upload(img)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    coarse = self._depth_est(None, img_dev)
+                    coarse = self._depth_est(None, frame_dev)
                 instances, _ = self.run_instance_segmentation(img_dev, scale_down_to_maxsize=False)
                 main.wait_stream(side)
                 coarse.record_stream(main)
-                img = img_dev if isinstance(img, torch.Tensor) else img
             elif instances is None:
-                instances, _ = self.run_instance_segmentation(img, scale_down_to_maxsize=False)
-            H, W = img.shape[:2]
-            if scaledown_size(H, W, self.cfg.max_size) != (H, W):
-                raise NotImplementedError("max_size smaller than the image needs cv2.resize of the frame (not restated); "
-                                          "use max_size >= max(H, W)")
-            instances.resize(H, W)
-            self.cfg.int_height, self.cfg.int_width = H, W
-            img_d = self.animeinsseg._upload(img)
-            img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
-            cfg = self.cfg.copy()
-            disparity = self.infer_disparity(img, instances, img_tensor, kcfg=cfg, coarse=coarse, verbose=verbose)
-            return self._finish_config(cfg, img, img_tensor, instances, disparity)
+                instances, _ = self.run_instance_segmentation(img_dev, scale_down_to_maxsize=False)
+            return self._config_from(img, instances, coarse, verbose, frame_dev=frame_dev)
 
     def generate_kenburns_configs(self, imgs, verbose: bool = False):
         """MI355X addition (the reference loops image by image, run_kenburns_batch.py:36-62): equally sized frames share one
         batched detector run, shared ISNet refine batches and one batched LeReS run; the per-frame glue is unchanged."""
         with torch.no_grad():
             imgs_d = [self.animeinsseg._upload(im) for im in imgs]
+            frames_d = [self._scaled_frame(t) for t in imgs_d]
             seg = lambda: self.animeinsseg.infer(list(imgs_d), self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None,
                                                  output_type='tensor', max_instances=self.max_instances)
             if self.overlap_depth:
@@ -475,7 +477,7 @@ class KenBurnsPipeline:
                 per = (len(imgs_d) + k - 1) // k
                 coarse = []
                 for si in range(k):
-                    grp = imgs_d[si * per:(si + 1) * per]
+                    grp = frames_d[si * per:(si + 1) * per]
                     if not grp:
                         continue
                     side = self._side_streams[si]
@@ -489,25 +491,24 @@ class KenBurnsPipeline:
                     c.record_stream(main)
             else:
                 insts = seg()
-                coarse = self._depth_est_leres_batch(imgs_d)
-            saved = self.overlap_depth
-            try:
-                self.overlap_depth = False
-                return [self._config_from(im, inst, c, verbose) for im, inst, c in zip(imgs_d, insts, coarse)]
-            finally:
-                self.overlap_depth = saved
+                coarse = self._depth_est_leres_batch(frames_d)
+            return [self._config_from(im, inst, c, verbose, frame_dev=f) for im, inst, c, f in zip(imgs, insts, coarse, frames_d)]
 
-    def _config_from(self, img, instances, coarse, verbose=False):
-        H, W = img.shape[:2]
-        if scaledown_size(H, W, self.cfg.max_size) != (H, W):
-            raise NotImplementedError("max_size smaller than the image needs cv2.resize of the frame (not restated)")
+    def _config_from(self, img, instances, coarse, verbose=False, frame_dev=None):
+        """kenburns_effect.py:917-951 from the scaled frame on: instances.resize, depth glue, point cloud"""
+        if frame_dev is None:
+            frame_dev = self._scaled_frame(self.animeinsseg._upload(img))
+        H, W = int(frame_dev.shape[0]), int(frame_dev.shape[1])
         instances.resize(H, W)
         self.cfg.int_height, self.cfg.int_width = H, W
-        img_d = self.animeinsseg._upload(img)
-        img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+        img_tensor = (frame_dev.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
         cfg = self.cfg.copy()
-        disparity = self.infer_disparity(img, instances, img_tensor, kcfg=cfg, coarse=coarse, verbose=verbose)
-        return self._finish_config(cfg, img, img_tensor, instances, disparity)
+        disparity = self.infer_disparity(frame_dev, instances, img_tensor, kcfg=cfg, coarse=coarse, verbose=verbose)
+        if tuple(frame_dev.shape) == tuple(img.shape):
+            kept = img                                             # cfg.original_img_nparray: the caller's own array / tensor
+        else:
+            kept = frame_dev if isinstance(img, torch.Tensor) else frame_dev.cpu().numpy()
+        return self._finish_config(cfg, kept, img_tensor, instances, disparity)
 
     def _finish_config(self, cfg, img, img_tensor, instances, disparity):
         """kenburns_effect.py:928-951"""
@@ -542,35 +543,8 @@ class KenBurnsPipeline:
 
     # ---- autozoom (kenburns_effect.py:953-977, common.py:86-142) ------------------------------------------------
     def process_autozoom(self, objSettings, objCommon):
-        shift = objSettings['fltShift']
-        lin = np.linspace(-shift, shift, 16)
-        cw = objSettings['objFrom']['intCropWidth'] / objSettings['fltZoom']
-        ch = objSettings['objFrom']['intCropHeight'] / objSettings['fltZoom']
-        d_from = objCommon['objDepthrange'][0]
-        d_to = d_from * (cw / objSettings['objFrom']['intCropWidth'])
-        cu, cv = objSettings['objFrom']['fltCenterU'], objSettings['objFrom']['fltCenterV']
-        W, H = objCommon['intWidth'], objCommon['intHeight']
-        cands = []
-        for iu in range(16):
-            for iv in range(16):
-                su, sv = float(lin[iv]), float(lin[iu])        # npyShiftU[intU,intV] = lin[intV]; npyShiftV[intU,intV] = lin[intU]
-                if cu + su < cw / 2.0 or cu + su > W - (cw / 2.0) or cv + sv < ch / 2.0 or cv + sv > H - (ch / 2.0):
-                    continue
-                cands.append((su, sv))
-        counts = torch.zeros(max(len(cands), 1), device=self.device)
-        rgb = objCommon['tenRawImage'].view(1, 3, -1)
-        for k, (su, sv) in enumerate(cands):                   # no host sync inside the loop
-            pts, _ = ops.process_shift({'tenPoints': objCommon['tenRawPoints'], 'fltShiftU': su, 'fltShiftV': sv,
-                                        'fltDepthFrom': d_from, 'fltDepthTo': d_to}, objCommon)
-            _, existing = ops.render_pointcloud(pts, rgb, W, H, objCommon['fltFocal'], objCommon['fltBaseline'])
-            counts[k] = (existing > 0.0).float().sum()
-        best, bu, bv = 0.0, None, None
-        for k, c in enumerate(counts.tolist()[:len(cands)]):   # first strictly-better candidate wins, like the reference
-            if best < c:
-                best, (bu, bv) = c, cands[k]
-        return {'fltCenterU': cu + bu, 'fltCenterV': cv + bv,
-                'intCropWidth': int(round(objSettings['objFrom']['intCropWidth'] / objSettings['fltZoom'])),
-                'intCropHeight': int(round(objSettings['objFrom']['intCropHeight'] / objSettings['fltZoom']))}
+        """common.py:86-142 through the batched coverage kernels (ops.process_autozoom)"""
+        return ops.process_autozoom(objSettings, objCommon)
 
     def autozoom(self, cfg: KenBurnsConfig, verbose: bool = False, inpaint: bool = True):
         with torch.no_grad():

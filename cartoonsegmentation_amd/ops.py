@@ -151,6 +151,79 @@ def process_shift(objSettings, objCommon):
     return shift_points(pts, shift), tenShift
 
 
+def resize_u8_linear(img, h, w):
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR) of a uint8 HxWxC (or HxW) device tensor -- the resampler of
+    utils/io_utils.py:254-274 scaledown_maxsize"""
+    if not img.is_cuda or img.dtype != torch.uint8:
+        raise _lib.CsmError("resize_u8_linear: uint8 device tensor expected")
+    img = img.contiguous()
+    C = 1 if img.dim() == 2 else int(img.shape[2])
+    out = torch.empty((h, w) if img.dim() == 2 else (h, w, C), dtype=torch.uint8, device=img.device)
+    check(_lib.load().csm_resize_u8_linear(ptr(img), i32(img.shape[0]), i32(img.shape[1]), i32(C), i32(h), i32(w), ptr(out),
+                                           stream_ptr()), "resize_u8_linear")
+    return out
+
+
+def autozoom_coverage(tenPoints, shifts, intWidth, intHeight, fltFocal, fltBaseline, chunk=None):
+    """coverage counts `(tenExisting > 0.0).float().sum()` of render_pointcloud(process_shift(tenPoints, shift_k)) for every
+    candidate shift_k = (sx, sy, sz) -- common.py:110-126 -- in batched launches (csm_autozoom_coverage), no colour rendered,
+    no host sync.  All candidates of one search share sz (common.py:92-93).  Returns an int32 device tensor [K]."""
+    import ctypes
+    import os
+    tenPoints = _dev(tenPoints, "tenPoints")
+    assert tenPoints.shape[0] == 1 and tenPoints.shape[1] == 3
+    L, K = _lib.load(), len(shifts)
+    counts = torch.zeros(max(K, 1), dtype=torch.int32, device=tenPoints.device)
+    if K == 0:
+        return counts[:0]
+    sz = {float(torch.tensor(float(s[2]), dtype=torch.float32).item()) for s in shifts}
+    assert len(sz) == 1, "the candidates of one autozoom search share the z shift"
+    xy = (ctypes.c_float * (2 * K))()
+    t = torch.tensor([[float(s[0]), float(s[1])] for s in shifts], dtype=torch.float32)      # FloatTensor rounding, common.py:74
+    for i in range(K):
+        xy[2 * i], xy[2 * i + 1] = t[i, 0].item(), t[i, 1].item()
+    chunk = int(chunk or os.environ.get('CSM_AUTOZOOM_CHUNK', L.csm_autozoom_max_chunk()))
+    chunk = max(1, min(chunk, L.csm_autozoom_max_chunk(), K))
+    scratch = torch.empty(L.csm_autozoom_scratch_floats(i32(intHeight), i32(intWidth), i32(chunk)), dtype=torch.float32,
+                          device=tenPoints.device)
+    check(L.csm_autozoom_coverage(ptr(tenPoints), i64(tenPoints.shape[2]), i32(intHeight), i32(intWidth), f64(fltFocal),
+                                  f64(fltBaseline), xy, f32(sz.pop()), i32(K), i32(chunk), ptr(scratch), ptr(counts), stream_ptr()),
+          "autozoom_coverage")
+    return counts[:K]
+
+
+def process_autozoom(objSettings, objCommon, return_counts=False):
+    """process_autozoom -- anime_3dkenburns/common.py:86-142: the 16 x 16 grid of candidate shifts whose crop stays inside the
+    image, the one with the largest rendered coverage wins (first strictly-better candidate, like the reference's `<`).
+    MI355X: all candidates in batched launches + ONE host read instead of <= 256 x (3 kernels + `.item()`)."""
+    import numpy as np
+    shift = objSettings['fltShift']
+    lin = np.linspace(-shift, shift, 16)
+    oF = objSettings['objFrom']
+    cw, ch = oF['intCropWidth'] / objSettings['fltZoom'], oF['intCropHeight'] / objSettings['fltZoom']
+    d_from = objCommon['objDepthrange'][0]
+    d_to = objCommon['objDepthrange'][0] * (cw / oF['intCropWidth'])
+    cu, cv = oF['fltCenterU'], oF['fltCenterV']
+    W, H = objCommon['intWidth'], objCommon['intHeight']
+    cands = []
+    for iu in range(16):
+        for iv in range(16):
+            su, sv = lin[iv].item(), lin[iu].item()        # npyShiftU[intU, intV] = lin[intV]; npyShiftV[intU, intV] = lin[intU]
+            if cu + su < cw / 2.0 or cu + su > W - (cw / 2.0) or cv + sv < ch / 2.0 or cv + sv > H - (ch / 2.0):
+                continue
+            cands.append((su, sv))
+    shifts = [shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, objCommon) for su, sv in cands]
+    counts = autozoom_coverage(objCommon['tenRawPoints'], shifts, W, H, objCommon['fltFocal'], objCommon['fltBaseline']).tolist()
+    best, bu, bv = 0.0, None, None
+    for (su, sv), c in zip(cands, counts):
+        if best < c:
+            best, bu, bv = float(c), su, sv
+    out = {'fltCenterU': cu + bu, 'fltCenterV': cv + bv,
+           'intCropWidth': int(round(oF['intCropWidth'] / objSettings['fltZoom'])),
+           'intCropHeight': int(round(oF['intCropHeight'] / objSettings['fltZoom']))}
+    return (out, cands, counts) if return_counts else out
+
+
 class WarpFrame:
     """Fused per-frame warp of KenBurnsPipeline.process_kenburns (kenburns_effect.py:1027-1040):
     process_shift -> render_pointcloud(cat[rgb,depth]) -> fill_disocclusion -> uint8 HWC.

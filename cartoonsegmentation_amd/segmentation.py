@@ -180,9 +180,16 @@ class AnimeInsSeg:
             raise NotImplementedError("annotation export / tagging are outside the hot-path scope (SURVEY 2.1)")
         assert output_type in {'tensor', 'numpy'}
         return_list = isinstance(imgs, list)
-        if isinstance(imgs, str):
-            raise NotImplementedError("image decoding (mmcv.imread) is not part of the hot path: pass a uint8 BGR ndarray")
+        if isinstance(imgs, str):                                 # prepare_data_pipeline, reference :667-693: a directory or one file
+            if os.path.isdir(imgs):
+                from utils.io_utils import find_all_imgs
+                imgs, return_list = find_all_imgs(imgs, abs_path=True), True
+            elif imgs.endswith('.txt') or imgs.endswith('.json'):
+                raise NotImplementedError("image lists / COCO files belong to the annotation tooling (SURVEY 2.1)")
         imgs = imgs if return_list else [imgs]
+        if any(isinstance(im, str) for im in imgs):               # single_image_preprocess, reference :62-64: mmcv.imread(path)
+            from utils.io_utils import imread
+            imgs = [imread(im) if isinstance(im, str) else im for im in imgs]
         same = len(imgs) > 1 and all(tuple(im.shape) == tuple(imgs[0].shape) for im in imgs)
         if same:            # equally sized frames: one batched detector run + refine batches shared across frames
             insts = [self._instances_from(d, pred_score_thr) for d in self.detect_raw_batch(imgs)]

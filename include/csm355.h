@@ -98,6 +98,18 @@ int csm_warp_frame(const float *pts, const float *rgb, const float *depth, int64
                    double focal, double baseline, float sx, float sy, float sz, float *scratch,
                    float *render_filled, uint8_t *frame_u8, void *stream);
 
+/* Coverage search of process_autozoom   anime_3dkenburns/common.py:86-142, batched.
+ * For each of K candidate camera shifts (sx_k, sy_k, shift_z) -- the float32 tenShift of process_shift (common.py:74) --
+ * counts[k] = number of pixels with tenExisting > 0 after process_shift + render_pointcloud of pts [1,3,N]
+ * (the `(tenExisting > 0.0).float().sum()` of common.py:126), without rendering any colour: z-buffer, degrid (Jacobi form) and
+ * the z-test only.  Candidates are processed `chunk` (<= csm_autozoom_max_chunk()) at a time, each with its own z-buffer plane.
+ * shifts_xy: HOST pointer to K x {sx, sy}; counts: DEVICE int32 [K] (zeroed by the call; read them once after the stream
+ * is synchronised); scratch: csm_autozoom_scratch_floats(H, W, chunk) device floats. */
+int csm_autozoom_max_chunk(void);
+size_t csm_autozoom_scratch_floats(int H, int W, int chunk);
+int csm_autozoom_coverage(const float *pts, int64_t N, int H, int W, double focal, double baseline, const float *shifts_xy,
+                          float shift_z, int K, int chunk, float *scratch, int *counts, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Dense networks: a flat "layer program" executed on one stream (no allocation, graph-capturable)
  *
@@ -231,6 +243,9 @@ int csm_det_preprocess(const uint8_t *img_hwc, int H, int W, int rh, int rw, int
  * uint8 image plumbing around the depth net and the frame loop (OpenCV semantics restated, [EXT])
  * ---------------------------------------------------------------------------------- */
 
+/* utils/io_utils.py:254-274 scaledown_maxsize (the frame itself: kenburns_effect.py:917): cv2.resize(INTER_LINEAR) of a uint8
+ * HWC image [H,W,C] (C <= 4) to [h,w,C]; the host applies the size rule. */
+int csm_resize_u8_linear(const uint8_t *src_hwc, int H, int W, int C, int h, int w, uint8_t *dst_hwc, void *stream);
 /* kenburns_effect.py:563-571 + depth_modules/leres/leres/depthmap.py:16-38: BGR u8 HWC [H,W,3] -> cv2 INTER_LINEAR to
  * (h,w) -> /255 -> RGB -> (x-mean)/std (ImageNet) -> fp32 NCHW [1,3,h,w] */
 int csm_leres_input(const uint8_t *img_hwc, int H, int W, int h, int w, float *out, void *stream);

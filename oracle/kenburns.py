@@ -39,12 +39,18 @@ def leres_depth(img, leres_prog_for, depth_est_size):
     return depth, y, q
 
 
-def depth_adjustment(masks_bool, disparity):
+def depth_adjustment(masks_bool, disparity, use_medium=False):
+    """kenburns_effect.py:39-91 without the resize round trip (disparity and image of equal size)"""
     adj = disparity.copy()
     for m in masks_bool:
         mf = m.astype(np.float32)[None, None]
         plane = adj * mf
         if float(plane.sum()) == 0:
+            continue
+        if use_medium:                                   # torch.median = lower median
+            sel = plane > 0
+            v = np.sort(adj[sel])
+            adj[sel] = v[(v.size - 1) // 2]
             continue
         rows = np.nonzero(plane.sum(axis=3).reshape(-1) > 0.0)[0]
         top, bottom = int(rows[0]), int(rows[-1])
@@ -77,8 +83,9 @@ def _points_from_normalised(disparity, focal, baseline):
     return None, depth, valid, pts, un
 
 
-def autozoom_target(kc, rgb, W, H, focal, baseline, shift=100.0, zoom=1.25):
-    """common.py:86-142"""
+def autozoom_target(kc, rgb, W, H, focal, baseline, shift=100.0, zoom=1.25, degrid_mode=1, counts_out=None):
+    """common.py:86-142 ; degrid_mode 0 = the raster in-place pass (what a sequential execution of the reference does),
+    1 = the Jacobi form the HIP build uses; counts_out (list) receives the coverage count of every candidate tried"""
     lin = np.linspace(-shift, shift, 16)
     icw, ich = int(math.floor(0.97 * W)), int(math.floor(0.97 * H))
     cw, ch = icw / zoom, ich / zoom
@@ -94,8 +101,10 @@ def autozoom_target(kc, rgb, W, H, focal, baseline, shift=100.0, zoom=1.25):
                 continue
             s = owarp.shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, common)
             ps = owarp.process_shift(kc['pts'], s)
-            _, existing = owarp.render_pointcloud(ps, rgb, W, H, focal, baseline, degrid_mode=1)
+            _, existing = owarp.render_pointcloud(ps, rgb, W, H, focal, baseline, degrid_mode=degrid_mode)
             c = float((existing > 0.0).astype(np.float32).sum())
+            if counts_out is not None:
+                counts_out.append(c)
             if best < c:
                 best, bu, bv = c, su, sv
     return {'fltCenterU': cu + bu, 'fltCenterV': cv + bv, 'intCropWidth': int(round(icw / zoom)), 'intCropHeight': int(round(ich / zoom))}, \

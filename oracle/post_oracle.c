@@ -238,6 +238,20 @@ static int cv_lin_u8(int p00, int p01, int p10, int p11, float fx, float fy)
 }
 
 /* kenburns_effect.py:563-571 + leres/depthmap.py:16-38 */
+/* cv2.resize(u8 HWC, INTER_LINEAR)  -- utils/io_utils.py:254-274 */
+void orc_resize_u8_linear(const uint8_t *src, int H, int W, int C, int h, int w, uint8_t *dst)
+{
+    double sy = (double)H / h, sx = (double)W / w;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int y0, y1, x0, x1; float fy, fx;
+            cv_src(y, H, sy, &y0, &y1, &fy); cv_src(x, W, sx, &x0, &x1, &fx);
+            for (int c = 0; c < C; ++c)
+                dst[((int64_t)y * w + x) * C + c] = (uint8_t)cv_lin_u8(src[((int64_t)y0 * W + x0) * C + c], src[((int64_t)y0 * W + x1) * C + c],
+                                                                      src[((int64_t)y1 * W + x0) * C + c], src[((int64_t)y1 * W + x1) * C + c], fx, fy);
+        }
+}
+
 void orc_leres_input(const uint8_t *img, int H, int W, int h, int w, float *out)
 {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};

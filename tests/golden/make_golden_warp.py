@@ -8,6 +8,8 @@ fill_disocclusion, process_shift, spatial_filter, depth_to_points are imported b
 path (ref_loader.py) and executed on CPU tensors; their CUDA kernel text is
 captured from the reference's own preprocess_kernel() expansion and run
 sequentially through cuda_on_cpu.h (g++ -ffp-contract=off).
+CSM_GOLDEN_FP_CONTRACT=fast python tests/golden/make_golden_warp.py  writes the warp_*_fast.npz twins (g++ -ffp-contract=fast
+-mfma): the two builds bracket NVRTC's default FMA contraction.
 """
 import ctypes
 import os
@@ -118,6 +120,12 @@ def render_case(name, H, W, seed, C, extra, shift, B=1):
         filled = co.fill_disocclusion(render, dm)
         frame = (filled[0, 0:3].numpy().transpose(1, 2, 0) * 255.0).clip(0.0, 255.0).astype(np.uint8)
         out.update(fill_depth=dm.numpy(), filled=filled.numpy(), frame=frame)
+    if ref_loader.FP_CONTRACT == 'fast':
+        # the other end of the FMA-contraction bracket (NVRTC contracts by default): only what the decisions are
+        # checked against -- z-buffers, coverage, final images -- under <name>_fast.npz
+        keep = ('zee_after_zee', 'zee_after_degrid_inplace', 'existing', 'render', 'filled', 'frame', 'fill_depth')
+        out = {k: v for k, v in out.items() if k in keep}
+        name = name + '_fast'
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     holes = float((existing == 0).float().mean())
     print(name, 'N', N, 'holes %.3f' % holes, 'bytes', os.path.getsize(os.path.join(HERE, name + '.npz')))
@@ -158,5 +166,6 @@ if __name__ == '__main__':
     render_case('warp_c_40x32_c68', 32, 40, 13, 68, 0.25, (3.0, 2.0, 0.9))
     render_case('warp_d_56x40_c4_b2', 40, 56, 14, 4, 0.3, (-5.0, -5.0, 0.75), B=2)
     render_case('warp_e_80x64_c4_big_shift', 64, 80, 15, 4, 0.0, (30.0, 20.0, 0.6))
-    pointwise_case('pointwise_72x56', 56, 72, 21)
-    discfill_case('discfill_48x40', 40, 48, 31)
+    if ref_loader.FP_CONTRACT != 'fast':
+        pointwise_case('pointwise_72x56', 56, 72, 21)
+        discfill_case('discfill_48x40', 40, 48, 31)

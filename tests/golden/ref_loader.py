@@ -67,7 +67,7 @@ class _CpuRawKernel:
             "    blockIdx.x = b; threadIdx.x = t; %s(%s); }\n}\n"
         ) % (self.name, ", ".join(params), self.name, ", ".join(names))
         full = '#include "cuda_on_cpu.h"\n' + src + driver
-        tag = hashlib.sha1((full + FP_CONTRACT).encode()).hexdigest()[:16]
+        tag = hashlib.sha1((full + FP_CONTRACT + ("-O2" if FP_CONTRACT == "fast" else "")).encode()).hexdigest()[:16]
         cpp, so = os.path.join(_BUILD, tag + ".cpp"), os.path.join(_BUILD, tag + ".so")
         if not os.path.exists(so):
             with open(cpp, "w") as f:
@@ -75,6 +75,9 @@ class _CpuRawKernel:
             cmd = ["g++", "-O1", "-ffp-contract=" + FP_CONTRACT, "-fno-fast-math", "-shared", "-fPIC",
                    "-I", HERE, cpp, "-o", so]
             if FP_CONTRACT == "fast":
+                # gcc forms FMAs in the widening-mul pass, which only runs from -O2 (at -O1 the "fast" build contains no
+                # vfmadd at all and the bracket would be vacuous); -O2 also inlines the float3 helpers so a*b+c is visible
+                cmd[1] = "-O2"
                 cmd.insert(1, "-mfma")
             subprocess.check_call(cmd)
         lib = ctypes.CDLL(so)
@@ -114,3 +117,56 @@ def load_warp_modules():
     mu = load_by_path("anime_3dkenburns.models.utils", "anime_3dkenburns/models/utils.py")
     co = load_by_path("anime_3dkenburns.common", "anime_3dkenburns/common.py")
     return mu, co, cu
+
+
+# ---- executing single definitions of files whose module-level imports cannot be satisfied here -----------------------------
+def extract_def(relpath, qualname, namespace):
+    """Compile ONE function / method of a reference file (its own text, taken from the file at run time through `ast`) and
+    define it in `namespace` (which supplies the globals the body needs).  Used for files whose module level imports mmdet /
+    mmcv / cv2 / omegaconf...: the definition is executed, the module is not imported.  Returns the function object."""
+    import ast
+    src = open(os.path.join(REF, relpath)).read()
+    tree = ast.parse(src)
+    body = tree.body
+    parts = qualname.split('.')
+    node = None
+    for i, part in enumerate(parts):
+        node = next((n for n in body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name == part), None)
+        if node is None:
+            raise KeyError("%s not found in %s" % (qualname, relpath))
+        body = getattr(node, 'body', [])
+    if isinstance(node, ast.FunctionDef):
+        node.decorator_list = []           # e.g. @torch.no_grad(), @AvoidCUDAOOM.retry_if_cuda_oom: wrappers, not semantics
+    mod = ast.Module(body=[node], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    exec(compile(mod, os.path.join(REF, relpath), 'exec'), namespace)
+    return namespace[parts[-1]]
+
+
+def cv2_stub():
+    """the only two cv2 calls the pinned paths reach when no image has to be scaled: copyMakeBorder (constant) ; resize raises,
+    so a fixture can never silently depend on an un-vendored OpenCV kernel"""
+    import numpy as np
+    cv2 = types.ModuleType("cv2")
+    cv2.BORDER_CONSTANT, cv2.INTER_LINEAR, cv2.INTER_AREA, cv2.LINE_AA = 0, 1, 3, 16
+
+    def copyMakeBorder(img, top, bottom, left, right, borderType, value=0):
+        pads = [(top, bottom), (left, right)] + [(0, 0)] * (img.ndim - 2)
+        v = value[0] if isinstance(value, (tuple, list)) else value
+        assert not isinstance(value, (tuple, list)) or all(x == v for x in value)
+        return np.pad(img, pads, mode='constant', constant_values=v)
+
+    def resize(*a, **k):
+        raise RuntimeError("cv2.resize is not vendored: pinned fixtures must not need it")
+    cv2.copyMakeBorder, cv2.resize = copyMakeBorder, resize
+    return cv2
+
+
+def load_anime_instances():
+    """the reference's AnimeInstances class (animeinsseg/anime_instances.py) with utils.constants loaded by path"""
+    install_stubs()
+    sys.modules.setdefault("cv2", cv2_stub())
+    _bare("utils")
+    load_by_path("utils.constants", "utils/constants.py")
+    _bare("animeinsseg")
+    return load_by_path("animeinsseg.anime_instances", "animeinsseg/anime_instances.py").AnimeInstances

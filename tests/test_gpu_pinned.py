@@ -1,0 +1,163 @@
+"""GPU: the HIP path (through the C ABI / the drop-in classes) against the fixtures produced by EXECUTING the reference's own
+text (tests/golden/make_golden_pinned.py): mask head (a5), mask up-sample / threshold (a6), refine glue (a7), depth adjustment
+(a10), autozoom search (a16).  CPU twins (oracle vs the same fixtures): tests/test_oracle_pinned.py."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("name", ["pin_maskhead_20x20", "pin_maskhead_12x28"])
+def test_maskhead_logits_vs_reference_text(name):
+    from cartoonsegmentation_amd import _lib
+    from cartoonsegmentation_amd._lib import check, i32, ptr, stream_ptr
+    d = _load(name)
+    feat = dev(d['mask_feat'][0].transpose(1, 2, 0))                               # NHWC like the engine's activations
+    h, w = feat.shape[:2]
+    n = len(d['priors'])
+    logits = torch.empty((n, h, w), device='cuda')
+    check(_lib.load().csm_maskhead_logits(ptr(feat), i32(8), i32(h), i32(w), i32(8), i32(8), ptr(dev(d['kernels'])), ptr(dev(d['priors'])),
+                                          i32(n), i32(8), ptr(logits), stream_ptr()), "maskhead")
+    ref = d['logits']
+    assert np.abs(logits.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("name", ["pin_boxprompt_100x140", "pin_boxprompt_152x96"])
+def test_segment_with_bboxes_vs_reference_text(name):
+    """AnimeInsSeg.segment_with_bboxes (reference :339-393) fed with the fixture's detections: masks, boxes, scores"""
+    from animeinsseg import AnimeInsSeg
+    d = _load(name)
+    H, W = int(d['H']), int(d['W'])
+    net = AnimeInsSeg('synthetic', default_det_size=int(d['S']), refine_kwargs={'refine_method': 'none'})
+    data = dict(n=len(d['boxes']), boxes=dev(d['boxes']), scores=dev(d['scores']), priors=dev(d['priors']), kernels=dev(d['kernels']),
+                H=H, W=W)
+    feat = dev(d['mask_feat'][0].transpose(1, 2, 0))
+    inst = net.segment_with_bboxes(np.zeros((H, W, 3), np.uint8), d['query'], data, feat)
+    masks = inst.masks.cpu().numpy()
+    assert masks.shape == d['masks'].shape and (masks != d['masks']).mean() <= 2e-4
+    assert np.array_equal(inst.bboxes.cpu().numpy(), d['out_bboxes'])
+    assert np.array_equal(inst.scores.cpu().numpy(), d['out_scores'])
+
+
+@pytest.mark.parametrize("name", ["pin_refine_90x74_T96", "pin_refine_64x64_T64"])
+def test_refine_glue_vs_reference_text(name):
+    """prepare_refine_batch (bit-exact), ISNet on that batch (vs the reference module's logits), sigmoid / crop / align_corners
+    resize / threshold on the fixture's (re-centred) logits"""
+    from cartoonsegmentation_amd import _lib
+    from cartoonsegmentation_amd._lib import check, f32, i32, ptr, stream_ptr
+    from cartoonsegmentation_amd.nets import build_isnet
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    from cartoonsegmentation_amd.weights import SynthWeights
+    L = _lib.load()
+    d = _load(name)
+    img, T = d['img'], int(d['T'])
+    H, W = img.shape[:2]
+    n = d['masks_in'].shape[0]
+    batch = torch.empty((n, 4, T, T), device='cuda')
+    check(L.csm_refine_prepare_batch(ptr(dev(img)), ptr(dev(d['masks_in'].astype(np.uint8))), i32(n), i32(H), i32(W), i32(H), i32(W),
+                                     i32(H), i32(W), i32(H), i32(W), i32(T), ptr(batch), stream_ptr()), "prepare")
+    assert np.array_equal(batch.cpu().numpy(), d['batch'])
+    raw = []
+    for k0 in range(0, n, 4):                                                   # the reference's batches of <= 4
+        b = min(4, n - k0)
+        cp = CompiledProgram(build_isnet(SynthWeights('isnet.'), b, T, T), torch.device('cuda'))
+        out = torch.empty((b, 1, T, T), device='cuda')
+        cp.run(batch[k0:k0 + b].contiguous(), out)
+        raw.append(out)
+    raw = torch.cat(raw).cpu().numpy()
+    assert np.abs(raw - d['logits_raw']).max() <= 2e-4 * float(np.abs(d['logits_raw']).max())
+    logits = dev(((d['logits_raw'] - np.float32(d['centre'])) / np.float32(d['scale'])).astype(np.float32))
+    out = torch.empty((n, H, W), dtype=torch.uint8, device='cuda')
+    check(L.csm_refine_threshold(ptr(logits), i32(n), i32(T), i32(T), i32(H), i32(W), i32(H), i32(W), f32(0.3), ptr(out), stream_ptr()),
+          "threshold")
+    diff = out.cpu().numpy().astype(bool) != d['masks_out']
+    assert diff.mean() <= 1e-4 and np.all(np.abs(d['probs'][diff] - 0.3) < 1e-5)
+
+
+def test_depth_adjustment_vs_reference_text():
+    from animeinsseg import AnimeInstances
+    from cartoonsegmentation_amd.kenburns import depth_adjustment_animesseg
+    d = _load("pin_depth_adjust")
+    H, W = d['disp'].shape[2:]
+    inst = AnimeInstances(dev(d['masks']), torch.zeros((4, 4), dtype=torch.int32, device='cuda'), torch.ones(4, device='cuda'))
+    img = torch.zeros(1, 3, H, W, device='cuda')
+    assert np.array_equal(depth_adjustment_animesseg(inst, dev(d['disp']), img, False).cpu().numpy(), d['adjusted'])
+    assert np.array_equal(depth_adjustment_animesseg(inst, dev(d['disp']), img, True).cpu().numpy(), d['adjusted_median'])
+    assert np.array_equal(depth_adjustment_animesseg(AnimeInstances(), dev(d['disp']), img, False).cpu().numpy(), d['adjusted_empty'])
+    got = depth_adjustment_animesseg(inst, dev(d['disp_small']), img, False).cpu().numpy()       # bilinear round trip: fp32 rounding
+    assert np.abs(got - d['adjusted_resized']).max() <= 1e-4 * float(d['adjusted_resized'].max())
+
+
+def test_batched_autozoom_vs_reference_text_and_oracle():
+    """csm_autozoom_coverage: coverage counts of every candidate == the oracle's per-candidate render (Jacobi degrid), and the
+    chosen target is, by the REFERENCE's own counts, within one pixel of the reference's best (its in-place degrid is a race)"""
+    from cartoonsegmentation_amd import ops
+    from oracle import kenburns as okb
+    d = _load("pin_autozoom_96x128")
+    H, W = int(d['H']), int(d['W'])
+    dr = d['depthrange']
+    common = {'objDepthrange': (float(dr[0]), float(dr[1]), (int(dr[2]), int(dr[3])), (0, 0)), 'intWidth': W, 'intHeight': H,
+              'fltFocal': float(d['focal']), 'fltBaseline': float(d['baseline']), 'tenRawPoints': dev(d['pts'])}
+    objFrom = {'fltCenterU': W / 2.0, 'fltCenterV': H / 2.0, 'intCropWidth': int(np.floor(0.97 * W)), 'intCropHeight': int(np.floor(0.97 * H))}
+    settings = {'fltShift': float(d['shift']), 'fltZoom': 1.25, 'objFrom': objFrom}
+    kc = dict(depthrange=common['objDepthrange'][:3], pts=d['pts'])
+    cj = []
+    to_j, _ = okb.autozoom_target(kc, d['rgb'], W, H, common['fltFocal'], common['fltBaseline'], shift=float(d['shift']), degrid_mode=1,
+                                  counts_out=cj)
+    for chunk in (None, 5):                                                      # default chunk and a ragged one
+        if chunk:
+            os.environ['CSM_AUTOZOOM_CHUNK'] = str(chunk)
+        try:
+            to, cands, counts = ops.process_autozoom(settings, common, return_counts=True)
+        finally:
+            os.environ.pop('CSM_AUTOZOOM_CHUNK', None)
+        assert len(counts) == len(d['counts']) and counts == [int(c) for c in cj]
+        assert to == to_j
+    c_ref = d['counts']
+    assert c_ref[int(np.argmax(counts))] >= c_ref.max() - 0.001 * H * W
+    assert np.abs(np.asarray(counts) - c_ref).max() <= 0.005 * H * W
+
+
+def test_frame_scaledown_and_path_input(tmp_path):
+    """generate_kenburns_config on an image larger than max_size (reference :917 scaledown_maxsize) given as a FILE PATH (:909):
+    the frame is the cv2-INTER_LINEAR restatement of the oracle, instances are resized to it, the rest of the pipeline runs"""
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    import ctypes
+    from PIL import Image
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd import synth
+    from oracle import segment as oseg
+    H, W = 400, 600
+    img = synth.image_u8(H, W, 21)
+    p = str(tmp_path / "in.png")
+    Image.fromarray(img[:, :, ::-1]).save(p)
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=96, max_size=384, refine_crf=False, focal=192.0,
+                         num_frame=2, mask_refine_kwargs={'refine_method': 'none'})
+    pipe = KenBurnsPipeline(cfg)
+    pipe.animeinsseg.set_detect_size(96)
+    kc = pipe.generate_kenburns_config(p)
+    h, w = 256, 384
+    assert (kc.int_height, kc.int_width) == (h, w) and kc['tenRawImage'].shape == (1, 3, h, w)
+    small = np.empty((h, w, 3), np.uint8)
+    oseg.lib().orc_resize_u8_linear(oseg._p(img), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(3), ctypes.c_int(h), ctypes.c_int(w),
+                                    oseg._p(small))
+    got = (kc['tenRawImage'][0].permute(1, 2, 0) * 255.0).round().to(torch.uint8).cpu().numpy()
+    assert np.array_equal(got, small)
+    assert isinstance(kc.original_img_nparray, np.ndarray) and kc.original_img_nparray.shape == (h, w, 3)
+    if not kc.instances.is_empty:
+        assert kc.instances.masks.shape[1:] == (h, w)
+    frames = pipe.autozoom(kc, inpaint=False)
+    assert len(frames) == 2 and frames[0].shape == (h, w, 3)
