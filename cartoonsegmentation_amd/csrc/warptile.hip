@@ -1,0 +1,526 @@
+// warptile.hip -- one Ken Burns output frame (kenburns_effect.py:1027-1040) with the splat done per DESTINATION TILE in LDS.
+//
+// Why: the r01 chain (warp.hip: fill, updateZee, degrid, updateOutput, finalize, fill-holes) spends half of its 142 us in
+// updateOutput, whose 20 fp32 atomics per point go to the L2 atomic units; those retire about one lane-atomic per channel and
+// clock (~0.25 T lane-atomics/s measured on the z pass and on the accumulate pass alike), 50x below what the LDS of 256 CUs
+// sustains.  A wave of consecutive source pixels also lands in one or two 32 x 32 destination tiles.  So:
+//
+//   k_tile_count    per point: process_shift + projection (warp_device.h, the reference's statements), the <= 4 tiles whose
+//                   1-px-expanded area its 2 x 2 footprint touches; ONE integer atomic per distinct tile per wave.
+//   k_tile_scan     exclusive scan of the tile counts (one block), re-arms the counters for the next frame.
+//   k_tile_scatter  same enumeration, writes 16-B entries {fx, fy, fltError, point index} into the tile's segment.
+//   k_tile_render   one 256-thread block per tile, everything else in LDS: z-buffer of the tile + 1-px ring (ds_min_i32 /
+//                   ds_max_u32: float min through the sign-split integer trick), Jacobi degrid, z-test + bilinear splat of
+//                   rgb / depth / weight (ds_add_f32), normalise, depth mask, uint8 frame, masked-depth plane, per-tile hole list.
+//   k_tile_holes    one block per tile that has holes: the 16 x 2 directional rays of fill_disocclusion (common.py:145-248)
+//                   march in an LDS copy of the valid map (tile + 32-px apron), continuing in global memory only beyond it.
+//
+// No float atomic reaches L2, the accumulator planes never exist in HBM, and the z-buffer decisions are the ones of the r01
+// chain bit for bit (min is order free; the degrid is the same Jacobi form; every comparison is the reference's expression).
+// Algorithmic bytes per frame, N points, P pixels: 12N + 12N (two projections) + 16 x 1.2N (entries written) + 2 x 16 x 1.2N
+// (entries read twice, the second time from L2) + 16N (rgb + depth gathers) + 8P (uint8 frame, valid byte, masked depth) ~=
+// 106 B per pixel at N = P (111 MB at 1024^2) -- against 155 B in the r01 structure, with the L2 atomics gone.
+#include "warp_device.h"
+#include <cstdlib>
+
+namespace {
+using namespace csmwarp;
+
+constexpr int kBlock = 256;
+constexpr int TW = 32, TH = 16, TPIX = TW * TH;      // destination tile (one bitmap word wide; 16 rows: 2048 blocks at 1024^2, 6 per CU)
+constexpr int ZW = TW + 2, ZH = TH + 2;              // z-buffer window: tile + 1-px ring (the degrid stencil)
+struct TileGeom { int ntx, nty, nt; };
+__host__ __device__ inline TileGeom tile_geom(int H, int W) {
+    TileGeom g; g.ntx = (W + TW - 1) / TW; g.nty = (H + TH - 1) / TH; g.nt = g.ntx * g.nty; return g;
+}
+__device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// tiles whose expanded area [t*T - 1, t*T + T] meets the footprint [v0, v0 + 1]:  ceil(v0 / T) - 1 <= t <= floor((v0 + 2) / T)
+__device__ __forceinline__ void tile_range(int v0, int T, int nt, int &lo, int &hi) {
+    lo = floor_div(v0 + T - 1, T) - 1;
+    hi = floor_div(v0 + 2, T);
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > nt - 1 ? nt - 1 : hi;
+}
+
+struct Entry { float fx, fy, err; int idx; };        // 16 B
+
+// Binning = counting sort without hot global counters.  (The first version used one global atomicAdd per distinct tile per wave:
+// ~20 k atomics on 1024 adjacent counters = 32 cache lines; same-line device-scope atomics serialise at the memory side and the
+// count pass alone took 49 us.)  Each block owns kPPB consecutive points and histograms their tiles in LDS; per tile it touches
+// it reserves a run in the tile's segment with ONE global atomic (blocks x ~6 tiles, spread over all counters) and remembers
+// the run's start in blockbase[block][tile].  After the scan the scatter pass seeds LDS cursors from tile_off + blockbase and
+// hands out slots with LDS atomics.
+constexpr int kPPT = 4, kPPB = kBlock * kPPT;         // points per thread / per block
+
+struct PointBins { float fx, fy, err; int txl, txh, tyl, tyh; bool ok; };
+
+template <bool SHIFT>
+__device__ __forceinline__ PointBins bins_of_point(const float *__restrict__ pts, int64_t N, int64_t p, const ProjConst &pc, Shift s,
+                                                   const TileGeom &g) {
+    PointBins b; b.fx = b.fy = b.err = 0.f; b.txl = b.tyl = 0; b.txh = b.tyh = -1;
+    b.ok = p < N;
+    if (b.ok) {
+        float x, y, z;
+        load_point<SHIFT>(pts, N, p, s, x, y, z);
+        b.ok = project(x, y, z, pc, b.fx, b.fy, b.err);
+    }
+    if (b.ok) {
+        // a footprint that far out cannot touch the image; the range test also keeps (int)floorf() away from overflow (NaN fails)
+        b.ok = b.fx > -4.0f && b.fy > -4.0f && b.fx < (float)(pc.W + 4) && b.fy < (float)(pc.H + 4);
+        if (b.ok) {
+            const int x0 = (int)floorf(b.fx), y0 = (int)floorf(b.fy);
+            tile_range(x0, TW, g.ntx, b.txl, b.txh);
+            tile_range(y0, TH, g.nty, b.tyl, b.tyh);
+            b.ok = b.txl <= b.txh && b.tyl <= b.tyh;
+        }
+    }
+    return b;
+}
+
+template <bool SHIFT>
+__global__ __launch_bounds__(kBlock) void k_tile_count(const float *__restrict__ pts, int64_t N, ProjConst pc, Shift s, TileGeom g,
+                                                        int *__restrict__ tile_total, int *__restrict__ blockbase) {
+    extern __shared__ int hist[];                     // [nt]
+    for (int t = threadIdx.x; t < g.nt; t += kBlock) hist[t] = 0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * kPPB + threadIdx.x;
+#pragma unroll 2
+    for (int i = 0; i < kPPT; ++i) {
+        const PointBins b = bins_of_point<SHIFT>(pts, N, p0 + (int64_t)i * kBlock, pc, s, g);
+        if (!b.ok) continue;
+        for (int ty = b.tyl; ty <= b.tyh; ++ty)
+            for (int tx = b.txl; tx <= b.txh; ++tx) atomicAdd(&hist[ty * g.ntx + tx], 1);
+    }
+    __syncthreads();
+    int *bb = blockbase + (int64_t)blockIdx.x * g.nt;
+    for (int t = threadIdx.x; t < g.nt; t += kBlock) {
+        const int c = hist[t];
+        if (c) bb[t] = atomicAdd(tile_total + t, c);
+    }
+}
+
+// exclusive scan of a[0..n) in LDS by one block (n <= 8192): consecutive runs per thread + wave shuffle scan + wave totals.
+// On return a[i] holds the exclusive prefix and the function returns the grand total (all threads).
+__device__ __forceinline__ int block_exclusive_scan(int *a, int n, int *wsum /* [kBlock/64] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + kBlock - 1) / kBlock;
+    const int b = tid * per, e = b + per < n ? b + per : n;
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += a[i];
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int run = inc - sum, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { const int v = wsum[w]; run += (w < wave) ? v : 0; total += v; }
+    for (int i = b; i < e; ++i) { const int c = a[i]; a[i] = run; run += c; }
+    __syncthreads();
+    return total;
+}
+
+// Scatter pass.  Every block scans the tile totals itself (8 KB of L2 reads and ~1 us, in parallel on all CUs) instead of waiting
+// for a one-block scan kernel (4.8 us + a kernel boundary); block 0 also publishes the offsets for k_tile_render.
+template <bool SHIFT>
+__global__ __launch_bounds__(kBlock) void k_tile_scatter(const float *__restrict__ pts, int64_t N, ProjConst pc, Shift s, TileGeom g,
+                                                          const int *__restrict__ totals, int *__restrict__ offs,
+                                                          const int *__restrict__ blockbase, Entry *__restrict__ entries) {
+    extern __shared__ int cur[];                      // [nt]; entries of tiles this block does not touch are never used
+    __shared__ int wsum[kBlock / 64];
+    for (int t = threadIdx.x; t < g.nt; t += kBlock) cur[t] = totals[t];
+    __syncthreads();
+    const int total = block_exclusive_scan(cur, g.nt, wsum);
+    const int *bb = blockbase + (int64_t)blockIdx.x * g.nt;
+    if (blockIdx.x == 0) {
+        for (int t = threadIdx.x; t < g.nt; t += kBlock) offs[t] = cur[t];
+        if (threadIdx.x == 0) offs[g.nt] = total;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < g.nt; t += kBlock) cur[t] += bb[t];
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * kPPB + threadIdx.x;
+#pragma unroll 2
+    for (int i = 0; i < kPPT; ++i) {
+        const int64_t p = p0 + (int64_t)i * kBlock;
+        const PointBins b = bins_of_point<SHIFT>(pts, N, p, pc, s, g);
+        if (!b.ok) continue;
+        Entry e; e.fx = b.fx; e.fy = b.fy; e.err = b.err; e.idx = (int)p;
+        for (int ty = b.tyl; ty <= b.tyh; ++ty)
+            for (int tx = b.txl; tx <= b.txh; ++tx) entries[atomicAdd(&cur[ty * g.ntx + tx], 1)] = e;
+    }
+}
+
+// N == 0: no scatter pass runs; publish all-zero offsets
+__global__ __launch_bounds__(kBlock) void k_tile_zero_offs(int *__restrict__ offs, int nt) {
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t <= nt; t += gridDim.x * kBlock) offs[t] = 0;
+}
+
+struct FrameOut {
+    uint8_t *frame;          // [H,W,3]
+    unsigned *vbits;         // [H][ntx]   bit x%32 of word (y, x/32) = masked depth > 0 (fill_disocclusion's validity, common.py:160)
+    unsigned short *cbits;   // [W][cpitch] the same map transposed, 16 rows per half-word: read as 32-bit words (x, y/32)
+    float *mdepth;           // [P]   render[3] * (existing > 0)   (kenburns_effect.py:1039)
+    float *render;           // [4,P] or null
+    unsigned short *holes;   // [nt][TPIX] tile-local pixel ids
+    int *hole_count;         // [nt]
+    int *totals;             // [nt] bin counters of k_tile_count (zeroed here for the next frame)
+    int cpitch;              // half-words per column of cbits (nty rounded up to even)
+};
+
+__device__ __forceinline__ void lds_min_f32(float *addr, float v) {        // warp_device.h::atomic_min_f32 on LDS
+    if (v >= 0.0f) atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}
+
+// Accumulators are 64-bit FIXED POINT in LDS.  Measured on gfx950 (phase ablation of this kernel at 1024^2): splatting the five
+// channels with ds_add_f32 costs 88 us per frame (~0.2 lane-atomics per clock and CU), with ds_add_u64 19 us, and a
+// sort-by-pixel + pull variant without float atomics 37 us (instruction bound).  Every product v * w is formed in fp32 exactly as
+// the reference forms it (VALUE(data) * fltNorthwest, models/utils.py:270-310), converted to a 64-bit integer (2^-40 units for
+// colour and weight, 2^-20 for depth: |v w| < 2^22 resp. 2^42) and added with an integer atomic: the sum is exact, order
+// free -- deterministic, unlike the reference's fp32 atomicAdd -- and rounded to fp32 once at the end, i.e. within one ulp of the
+// exact sum every fp32 summation order approximates.  A positive product never converts to 0, so `existing > 0` and
+// `depth mask > 0` (the decisions fill_disocclusion depends on) are exactly the reference's.
+constexpr float kScaleC = 1099511627776.0f;           // 2^40
+constexpr float kScaleD = 1048576.0f;                 // 2^20
+__device__ __forceinline__ unsigned long long to_fixed(float prod, float scale) {
+    long long q = (long long)(prod * scale);
+    if (q == 0) q = prod > 0.0f ? 1 : (prod < 0.0f ? -1 : 0);
+    return (unsigned long long)q;
+}
+__device__ __forceinline__ float from_fixed(unsigned long long q, double inv_scale) { return (float)((double)(long long)q * inv_scale); }
+
+__global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict__ entries, const int *__restrict__ offs,
+                                                         const float *__restrict__ rgb, const float *__restrict__ depth, int64_t N,
+                                                         int H, int W, TileGeom g, FrameOut out, int dbg) {
+    __shared__ float zee[ZH * ZW];
+    __shared__ float zd[TPIX];
+    __shared__ unsigned long long acc[5 * TPIX];
+    __shared__ unsigned rowbits[TH];
+    __shared__ int nholes;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int tx0 = (t % g.ntx) * TW, ty0 = (t / g.ntx) * TH;
+    for (int i = tid; i < ZH * ZW; i += kBlock) zee[i] = 1000000.0f;        // models/utils.py:59
+    for (int i = tid; i < 5 * TPIX; i += kBlock) acc[i] = 0ull;
+    if (tid == 0) nholes = 0;
+    __syncthreads();
+    const int e0 = offs[t], e1 = offs[t + 1];
+    // ---- updateZee (models/utils.py:101-147) on the window ------------------------------------------------------------------
+    for (int e = e0 + tid; e < e1; e += kBlock) {
+        const Entry en = entries[e];
+        int x0, y0, cx, cy; float w[4];
+        corner_weights(en.fx, en.fy, x0, y0, w);
+        if (!argmax_corner(w, x0, y0, cx, cy)) continue;
+        if (cx < 0 || cx >= W || cy < 0 || cy >= H) continue;
+        const int lx = cx - (tx0 - 1), ly = cy - (ty0 - 1);
+        if (lx < 0 || lx >= ZW || ly < 0 || ly >= ZH) continue;
+        lds_min_f32(&zee[ly * ZW + lx], en.err);
+    }
+    __syncthreads();
+    // ---- updateDegrid (models/utils.py:152-212), Jacobi form ------------------------------------------------------------------
+    for (int i = tid; i < TPIX; i += kBlock) {
+        const int lx = i % TW, ly = i / TW;
+        const int x = tx0 + lx, y = ty0 + ly;
+        const float c = zee[(ly + 1) * ZW + lx + 1];
+        float r = c;
+        if (x < W && y < H) {
+            int cnt = 0; float sum = 0.0f;
+            const int ox[4] = {1, 0, 1, 1}, oy[4] = {0, 1, 1, -1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x1 = x + ox[k], y1 = y + oy[k], x2 = x - ox[k], y2 = y - oy[k];
+                if (x1 < 0 || x1 >= W || y1 < 0 || y1 >= H) continue;
+                if (x2 < 0 || x2 >= W || y2 < 0 || y2 >= H) continue;
+                const float a = zee[(ly + 1 + oy[k]) * ZW + lx + 1 + ox[k]], d = zee[(ly + 1 - oy[k]) * ZW + lx + 1 - ox[k]];
+                if ((double)c >= (double)a + 1.0 && (double)c >= (double)d + 1.0) { cnt += 2; sum += a; sum += d; }
+            }
+            if (cnt > 0) r = fminf(c, sum / (float)cnt);
+        }
+        zd[i] = r;
+    }
+    __syncthreads();
+    // ---- updateOutput (models/utils.py:215-313): z-test + bilinear splat, C = rgb + depth, + the ones channel -------------------
+    for (int e = e0 + tid; e < e1 && !(dbg & 2); e += kBlock) {
+        const Entry en = entries[e];
+        int x0, y0; float w[4];
+        corner_weights(en.fx, en.fy, x0, y0, w);
+        int li[4]; bool pass[4]; bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+            const int lx = cx - tx0, ly = cy - ty0;
+            const bool in = lx >= 0 && lx < TW && ly >= 0 && ly < TH && cx < W && cy < H;      // cx, cy >= 0 follows from lx, ly >= 0
+            li[k] = in ? ly * TW + lx : 0;
+            pass[k] = in && ((double)en.err <= (double)zd[li[k]] + 1.0);
+            any = any || pass[k];
+        }
+        if (!any) continue;
+        const int64_t p = en.idx;
+        const float v0 = rgb[p], v1 = rgb[N + p], v2 = rgb[2 * N + p], v3 = depth[p];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!pass[k]) continue;
+            const float wk = w[k];
+            atomicAdd(&acc[li[k]], to_fixed(v0 * wk, kScaleC));
+            atomicAdd(&acc[TPIX + li[k]], to_fixed(v1 * wk, kScaleC));
+            atomicAdd(&acc[2 * TPIX + li[k]], to_fixed(v2 * wk, kScaleC));
+            atomicAdd(&acc[3 * TPIX + li[k]], to_fixed(v3 * wk, kScaleD));
+            atomicAdd(&acc[4 * TPIX + li[k]], to_fixed(1.0f * wk, kScaleC));
+        }
+    }
+    __syncthreads();
+    // ---- models/utils.py:315 normalise; kenburns_effect.py:1039-1040 depth mask + uint8; hole list for fill_disocclusion --------
+    const int64_t plane = (int64_t)H * W;
+    for (int i = tid; i < TPIX; i += kBlock) {                                // a wave = two 32-px rows of the tile
+        const int lx = i % TW, ly = i / TW;
+        const int x = tx0 + lx, y = ty0 + ly;
+        const bool inside = x < W && y < H;
+        const float e = from_fixed(acc[4 * TPIX + i], 1.0 / 1099511627776.0);
+        const float den = e + 0.0000001f;
+        const float r0 = from_fixed(acc[i], 1.0 / 1099511627776.0) / den, r1 = from_fixed(acc[TPIX + i], 1.0 / 1099511627776.0) / den;
+        const float r2 = from_fixed(acc[2 * TPIX + i], 1.0 / 1099511627776.0) / den, r3 = from_fixed(acc[3 * TPIX + i], 1.0 / 1048576.0) / den;
+        const float m = r3 * (e > 0.0f ? 1.0f : 0.0f);
+        const bool okp = inside && (double)m > 0.0;                             // common.py:160
+        const unsigned long long bits = __ballot(okp);
+        if ((tid & 31) == 0) {
+            rowbits[ly] = (unsigned)(bits >> (tid & 32));
+            if (y < H) out.vbits[(int64_t)y * g.ntx + (t % g.ntx)] = (unsigned)(bits >> (tid & 32));
+        }
+        if (!inside || (dbg & 16)) continue;
+        const int64_t o = (int64_t)y * W + x;
+        out.mdepth[o] = m;
+        if (out.render) { out.render[o] = r0; out.render[plane + o] = r1; out.render[2 * plane + o] = r2; out.render[3 * plane + o] = r3; }
+        out.frame[o * 3 + 0] = to_u8(r0); out.frame[o * 3 + 1] = to_u8(r1); out.frame[o * 3 + 2] = to_u8(r2);
+        if (!okp) out.holes[(int64_t)t * TPIX + atomicAdd(&nholes, 1)] = (unsigned short)i;
+    }
+    __syncthreads();
+    if (tid == 0) { out.hole_count[t] = nholes; out.totals[t] = 0; }           // the bin counter is re-armed for the next frame
+    if (tid < TW && tx0 + tid < W) {                                            // 16 x 32 bit transpose: a half-word per column
+        unsigned c = 0;
+#pragma unroll
+        for (int r = 0; r < TH; ++r) c |= ((rowbits[r] >> tid) & 1u) << r;
+        out.cbits[(int64_t)(tx0 + tid) * out.cpitch + (t / g.ntx)] = (unsigned short)c;
+        if ((g.nty & 1) && t / g.ntx == g.nty - 1) out.cbits[(int64_t)(tx0 + tid) * out.cpitch + g.nty] = 0;   // pad to whole words
+    }
+}
+
+__constant__ float kDirX[16] = {-1, 0, 1, 1, -1, 1, 2, 2, -2, -1, 1, 2, 3, 3, 3, 3};   // common.py:168
+__constant__ float kDirY[16] = {1, 1, 1, 0, 2, 2, 1, -1, 3, 3, 3, 3, 2, 1, -1, -2};    // common.py:169
+
+// fill_disocclusion (common.py:145-248).  Holes are taken from the per-tile lists through a flat index (every block scans the
+// tile hole counts in LDS and binary-searches its holes): all groups of 32 lanes carry the same load wherever the holes are --
+// the r01 kernel's balance without its global append counter.  32 lanes per hole = 16 directions x {from, to}; every lane marches
+// ONE ray through the valid BITMAP (128 KB at 1024^2: cache resident) with 4 speculative steps per round trip; the two axis
+// directions, whose rays run the length of a disoccluded border strip, scan the row / column bitmap a word (32 px) at a time --
+// their steps are exact integers in fp32, so the visited pixels are the same.  A 16-lane lexicographic (distance, direction)
+// minimum then picks the direction exactly like the reference's sequential loop (shortest distance, first direction wins ties).
+__global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g, FrameOut out, int dbg) {
+    extern __shared__ int prefix[];                                              // [nt + 1] exclusive prefix of hole_count
+    __shared__ int wsum[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const int per = (g.nt + kBlock - 1) / kBlock;
+        const int b = tid * per, e = b + per < g.nt ? b + per : g.nt;
+        int sum = 0;
+        for (int i = b; i < e; ++i) sum += out.hole_count[i];
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int run = inc - sum;
+#pragma unroll
+        for (int w2 = 0; w2 < kBlock / 64; ++w2) run += (w2 < wave) ? wsum[w2] : 0;
+        for (int i = b; i < e; ++i) { prefix[i] = run; run += out.hole_count[i]; }
+        if (tid == kBlock - 1) prefix[g.nt] = run;
+        __syncthreads();
+    }
+    const int total = prefix[g.nt];
+    const int lane32 = tid & 31, k = lane32 & 15;
+    const bool to = lane32 >= 16;
+    float dx = kDirX[k], dy = kDirY[k];
+    const float nrm = sqrtf((dx * dx) + (dy * dy));                             // common.py:172-175
+    dx /= nrm; dy /= nrm;
+    const float sx = to ? dx : -dx, sy = to ? dy : -dy;                         // a - d == a + (-d) exactly
+    const int64_t plane = (int64_t)H * W;
+    const int groups = gridDim.x * (kBlock >> 5);
+    for (int h = blockIdx.x * (kBlock >> 5) + (tid >> 5); h < total; h += groups) {
+        int lo = 0, hi = g.nt;                                                  // largest t with prefix[t] <= h
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= h) lo = mid; else hi = mid; }
+        const int t = lo;
+        const int li = out.holes[(int64_t)t * TPIX + (h - prefix[t])];
+        const int x = (t % g.ntx) * TW + li % TW, y = (t / g.ntx) * TH + li / TW;
+        float fx = (float)x, fy = (float)y;
+        int ix = 0, iy = 0;
+        bool ok = false;
+        if ((dbg & 256) && (k == 1 || k == 3)) { ok = false; }
+        else if ((dbg & 128) && k != 1 && k != 3) { ok = false; }
+        else if (k == 3) {
+            // direction (1, 0): the ray visits (x +- j, y) exactly (integer steps are exact in fp32) -> scan the row bitmap by words
+            const unsigned *R = out.vbits + (int64_t)y * g.ntx;
+            if (to) {
+                int q = (x + 1) >> 5;
+                unsigned bits = (x + 1 < W) ? (R[q] & (0xFFFFFFFFu << ((x + 1) & 31))) : 0u;
+                while (bits == 0u && ++q < g.ntx) bits = R[q];
+                ok = bits != 0u; ix = ok ? q * 32 + __ffs((int)bits) - 1 : W; iy = y;
+            } else {
+                int q = (x - 1) >> 5;
+                unsigned bits = (x - 1 >= 0) ? (R[q] & (0xFFFFFFFFu >> (31 - ((x - 1) & 31)))) : 0u;
+                while (bits == 0u && --q >= 0) bits = R[q];
+                ok = bits != 0u; ix = ok ? q * 32 + 31 - __clz((int)bits) : -1; iy = y;
+            }
+        } else if (k == 1) {
+            // direction (0, 1): the same on the transposed bitmap
+            const unsigned *C = reinterpret_cast<const unsigned *>(out.cbits + (int64_t)x * out.cpitch);
+            const int nq = out.cpitch >> 1;                                      // whole 32-row words per column
+            if (to) {
+                int q = (y + 1) >> 5;
+                unsigned bits = (y + 1 < H) ? (C[q] & (0xFFFFFFFFu << ((y + 1) & 31))) : 0u;
+                while (bits == 0u && ++q < nq) bits = C[q];
+                ok = bits != 0u; iy = ok ? q * 32 + __ffs((int)bits) - 1 : H; ix = x;
+            } else {
+                int q = (y - 1) >> 5;
+                unsigned bits = (y - 1 >= 0) ? (C[q] & (0xFFFFFFFFu >> (31 - ((y - 1) & 31)))) : 0u;
+                while (bits == 0u && --q >= 0) bits = C[q];
+                ok = bits != 0u; iy = ok ? q * 32 + 31 - __clz((int)bits) : -1; ix = x;
+            }
+        } else {
+            for (;;) {                                                          // common.py:186-193 / :197-204
+                constexpr int kAhead = 4;        // speculative steps per trip: the positions do not depend on what is read
+                int jx[kAhead], jy[kAhead], v[kAhead];
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) { fx += sx; fy += sy; jx[j] = (int)roundf(fx); jy[j] = (int)roundf(fy); }
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) {
+                    const bool inb = jx[j] >= 0 && jx[j] < W && jy[j] >= 0 && jy[j] < H;
+                    const unsigned word = inb ? out.vbits[(int64_t)jy[j] * g.ntx + (jx[j] >> 5)] : 0u;
+                    v[j] = inb ? (int)((word >> (jx[j] & 31)) & 1u) : 2;        // 2 = left the image: the ray stops, nothing found
+                }
+                int stop = -1;
+#pragma unroll
+                for (int j = kAhead - 1; j >= 0; --j) if (v[j] != 0) stop = j;
+                if (stop >= 0) {
+#pragma unroll
+                    for (int j = 0; j < kAhead; ++j) if (j == stop) { ix = jx[j]; iy = jy[j]; ok = v[j] == 1; }
+                    break;
+                }
+            }
+        }
+        // pair the from/to rays of one direction (lanes k and k+16)
+        const int ox = __shfl_xor(ix, 16), oy = __shfl_xor(iy, 16);
+        const bool ook = __shfl_xor((int)ok, 16) != 0;
+        const int fromx = to ? ox : ix, fromy = to ? oy : iy, tox = to ? ix : ox, toy = to ? iy : oy;
+        const float ddx = (float)(tox - fromx), ddy = (float)(toy - fromy);
+        const float dist = sqrtf(ddx * ddx + ddy * ddy);                        // common.py:208
+        const bool cand = ok && ook && (1000000.0f > dist);                     // fltShortest starts at 1e6, strict >
+        float best = cand ? dist : INFINITY;
+        int bestk = cand ? k : 16;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {                                // 16-lane lexicographic (dist, k) min
+            const float od = __shfl_xor(best, off); const int okk = __shfl_xor(bestk, off);
+            if (od < best || (od == best && okk < bestk)) { best = od; bestk = okk; }
+        }
+        if (bestk < 16) {
+            const int srcl = (tid & 32) + bestk;                                // the "from" lane of the winning direction
+            const int wfx = __shfl(fromx, srcl), wfy = __shfl(fromy, srcl), wtx = __shfl(tox, srcl), wty = __shfl(toy, srcl);
+            const int64_t of = (int64_t)wfy * W + wfx, ot = (int64_t)wty * W + wtx;
+            const float dfrom = out.mdepth[of], dto = out.mdepth[ot];
+            const int64_t so = dfrom < dto ? ot : of;                           // common.py:214-217
+            const int64_t o = (int64_t)y * W + x;
+            if (lane32 < 3) out.frame[o * 3 + lane32] = out.frame[so * 3 + lane32];   // uint8 of the same render value
+            if (out.render && lane32 < 4) out.render[(int64_t)lane32 * plane + o] = out.render[(int64_t)lane32 * plane + so];
+        }
+    }
+}
+
+// scratch layout (bytes, 16-B aligned sections):
+//   header ints : totals[nt] (zero between frames) | offs[nt+1] | hole_count[nt]
+//   vbits[H * ntx] (u32) | cbits[W * cpitch] (u16) | mdepth[P] (f32) | holes[nt * TPIX] (u16) | blockbase[nblocks * nt] (int) |
+//   entries[4 * N] (16 B)
+struct TileScratch { int *totals, *offs, *hole_count; unsigned *vbits; unsigned short *cbits; float *mdepth; unsigned short *holes;
+                     int *blockbase; Entry *entries; int cpitch; };
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+inline size_t header_bytes(int nt) { return align16(sizeof(int) * (size_t)(3 * nt + 1)); }
+inline size_t bin_blocks(int64_t N) { return (size_t)((N + kPPB - 1) / kPPB); }
+struct Sizes { size_t vbits, cbits, mdepth, holes, blockbase; int cpitch; };
+inline Sizes section_sizes(int H, int W, int64_t N) {
+    const TileGeom g = tile_geom(H, W);
+    Sizes z; z.cpitch = g.nty + (g.nty & 1);          // half-words per column, padded to whole 32-row words
+    z.vbits = align16(4 * (size_t)H * g.ntx);
+    z.cbits = align16(2 * (size_t)W * z.cpitch);
+    z.mdepth = align16(4 * (size_t)H * W);
+    z.holes = align16(2 * (size_t)g.nt * TPIX);
+    z.blockbase = align16(4 * bin_blocks(N) * (size_t)g.nt);
+    return z;
+}
+inline TileScratch carve(void *scratch, int H, int W, int nt, int64_t N) {
+    const Sizes z = section_sizes(H, W, N);
+    TileScratch s; char *p = (char *)scratch;
+    s.totals = (int *)p; s.offs = s.totals + nt; s.hole_count = s.offs + nt + 1;
+    p += header_bytes(nt);
+    s.vbits = (unsigned *)p; p += z.vbits;
+    s.cbits = (unsigned short *)p; p += z.cbits;
+    s.mdepth = (float *)p; p += z.mdepth;
+    s.holes = (unsigned short *)p; p += z.holes;
+    s.blockbase = (int *)p; p += z.blockbase;
+    s.entries = (Entry *)p;
+    s.cpitch = z.cpitch;
+    return s;
+}
+
+}  // namespace
+
+extern "C" size_t csm_warp_tile_scratch_bytes(int H, int W, int64_t N) {
+    if (H <= 0 || W <= 0 || N < 0) return 0;
+    const Sizes z = section_sizes(H, W, N);
+    return header_bytes(tile_geom(H, W).nt) + z.vbits + z.cbits + z.mdepth + z.holes + z.blockbase + 16 * 4 * (size_t)N + 16;
+}
+
+extern "C" size_t csm_warp_tile_header_bytes(int H, int W) { return (H <= 0 || W <= 0) ? 0 : header_bytes(tile_geom(H, W).nt); }
+
+// largest tile count the block-local histograms / prefix tables support (LDS: 4 B per tile); larger frames use csm_warp_frame
+extern "C" int csm_warp_tile_supported(int H, int W) { return H > 0 && W > 0 && tile_geom(H, W).nt <= 8192; }
+
+static int g_tile_dbg = -1;
+
+extern "C" int csm_warp_frame_tiled(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal,
+                                    double baseline, float sx, float sy, float sz, void *scratch, float *render_filled,
+                                    uint8_t *frame_u8, void *stream) {
+    CSM_REQUIRE(scratch && frame_u8 && N >= 0 && H > 0 && W > 0 && N < (1ll << 29));
+    CSM_REQUIRE(N == 0 || (pts && rgb && depth));
+    CSM_REQUIRE((((uintptr_t)scratch) & 15) == 0);
+    if (!csm_warp_tile_supported(H, W)) return csm::fail_arg("frame too large for the tiled path (more than 8192 tiles): use csm_warp_frame");
+    if (g_tile_dbg < 0) { const char *e = getenv("CSM_TILE_DBG"); g_tile_dbg = e ? atoi(e) : 0; }   // measurement aid (phase ablation)
+    hipStream_t st = (hipStream_t)stream;
+    const TileGeom g = tile_geom(H, W);
+    const TileScratch ts = carve(scratch, H, W, g.nt, N);
+    const ProjConst pc = make_proj(H, W, focal, baseline);
+    const Shift s{sx, sy, sz};
+    const size_t lds = sizeof(int) * (size_t)(g.nt + 1);
+    const unsigned nb = (unsigned)bin_blocks(N);
+    int rc;
+    if (N > 0) {
+        k_tile_count<true><<<nb, kBlock, lds, st>>>(pts, N, pc, s, g, ts.totals, ts.blockbase);
+        rc = csm::check_launch("k_tile_count"); if (rc) return rc;
+    }
+    if (N > 0) {
+        k_tile_scatter<true><<<nb, kBlock, lds, st>>>(pts, N, pc, s, g, ts.totals, ts.offs, ts.blockbase, ts.entries);
+        rc = csm::check_launch("k_tile_scatter"); if (rc) return rc;
+    } else {
+        k_tile_zero_offs<<<8, kBlock, 0, st>>>(ts.offs, g.nt);
+        rc = csm::check_launch("k_tile_zero_offs"); if (rc) return rc;
+    }
+    FrameOut out{frame_u8, ts.vbits, ts.cbits, ts.mdepth, render_filled, ts.holes, ts.hole_count, ts.totals, ts.cpitch};
+    if (!(g_tile_dbg & 64)) {
+        k_tile_render<<<g.nt, kBlock, 0, st>>>(ts.entries, ts.offs, rgb, depth, N, H, W, g, out, g_tile_dbg);
+        rc = csm::check_launch("k_tile_render"); if (rc) return rc;
+    }
+    if (!(g_tile_dbg & 32)) {
+        static int hb = 0;
+        if (!hb) { const char *e = getenv("CSM_TILE_HOLE_BLOCKS"); hb = e ? atoi(e) : 1024; if (hb < 1) hb = 1024; }
+        k_tile_holes<<<hb, kBlock, lds, st>>>(H, W, g, out, g_tile_dbg);
+        rc = csm::check_launch("k_tile_holes"); if (rc) return rc;
+    }
+    return CSM_OK;
+}

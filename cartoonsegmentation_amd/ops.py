@@ -227,22 +227,44 @@ def process_autozoom(objSettings, objCommon, return_counts=False):
 class WarpFrame:
     """Fused per-frame warp of KenBurnsPipeline.process_kenburns (kenburns_effect.py:1027-1040):
     process_shift -> render_pointcloud(cat[rgb,depth]) -> fill_disocclusion -> uint8 HWC.
-    Owns the scratch so the frame loop allocates nothing."""
+    Owns the scratch so the frame loop allocates nothing.  path 'tiled' (default): destination-tile binning + LDS splat
+    (csm_warp_frame_tiled); 'atomics': the global-atomic chain of csm_warp_frame (CSM_WARP_PATH selects)."""
 
-    def __init__(self, H, W, device, keep_render=False):
-        self.H, self.W = H, W
-        n = _lib.load().csm_warp_frame_scratch_floats(i32(H), i32(W))
-        self.scratch = torch.empty(n, dtype=torch.float32, device=device)
+    def __init__(self, H, W, device, keep_render=False, path=None):
+        import os
+        self.H, self.W, self.device = H, W, device
+        self.path = path or os.environ.get('CSM_WARP_PATH', 'tiled')
+        assert self.path in ('tiled', 'atomics')
         self.frame = torch.empty((H, W, 3), dtype=torch.uint8, device=device)
         self.render = torch.empty((1, 4, H, W), dtype=torch.float32, device=device) if keep_render else None
+        self.scratch, self._cap = None, -1
+        if self.path == 'atomics':
+            n = _lib.load().csm_warp_frame_scratch_floats(i32(H), i32(W))
+            self.scratch = torch.empty(n, dtype=torch.float32, device=device)
+
+    def _tile_scratch(self, N):
+        if N > self._cap:                                  # the point cloud grows when inpainting appends points
+            L = _lib.load()
+            cap = int(N * 1.25) + 1024
+            nbytes = L.csm_warp_tile_scratch_bytes(i32(self.H), i32(self.W), i64(cap))
+            self.scratch = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            hdr = (L.csm_warp_tile_header_bytes(i32(self.H), i32(self.W)) + 3) // 4
+            self.scratch[:hdr].zero_()                     # the bin counters must start at zero; every frame re-arms them
+            self._cap = cap
+        return self.scratch
 
     def __call__(self, tenPoints, tenImage, tenDepth, fltFocal, fltBaseline, shift, stream=None):
         N = tenPoints.shape[2]
         sx, sy, sz = _f32x3(shift)
         st = stream_ptr() if stream is None else stream
-        check(_lib.load().csm_warp_frame(ptr(tenPoints), ptr(tenImage), ptr(tenDepth), i64(N), i32(self.H), i32(self.W),
-                                         f64(fltFocal), f64(fltBaseline), sx, sy, sz, ptr(self.scratch),
-                                         ptr(self.render), ptr(self.frame), st), "warp_frame")
+        if self.path == 'tiled':
+            check(_lib.load().csm_warp_frame_tiled(ptr(tenPoints), ptr(tenImage), ptr(tenDepth), i64(N), i32(self.H), i32(self.W),
+                                                   f64(fltFocal), f64(fltBaseline), sx, sy, sz, ptr(self._tile_scratch(N)),
+                                                   ptr(self.render), ptr(self.frame), st), "warp_frame_tiled")
+        else:
+            check(_lib.load().csm_warp_frame(ptr(tenPoints), ptr(tenImage), ptr(tenDepth), i64(N), i32(self.H), i32(self.W),
+                                             f64(fltFocal), f64(fltBaseline), sx, sy, sz, ptr(self.scratch),
+                                             ptr(self.render), ptr(self.frame), st), "warp_frame")
         return self.frame, self.render
 
 

@@ -403,9 +403,11 @@ class AnimeInsSeg:
         feat, ld, fh, fw = self._mask_feat_of(d, mask_feat)          # the caller's tensor, as in the reference
         n = int(idx.numel())
         logits = torch.empty((n, fh, fw), dtype=torch.float32, device=self.device)
+        # named, so both gathers are alive when the kernel is enqueued: two temporaries in one argument list can be handed the SAME
+        # block by the caching allocator (the first is released before the second is allocated)
+        ker_sel, pri_sel = d['kernels'][idx].contiguous(), d['priors'][idx].contiguous()
         check(L.csm_maskhead_logits(ptr(feat), i32(ld), i32(fh), i32(fw), i32(cfg.num_prototypes), i32(cfg.dyconv_channels),
-                                    ptr(d['kernels'][idx].contiguous()), ptr(d['priors'][idx].contiguous()), i32(n),
-                                    i32(cfg.strides[0]), ptr(logits), stream_ptr()), "maskhead")
+                                    ptr(ker_sel), ptr(pri_sel), i32(n), i32(cfg.strides[0]), ptr(logits), stream_ptr()), "maskhead")
         masks = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
         check(L.csm_mask_resize_threshold(ptr(logits), i32(n), i32(fh), i32(fw), i32(cfg.strides[0]), i32(long_side),
                                           i32(long_side), i32(H), i32(W), f32(0.5), ptr(masks), stream_ptr()), "mask_resize")

@@ -98,6 +98,19 @@ int csm_warp_frame(const float *pts, const float *rgb, const float *depth, int64
                    double focal, double baseline, float sx, float sy, float sz, float *scratch,
                    float *render_filled, uint8_t *frame_u8, void *stream);
 
+/* The same frame as csm_warp_frame with the splat done per destination tile in LDS (warptile.hip): points are binned by the
+ * 32 x 32 tile(s) their footprint touches (integer atomics only), then one block per tile builds the z-buffer window, degrids,
+ * z-tests, accumulates (LDS float atomics), normalises and writes the uint8 frame; holes are filled per tile from an LDS copy of
+ * the valid map.  Same decisions (z-buffer, coverage, fill sources) as csm_warp_frame; colours equal up to fp32 summation order,
+ * which is unordered in the reference as well.
+ * scratch: csm_warp_tile_scratch_bytes(H, W, N) bytes, 16-B aligned; its first csm_warp_tile_header_bytes(H, W) bytes must be
+ * ZERO before the first call (hipMemset once after allocation) -- every call leaves them re-armed for the next frame. */
+size_t csm_warp_tile_scratch_bytes(int H, int W, int64_t N);
+size_t csm_warp_tile_header_bytes(int H, int W);
+int csm_warp_frame_tiled(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal,
+                         double baseline, float sx, float sy, float sz, void *scratch, float *render_filled, uint8_t *frame_u8,
+                         void *stream);
+
 /* Coverage search of process_autozoom   anime_3dkenburns/common.py:86-142, batched.
  * For each of K candidate camera shifts (sx_k, sy_k, shift_z) -- the float32 tenShift of process_shift (common.py:74) --
  * counts[k] = number of pixels with tenExisting > 0 after process_shift + render_pointcloud of pts [1,3,N]

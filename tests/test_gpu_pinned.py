@@ -29,7 +29,8 @@ def test_maskhead_logits_vs_reference_text(name):
     h, w = feat.shape[:2]
     n = len(d['priors'])
     logits = torch.empty((n, h, w), device='cuda')
-    check(_lib.load().csm_maskhead_logits(ptr(feat), i32(8), i32(h), i32(w), i32(8), i32(8), ptr(dev(d['kernels'])), ptr(dev(d['priors'])),
+    ker, pri = dev(d['kernels']), dev(d['priors'])                                # kept alive across the launch
+    check(_lib.load().csm_maskhead_logits(ptr(feat), i32(8), i32(h), i32(w), i32(8), i32(8), ptr(ker), ptr(pri),
                                           i32(n), i32(8), ptr(logits), stream_ptr()), "maskhead")
     ref = d['logits']
     assert np.abs(logits.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max()))
@@ -67,7 +68,8 @@ def test_refine_glue_vs_reference_text(name):
     H, W = img.shape[:2]
     n = d['masks_in'].shape[0]
     batch = torch.empty((n, 4, T, T), device='cuda')
-    check(L.csm_refine_prepare_batch(ptr(dev(img)), ptr(dev(d['masks_in'].astype(np.uint8))), i32(n), i32(H), i32(W), i32(H), i32(W),
+    img_d, masks_d = dev(img), dev(d['masks_in'].astype(np.uint8))               # kept alive across the launch
+    check(L.csm_refine_prepare_batch(ptr(img_d), ptr(masks_d), i32(n), i32(H), i32(W), i32(H), i32(W),
                                      i32(H), i32(W), i32(H), i32(W), i32(T), ptr(batch), stream_ptr()), "prepare")
     assert np.array_equal(batch.cpu().numpy(), d['batch'])
     raw = []
@@ -140,16 +142,16 @@ def test_frame_scaledown_and_path_input(tmp_path):
     from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
     from cartoonsegmentation_amd import synth
     from oracle import segment as oseg
-    H, W = 400, 600
+    H, W = 640, 960
     img = synth.image_u8(H, W, 21)
     p = str(tmp_path / "in.png")
     Image.fromarray(img[:, :, ::-1]).save(p)
-    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=96, max_size=384, refine_crf=False, focal=192.0,
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=96, max_size=600, refine_crf=False, focal=300.0,
                          num_frame=2, mask_refine_kwargs={'refine_method': 'none'})
     pipe = KenBurnsPipeline(cfg)
     pipe.animeinsseg.set_detect_size(96)
     kc = pipe.generate_kenburns_config(p)
-    h, w = 256, 384
+    h, w = 400, 600
     assert (kc.int_height, kc.int_width) == (h, w) and kc['tenRawImage'].shape == (1, 3, h, w)
     small = np.empty((h, w, 3), np.uint8)
     oseg.lib().orc_resize_u8_linear(oseg._p(img), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(3), ctypes.c_int(h), ctypes.c_int(w),

@@ -131,11 +131,16 @@ def _frame_case(ops, H, W, seed, extra=0):
     return sc, pts, rgb, dep, shift
 
 
-@pytest.mark.parametrize("H,W,extra", [(96, 128, 0), (250, 333, 5000), (1024, 1024, 0)])
-def test_warp_frame_fused_vs_oracle(ops, H, W, extra):
+@pytest.mark.parametrize("path", ["tiled", "atomics"])
+@pytest.mark.parametrize("H,W,extra", [(96, 128, 0), (250, 333, 5000), (1024, 1024, 0), (1024, 1024, 600000)])
+def test_warp_frame_fused_vs_oracle(ops, H, W, extra, path):
+    """both frame paths (tile-binned LDS splat / global-atomic chain) against the oracle frame; the second call re-uses the
+    scratch (the tile counters must be re-armed by the first)"""
     sc, pts, rgb, dep, shift = _frame_case(ops, H, W, 1234, extra)
-    wf = ops.WarpFrame(H, W, 'cuda', keep_render=True)
-    frame, render = wf(dev(pts), dev(rgb), dev(dep), sc['focal'], sc['baseline'], shift)
+    wf = ops.WarpFrame(H, W, 'cuda', keep_render=True, path=path)
+    d_pts, d_rgb, d_dep = dev(pts), dev(rgb), dev(dep)
+    wf(d_pts, d_rgb, d_dep, sc['focal'], sc['baseline'], [0.5 * v for v in shift])
+    frame, render = wf(d_pts, d_rgb, d_dep, sc['focal'], sc['baseline'], shift)
     frame, render = frame.cpu().numpy(), render.cpu().numpy()
     filled_o, existing_o, frame_o = orc.warp_frame(pts, np.concatenate([rgb, dep], 1), H, W, sc['focal'], sc['baseline'],
                                                    np.asarray(shift, np.float32), degrid_mode=1)
@@ -148,6 +153,39 @@ def test_warp_frame_fused_vs_oracle(ops, H, W, extra):
     r, e = ops.render_pointcloud(ps, dev(np.concatenate([rgb, dep], 1)), W, H, sc['focal'], sc['baseline'])
     f2 = ops.fill_disocclusion(r, r[:, 3:4] * (e > 0.0).float())
     assert close_frac(f2.cpu().numpy(), render, 1e-3, 1e-5) >= 0.9995
+
+
+def test_tiled_frame_edge_cases(ops):
+    """tile path: empty cloud, clouds entirely outside the image / behind the camera, image sizes that are not multiples of the
+    32 x 32 tile, a cloud that piles onto a few pixels (one tile gets every entry)"""
+    from cartoonsegmentation_amd import synth
+    H, W = 45, 70
+    wf = ops.WarpFrame(H, W, 'cuda', keep_render=True, path='tiled')
+    z3, z1 = torch.zeros(1, 3, 0, device='cuda'), torch.zeros(1, 1, 0, device='cuda')
+    frame, render = wf(z3, z3, z1, 35.0, 40.0, [0.0, 0.0, 0.0])
+    assert int(frame.max()) == 0 and float(render.abs().max()) == 0.0
+    pts = torch.tensor([[[0.0, 1e4, -1e4, 0.0, 3.0], [0.0, 0.0, 0.0, 0.0, 1e5], [-5.0, 10.0, 10.0, 0.0005, 20.0]]], device='cuda')
+    frame, render = wf(pts, torch.ones(1, 3, 5, device='cuda'), torch.ones(1, 1, 5, device='cuda'), 35.0, 40.0, [0.0, 0.0, 0.0])
+    assert int(frame.max()) == 0
+    sc, p, rgb, dep, shift = _frame_case(ops, H, W, 77)
+    for path in ('tiled', 'atomics'):
+        w2 = ops.WarpFrame(H, W, 'cuda', keep_render=True, path=path)
+        fr, rn = w2(dev(p), dev(rgb), dev(dep), sc['focal'], sc['baseline'], shift)
+        fo, eo, fro = orc.warp_frame(p, np.concatenate([rgb, dep], 1), H, W, sc['focal'], sc['baseline'], np.asarray(shift, np.float32), 1)
+        assert close_frac(rn.cpu().numpy(), fo) >= 0.999, path
+        assert (np.abs(fr.cpu().numpy().astype(np.int32) - fro.astype(np.int32)) <= 1).mean() >= 0.999, path
+    # pile-up: 20000 points within a 3 x 3 px neighbourhood
+    g = np.random.default_rng(5)
+    n = 20000
+    z = g.uniform(30, 60, n).astype(np.float32)
+    xy = g.uniform(-0.02, 0.02, (2, n)).astype(np.float32) * z
+    pp = np.stack([xy[0], xy[1], z])[None].astype(np.float32)
+    cc = g.uniform(0, 1, (1, 3, n)).astype(np.float32)
+    dd = z[None, None].copy()
+    fr, rn = wf(dev(pp), dev(cc), dev(dd), 35.0, 40.0, [0.0, 0.0, 0.0])
+    fo, eo, fro = orc.warp_frame(pp, np.concatenate([cc, dd], 1), H, W, 35.0, 40.0, np.zeros(3, np.float32), 1)
+    assert close_frac(rn.cpu().numpy(), fo, 1e-3, 1e-4) >= 0.999
+    assert (np.abs(fr.cpu().numpy().astype(np.int32) - fro.astype(np.int32)) <= 1).mean() >= 0.999
 
 
 def test_properties_full_size(ops):
