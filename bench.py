@@ -3,9 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one 1024x1024 frame per rank (weak scaling: every
-rank owns its own frames; outputs are gathered to rank 0 over RCCL inside the
-timed region).  Inputs are synthetic, seeded and already resident in HBM when timing starts.
+A "step" is one pass of the hot path over `--batch` (default 8) 1024x1024 frames per rank (weak
+scaling: every rank owns its own frames, 8 per rank = BASELINE configs[3]'s 64 frames on 8 GPUs;
+SURVEY.md 8e; outputs are gathered to rank 0 over RCCL inside the timed region).  Inputs are synthetic, seeded and already resident in HBM when timing starts.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel,
 HIP-event timed on the launch stream) and `cpu_baseline` (the oracle timed on this host).
 """
@@ -32,9 +32,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--workload", default="auto", help="auto | warp | frame")
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step (frame workload)")
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (frame workload); 8 per rank = BASELINE configs[3] "
+                                                        "(64 frames on 8 GPUs), and the same per-rank work at every N (weak scaling)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra single-GPU measurements (batch / instances / det size / video)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=90.0, help="budget of the host-side oracle run (full-size nets; stages that "
+                                                                    "would not fit are scaled from the measured GFLOP/s and say so)")
     return ap.parse_args()
 
 
@@ -159,7 +162,7 @@ class FrameWorkload(Workload):
     name = "seg+depth+warp"
     INSTANCES = 2
 
-    def __init__(self, size, rank, device, batch=16):
+    def __init__(self, size, rank, device, batch=8):
         self.frames_per_step = batch
         os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"          # no checkpoints exist offline: closed-form weights
         # every rank builds the same closed-form weights (a rank with placeholder zeros finds no instance, builds no ISNet and
@@ -173,9 +176,10 @@ class FrameWorkload(Workload):
         self.pipe = KenBurnsPipeline(cfg, device=str(device))
         self.pipe.max_instances = self.INSTANCES          # synthetic weights score every prior ~0.49: cap like infer(max_instances=)
         self.pipe.overlap_depth = os.environ.get("CSM_OVERLAP_DEPTH", "1") == "1"
-        self.imgs = [torch.from_numpy(synth.image_u8(size, size, 1234 + 64 * rank + k)).to(device) for k in range(batch)]
+        self.all_imgs = [torch.from_numpy(synth.image_u8(size, size, 1234 + 64 * rank + k)).to(device) for k in range(max(batch, 16))]
+        self.imgs = self.all_imgs[:batch]
         self.wf = ops.WarpFrame(size, size, device)
-        self.out = torch.empty((batch, size, size, 3), dtype=torch.uint8, device=device)
+        self.out = torch.empty((max(batch, 16), size, size, 3), dtype=torch.uint8, device=device)
         self.n_inst = None
 
     def step(self):
@@ -194,7 +198,92 @@ class FrameWorkload(Workload):
             pw, ph = int(0.97 * W), int(0.97 * H)
             check(load().csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0), ptr(self.out[k]),
                                             stream_ptr()))
-        return self.out
+        return self.out[:self.frames_per_step]
+
+    # ---- extra single-GPU measurements (batch 1 = BASELINE configs[1..2], n instances in {1, 8}, det 1024, the video) ----
+    def _fps(self, batch=None, instances=None, det=None, steps=3):
+        """frames/s of step() under a variant of the configuration (one untimed step builds + tunes whatever is new)"""
+        keep = (self.frames_per_step, self.imgs, self.pipe.max_instances, self.pipe.animeinsseg.default_det_size)
+        try:
+            if batch is not None:
+                self.frames_per_step, self.imgs = batch, self.all_imgs[:batch]
+            if instances is not None:
+                self.pipe.max_instances = instances
+            if det is not None:
+                self.pipe.animeinsseg.set_detect_size(det)
+            self.step(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            return {"frames_per_s": round(steps * self.frames_per_step / dt, 2), "ms_per_frame": round(dt / (steps * self.frames_per_step) * 1e3, 3),
+                    "batch": self.frames_per_step, "instances_found": self.n_inst, "det_size": self.pipe.animeinsseg.default_det_size}
+        finally:
+            self.frames_per_step, self.imgs, self.pipe.max_instances = keep[0], keep[1], keep[2]
+            self.pipe.animeinsseg.set_detect_size(keep[3])
+
+    def _video(self):
+        """run_kenburns.py on one 1024x1024 image with the shipped yaml's switches (configs/3dkenburns.yaml: inpainting, 75 frames,
+        depth_field): 1 seg + 1 depth + autozoom search + 2 inpaint passes + 75 x (warp + bokeh + crop/resize)."""
+        pipe = self.pipe
+        def once(stages=None):
+            t = [time.perf_counter()]
+            def mark():
+                if stages is not None:
+                    torch.cuda.synchronize(); t.append(time.perf_counter())
+            kc = pipe.generate_kenburns_config(self.all_imgs[0]); mark()
+            kc.depth_field, kc.num_frame = True, 75
+            objFrom = {'fltCenterU': kc.int_width / 2.0, 'fltCenterV': kc.int_height / 2.0,
+                       'intCropWidth': int(np.floor(0.97 * kc.int_width)), 'intCropHeight': int(np.floor(0.97 * kc.int_height))}
+            objTo = pipe.process_autozoom({'fltShift': 100.0, 'fltZoom': 1.25, 'objFrom': objFrom}, kc); mark()
+            frames, _ = pipe.process_kenburns({'fltSteps': np.linspace(0.0, 1.0, kc.num_frame).tolist(), 'objFrom': objFrom, 'objTo': objTo,
+                                               'boolInpaint': True}, kc, True, False, to_numpy=False)
+            torch.cuda.synchronize(); t.append(time.perf_counter())
+            if stages is not None:
+                stages.update(config_ms=round((t[1] - t[0]) * 1e3, 2), autozoom_ms=round((t[2] - t[1]) * 1e3, 2),
+                              inpaint_and_75_frames_ms=round((t[3] - t[2]) * 1e3, 2), points_after_inpaint=int(kc['tenInpaPoints'].shape[2]))
+            return len(frames)
+        once(); torch.cuda.synchronize()                       # builds the Inpaint programs
+        st = {}
+        once(st)
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(2):
+            n += once()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        st.update(video_ms=round(dt * 1e3, 2), output_frames_per_s=round(75 / dt, 1), videos_per_s=round(1 / dt, 2),
+                  what="1 seg + 1 depth + autozoom (256 candidates) + 2 inpaint + 75 x (warp + bokeh + crop/resize), 1024x1024, frames stay on the device")
+        return st
+
+    def _warp_points(self):
+        """the warp chain by itself (csm_warp_frame_tiled), HIP-event timed: N = P at 1024^2 and the L3-spilling 2048^2 point"""
+        from cartoonsegmentation_amd import synth
+        out = {}
+        for size in (1024, 2048):
+            sc = synth.warp_scene(size, size, 1234)
+            disp = torch.from_numpy(sc['disp']).to(self.device)
+            disp = disp / disp.max() * sc['baseline']
+            depth, _, pts, _ = self.ops.disparity_to_points(disp, sc['focal'], sc['baseline'])
+            pts, dep, rgb = pts.view(1, 3, -1).contiguous(), depth.view(1, 1, -1).contiguous(), torch.from_numpy(sc['rgb']).to(self.device)
+            loc = int(depth.argmin().item())
+            settings, common = synth.shift_request(sc, float(depth.min().item()), (loc % size, loc // size))
+            shift = self.ops.shift_vector(settings, common)
+            for path in ("tiled", "atomics"):
+                wf = self.ops.WarpFrame(size, size, self.device, path=path)
+                ms = event_time_ms(lambda: wf(pts, rgb, dep, sc['focal'], sc['baseline'], shift), 50, warm=5)
+                alg = 155.0 * size * size                       # SURVEY 8d: B_warp = 155 P bytes per frame for N = P, C = 4
+                out["%s_%d" % (path, size)] = {"us_per_frame": round(ms * 1e3, 2), "algorithmic_bytes": alg,
+                                               "GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        return out
+
+    def variants(self):
+        v = {"batch1": self._fps(batch=1), "batch16": self._fps(batch=16), "instances1": self._fps(instances=1),
+             "instances8": self._fps(instances=8), "det1024_batch4": self._fps(batch=4, det=1024), "video": self._video(),
+             "warp_chain": self._warp_points()}
+        v["reference_shaped_ratio"] = "1 seg + 1 depth + 75 warps: see video (inpaint_and_75_frames_ms vs config_ms)"
+        return v
 
     def weight_buffers(self):
         """the three packed weight buffers, created if this rank's first step did not need them (e.g. no instance -> no ISNet run):
@@ -277,10 +366,10 @@ class FrameWorkload(Workload):
 
     def cpu_baseline(self, seconds):
         from oracle import frame as oframe
-        return oframe.cpu_baseline(seconds)
+        return oframe.cpu_baseline(seconds, frame=self.H, instances=self.INSTANCES)
 
 
-def make_workload(kind, size, rank, device, world, dist, batch=16):
+def make_workload(kind, size, rank, device, world, dist, batch=8):
     if kind in ("auto", "frame"):
         wl = FrameWorkload(size, rank, device, batch)
     elif kind == "warp":
@@ -327,12 +416,34 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if dist is not None:
+        # multi-rank start-up: rank 0 builds the weights and tunes the conv tiles, the others wait, then build with the tile table
+        # rank 0 saved (CSM_TUNE_CACHE: no tuning launches on 7 of 8 ranks) and with PLACEHOLDER weights (zeros of the right shapes):
+        # what they compute with arrives through the RCCL broadcast below, like a checkpoint read by rank 0 would
+        os.environ.setdefault("CSM_TUNE_CACHE", "/tmp/csm_tune_%s_%s.txt" % (os.environ.get("MASTER_PORT", "0"), a.size))
+        if rank != 0:
+            os.environ["CSM_WEIGHTS_PLACEHOLDER"] = "1"
     wl = make_workload(a.workload, a.size, rank, device, world, dist, a.batch)
 
-    wl.step_and_gather()                      # compiles the layer programs (lazy) -- untimed
-    bcast_bytes = wl.broadcast_weights() if (dist is not None and hasattr(wl, "broadcast_weights")) else 0
-    if dist is not None:
-        wl.step_and_gather()                  # ranks != 0 now hold real weights: build/tune whatever their first step skipped -- untimed
+    weights_equal = None
+    if dist is None:
+        wl.step_and_gather()                  # compiles the layer programs (lazy) -- untimed
+        bcast_bytes = 0
+    else:
+        if rank == 0:
+            wl.step(); torch.cuda.synchronize()       # builds + tunes + saves the tile table -- untimed
+        dist.barrier()
+        if rank != 0:
+            wl.step(); torch.cuda.synchronize()       # same programs, tiles from the table, placeholder weights -- untimed
+        dist.barrier()
+        bcast_bytes = wl.broadcast_weights() if hasattr(wl, "broadcast_weights") else 0
+        if hasattr(wl, "weight_buffers"):             # every rank must now hold rank 0's weights bit for bit
+            sums = torch.stack([w.double().sum() for w in wl.weight_buffers()])
+            hi, lo = sums.clone(), sums.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            weights_equal = bool(torch.equal(hi, lo)) and bool((hi != 0).all())
+            assert weights_equal, "weights differ between ranks after the broadcast"
+        wl.step_and_gather()                  # ranks != 0 now hold real weights: build whatever their first step skipped -- untimed
     for _ in range(a.warmup):
         wl.step_and_gather()
     if dist is not None:
@@ -362,8 +473,12 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline(a.cpu_seconds)
         out.update(wl.extra())
+        if world == 1 and not a.no_variants and hasattr(wl, "variants"):
+            out["variants"] = wl.variants()
         if world > 1:
             out["weights_broadcast_bytes"] = bcast_bytes
+            out["weights_equal_after_broadcast"] = weights_equal
+            out["tile_table"] = os.environ.get("CSM_TUNE_CACHE")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

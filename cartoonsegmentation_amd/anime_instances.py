@@ -9,14 +9,27 @@ from typing import List
 import numpy as np
 import torch
 
-# utils/constants.py:63-67 palette access (get_color(idx) -> BGR tuple); own palette values
-_PALETTE = [(56, 56, 255), (151, 157, 255), (31, 112, 255), (29, 178, 255), (49, 210, 207), (10, 249, 72), (23, 204, 146),
-            (134, 219, 61), (52, 147, 26), (187, 212, 0), (168, 153, 44), (255, 194, 0), (147, 69, 52), (255, 115, 100),
-            (236, 24, 0), (255, 56, 132), (133, 0, 82), (255, 56, 203), (200, 149, 255), (199, 55, 255)]
+class Colors:
+    """instance colours of the notebook / draw_instances: utils/constants.py:44-57 (hex table -> RGB, returned as BGR by default)"""
+    _HEX = ('FF1010', '10FF10', 'FFF010', '100FFF', '0018EC', 'FF3838', 'FF9D97', 'FF701F', 'FFB21D', 'CFD231', '48F90A', '92CC17',
+            '3DDB86', '1A9334', '00D4BB', '2C99A8', '00C2FF', '344593', '6473FF', '0018EC', '8438FF', '520085', 'CB38FF', 'FF95C8',
+            'FF37C7')
+
+    def __init__(self):
+        self.palette = [tuple(int(h[i:i + 2], 16) for i in (0, 2, 4)) for h in self._HEX]
+        self.n = len(self.palette)
+
+    def __call__(self, i, bgr=True):
+        r, g, b = self.palette[int(i) % self.n]
+        return (b, g, r) if bgr else (r, g, b)
+
+
+colors = Colors()
 
 
 def get_color(idx):
-    return _PALETTE[int(idx) % len(_PALETTE)]
+    """utils/constants.py:59-63"""
+    return 255 if idx == -1 else colors(idx)
 
 
 class AnimeInstances:

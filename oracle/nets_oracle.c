@@ -118,6 +118,90 @@ static void orc_conv(const csm_op *op, view_t in, view_t res, view_t out, const 
     }
 }
 
+/* The same convolution, organised for speed (bench.py's cpu_baseline times the full-size nets with it): identical fmaf chains --
+ * same operands, same order, taps outside the image skipped, channels >= cin skipped -- but the weights are first re-laid in CHAIN
+ * order per output channel (unit-stride reads instead of a kh*kw stride), and four output channels advance together so that four
+ * independent chains hide the FMA latency.  tests/test_oracle_nets.py asserts bit-equality with orc_conv on every feature
+ * (groups, stride, dilation, ragged cin / cout, split-K).  ORC_CONV_REFERENCE=1 selects the plain loop nest. */
+static void orc_conv_fast(const csm_op *op, view_t in, view_t res, view_t out, const float *W, const float *bias,
+                          const float *slope)
+{
+    const int kh = op->kh, kw = op->kw, cin = op->cin_g, cout = op->cout_g, G = op->groups, taps = kh * kw;
+    const int ncb = (cin + 31) / 32, S = op->ksplit > 1 ? op->ksplit : 1, Tall = taps * ncb;
+    const int64_t M = (int64_t)out.n * out.h * out.w;
+    int *cidx = (int *)malloc(sizeof(int) * (size_t)ncb * 32), *ncnt = (int *)malloc(sizeof(int) * ncb);
+    int *koff = (int *)malloc(sizeof(int) * (ncb + 1)), *run_of = (int *)malloc(sizeof(int) * Tall);
+    int Ktot = 0;
+    for (int cb = 0; cb < ncb; ++cb) {            /* channels of the block in chain order: 8-blocks, then 0,4,1,5,2,6,3,7 */
+        int n = 0;
+        for (int kb = cb * 32; kb < cb * 32 + 32 && kb < cin; kb += 8)
+            for (int t = 0; t < 4; ++t)
+                for (int h = 0; h < 2; ++h) { int c = kb + 4 * h + t; if (c < cin) cidx[cb * 32 + n++] = c; }
+        ncnt[cb] = n; koff[cb] = Ktot; Ktot += n * taps;
+    }
+    koff[ncb] = Ktot;
+    for (int chunk = 0; chunk < Tall; ++chunk) {
+        int run = 0;
+        if (S > 1) { run = (int)(((int64_t)(chunk + 1) * S - 1) / Tall); while ((int64_t)run * Tall / S > chunk) --run; while ((int64_t)(run + 1) * Tall / S <= chunk) ++run; }
+        run_of[chunk] = run;
+    }
+    float *Wt = (float *)malloc(sizeof(float) * (size_t)G * cout * Ktot);
+#pragma omp parallel for schedule(static)
+    for (int oc = 0; oc < G * cout; ++oc)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int tp = 0; tp < taps; ++tp)
+                for (int i = 0; i < ncnt[cb]; ++i)
+                    Wt[(int64_t)oc * Ktot + koff[cb] + tp * ncnt[cb] + i] = W[((int64_t)oc * cin + cidx[cb * 32 + i]) * taps + tp];
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t m = 0; m < M; ++m) {
+        int n = (int)(m / ((int64_t)out.h * out.w));
+        int rem = (int)(m - (int64_t)n * out.h * out.w);
+        int oy = rem / out.w, ox = rem - oy * out.w;
+        const float *xp[64];                        /* kh * kw <= 49 in every net */
+        for (int ky = 0; ky < kh; ++ky)
+            for (int kx = 0; kx < kw; ++kx) {
+                int iy = oy * op->stride - op->pad + ky * op->dil, ix = ox * op->stride - op->pad + kx * op->dil;
+                xp[ky * kw + kx] = (iy < 0 || iy >= in.h || ix < 0 || ix >= in.w) ? NULL
+                                   : in.p + ((int64_t)(n * in.h + iy) * in.w + ix) * in.ld;
+            }
+        for (int g = 0; g < G; ++g)
+            for (int co = 0; co < cout; co += 4) {
+                const int nco = cout - co < 4 ? cout - co : 4, oc0 = g * cout + co;
+                float part[16][4];
+                for (int s_ = 0; s_ < S; ++s_) part[s_][0] = part[s_][1] = part[s_][2] = part[s_][3] = 0.0f;
+                for (int j = 0; j < nco; ++j) part[0][j] = bias ? bias[oc0 + j] : 0.0f;
+                const float *w0 = Wt + (int64_t)oc0 * Ktot, *w1 = w0 + (nco > 1 ? Ktot : 0), *w2 = w0 + (nco > 2 ? 2 * (int64_t)Ktot : 0),
+                            *w3 = w0 + (nco > 3 ? 3 * (int64_t)Ktot : 0);
+                for (int cb = 0; cb < ncb; ++cb) {
+                    const int nc = ncnt[cb];
+                    const int *ci = cidx + cb * 32;
+                    for (int tp = 0; tp < taps; ++tp) {
+                        if (!xp[tp]) continue;
+                        const float *x = xp[tp] + g * cin;
+                        const int run = run_of[cb * taps + tp], k0 = koff[cb] + tp * nc;
+                        float a0 = part[run][0], a1 = part[run][1], a2 = part[run][2], a3 = part[run][3];
+                        for (int i = 0; i < nc; ++i) {
+                            const float xv = x[ci[i]];
+                            a0 = fmaf(xv, w0[k0 + i], a0); a1 = fmaf(xv, w1[k0 + i], a1);
+                            a2 = fmaf(xv, w2[k0 + i], a2); a3 = fmaf(xv, w3[k0 + i], a3);
+                        }
+                        part[run][0] = a0; part[run][1] = a1; part[run][2] = a2; part[run][3] = a3;
+                    }
+                }
+                for (int j = 0; j < nco; ++j) {
+                    const int oc = oc0 + j;
+                    float acc = part[0][j];
+                    for (int s_ = 1; s_ < S; ++s_) acc += part[s_][j];
+                    if (op->res_mode == 1 && res.p) acc += res.p[m * res.ld + oc];
+                    acc = orc_act(acc, op->act, slope ? slope[oc] : 0.0f);
+                    if (op->res_mode == 2 && res.p) acc += res.p[m * res.ld + oc];
+                    out.p[m * out.ld + oc] = acc;
+                }
+            }
+    }
+    free(Wt); free(cidx); free(ncnt); free(koff); free(run_of);
+}
+
 /* depthwise: weights natural [c][kh][kw] */
 static void orc_dwconv(const csm_op *op, view_t in, view_t out, const float *W, const float *bias, const float *slope)
 {
@@ -264,7 +348,11 @@ int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
         const float *B = op->b_off >= 0 ? weights + op->b_off : NULL;
         const float *S = op->aux_off >= 0 ? weights + op->aux_off : NULL;
         switch (op->kind) {
-            case CSM_OP_CONV: orc_conv(op, in, in1, out, W, B, S); break;
+            case CSM_OP_CONV: {
+                const char *e = getenv("ORC_CONV_REFERENCE");
+                if (e && e[0] == '1') orc_conv(op, in, in1, out, W, B, S); else orc_conv_fast(op, in, in1, out, W, B, S);
+                break;
+            }
             case CSM_OP_DWCONV: orc_dwconv(op, in, out, W, B, S); break;
             case CSM_OP_MAXPOOL: orc_maxpool(op, in, out); break;
             case CSM_OP_BILINEAR: orc_bilinear(op, in, out); break;

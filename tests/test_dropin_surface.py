@@ -1,0 +1,55 @@
+"""CPU: every name the reference's callers import from the hot path's packages resolves in this repo: the
+drop-in import surface run_kenburns.py / run_kenburns_batch.py / run_segmentation.ipynb / kenburns_effect.py rely on."""
+import inspect
+
+
+def test_reference_import_statements_resolve():
+    from animeinsseg import AnimeInsSeg, AnimeInstances                                       # notebook cell 0, kenburns_effect.py:16
+    from animeinsseg.anime_instances import get_color                                         # notebook cell 0
+    from anime_3dkenburns import KenBurnsPipeline, npyframes2video                            # run_kenburns.py:7
+    from anime_3dkenburns.kenburns_effect import KenBurnsConfig, KenBurnsPipeline as K2       # naive_interface.py
+    from anime_3dkenburns.common import process_autozoom, process_shift, render_pointcloud, fill_disocclusion   # kenburns_effect.py:22
+    from anime_3dkenburns.models.utils import spatial_filter, depth_to_points                 # kenburns_effect.py:21
+    from utils.io_utils import find_all_imgs, scaledown_maxsize, resize_pad                   # run_kenburns_batch.py:9, animeinsseg/__init__.py:26
+    from utils.effects import bokeh_blur                                                      # kenburns_effect.py:14
+    from utils.constants import (DEFAULT_INPAINTNET_CKPT, DEFAULT_DEPTHREFINE_CKPT, DEFAULT_DETECTOR_CKPT, DEFAULT_DEVICE,  # :24
+                                 DEPTH_ZOE_CKPT, CATEGORIES, get_color as gc2)
+    assert K2 is KenBurnsPipeline and callable(process_autozoom) and gc2(3) == get_color(3)
+    assert DEFAULT_DETECTOR_CKPT.endswith('rtmdetl_e60.ckpt') and DEFAULT_DEVICE in ('cuda', 'cpu') and CATEGORIES[0]['id'] == 0
+    assert DEFAULT_INPAINTNET_CKPT and DEFAULT_DEPTHREFINE_CKPT and DEPTH_ZOE_CKPT
+    # signatures of the entry points (reference animeinsseg/__init__.py:187-189, :402-418; kenburns_effect.py:394, :898, :953, :979)
+    sig = inspect.signature(AnimeInsSeg.__init__).parameters
+    assert list(sig)[1:] == ['ckpt', 'default_det_size', 'device', 'refine_kwargs', 'tagger_path', 'mask_thr']
+    sig = inspect.signature(AnimeInsSeg.infer).parameters
+    assert list(sig)[1:17] == ['imgs', 'pred_score_thr', 'refine_kwargs', 'output_type', 'det_size', 'save_dir', 'save_visualization',
+                               'save_annotation', 'infer_tags', 'obj_id_start', 'img_id_start', 'verbose', 'infer_grey', 'save_mask_only',
+                               'val_dir', 'max_instances']
+    assert list(inspect.signature(KenBurnsPipeline.generate_kenburns_config).parameters)[1:] == ['img', 'instances', 'verbose', 'savep']
+    assert list(inspect.signature(KenBurnsPipeline.process_kenburns).parameters)[1:5] == ['objSettings', 'objCommon', 'inpaint', 'verbose']
+    assert list(inspect.signature(bokeh_blur).parameters) == ['img', 'depth', 'num_samples', 'lightness_factor', 'depth_factor', 'use_cuda',
+                                                             'focal_plane']
+    assert list(inspect.signature(scaledown_maxsize).parameters) == ['img', 'max_size', 'divisior']
+    assert AnimeInstances().is_empty and len(get_color(0)) == 3 and npyframes2video and find_all_imgs and resize_pad
+    assert spatial_filter and depth_to_points and process_shift and render_pointcloud and fill_disocclusion and KenBurnsConfig
+
+
+def test_get_color_is_the_reference_palette():
+    """utils/constants.py:44-57: hex table -> BGR tuples (the notebook draws with these)"""
+    from utils.constants import get_color
+    assert get_color(0) == (16, 16, 255) and get_color(1) == (16, 255, 16) and get_color(5) == (56, 56, 255)
+    assert get_color(25) == get_color(0) and get_color(-1) == 255
+
+
+def test_io_utils_host_logic(tmp_path):
+    import numpy as np
+    from PIL import Image
+    from utils.io_utils import find_all_imgs, imread, resize_pad, scaledown_size
+    a = np.random.default_rng(0).integers(0, 255, (20, 30, 3), dtype=np.uint8)
+    Image.fromarray(a[:, :, ::-1]).save(tmp_path / "a.png")
+    (tmp_path / "b.txt").write_text("x")
+    assert find_all_imgs(str(tmp_path)) == ['a.png'] and find_all_imgs(str(tmp_path), abs_path=True)[0].endswith('a.png')
+    assert np.array_equal(imread(str(tmp_path / "a.png")), a)                      # BGR like mmcv.imread
+    assert scaledown_size(1080, 1920, 1024) == (576, 1024) and scaledown_size(1500, 1000, 720) == (720, 480)
+    assert scaledown_size(600, 400, 640, 32) == (608, 416) and scaledown_size(100, 50, 720) == (100, 50)
+    img, pads = resize_pad(a, 32, pad_value=(0, 0, 0))                             # no scaling needed: pure host padding
+    assert img.shape == (32, 32, 3) and pads == (0, 12, 0, 2) and np.array_equal(img[:20, :30], a) and img[20:].max() == 0

@@ -280,3 +280,26 @@ def test_depth_glue_ops_vs_numpy():
     assert got[0] == float(norm.min()) and got[1] == float(norm.max())
     assert got[2] == float(crop.min()) and got[3] == float(crop.max())
     assert int(got[4]) == int(crop.argmin()) and int(got[5]) == int(crop.argmax())      # first row-major occurrence, like numpy / cv2
+
+
+def test_bench_two_ranks_end_to_end(tmp_path):
+    """bench.py's multi-rank path as the driver launches it (torch.distributed.run, 2 ranks), on ONE GPU over gloo (a logic check,
+    not a measurement): rank 1 builds with placeholder weights and rank 0's tile table, receives the weights through the
+    broadcast, the uint8 outputs are gathered, one JSON line comes out with global_batch = 2 x batch."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CSM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CSM_SYNTHETIC_WEIGHTS="1",
+               CSM_TUNE_CACHE=str(tmp_path / "tiles.txt"), CSM_BENCH_WATCHDOG="500")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "2", "--size", "320", "--steps", "1",
+           "--warmup", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["frames_per_gpu_step"] == 2
+    assert d["weights_broadcast_bytes"] > 1e8 and d["weights_equal_after_broadcast"] is True
+    assert d["value"] > 0 and d["scaling"] == "weak" and "roofline" in d
+    assert os.path.getsize(tmp_path / "tiles.txt") > 0

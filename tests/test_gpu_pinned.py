@@ -163,3 +163,33 @@ def test_frame_scaledown_and_path_input(tmp_path):
         assert kc.instances.masks.shape[1:] == (h, w)
     frames = pipe.autozoom(kc, inpaint=False)
     assert len(frames) == 2 and frames[0].shape == (h, w, 3)
+
+
+def test_run_kenburns_call_sequence_on_1920x1080_with_the_shipped_yaml(tmp_path, monkeypatch):
+    """run_kenburns.py:19-42 verbatim on a 1920 x 1080 image file with configs/3dkenburns.yaml's keys (max_size 1024 < image:
+    the frame is scaled down, BASELINE configs[0]'s example has this shape): KenBurnsPipeline(cfg path) ->
+    generate_kenburns_config(img) -> autozoom -> frames.  Only num_frame is cut (75 -> 3) and the checkpoints are closed-form."""
+    import yaml
+    from PIL import Image
+    monkeypatch.setenv("CSM_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("CSM_AUTOTUNE", "0")                      # built-in tile rule: this test is about function, not speed
+    from anime_3dkenburns import KenBurnsPipeline
+    from cartoonsegmentation_amd import synth
+    from utils.io_utils import imread
+    cfg = {'inpaint_type': 'default', 'detector': 'animeinsseg', 'num_frame': 3, 'playback': True, 'dof_speed': 50, 'depth_field': True,
+           'max_size': 1024, 'ldm_inpaint_size': 1024, 'sd_img2img_url': 'http://127.0.0.1:7860/sdapi/v1/img2img',
+           'mask_refine_kwargs': {'refine_method': 'refinenet_isnet', 'refine_size': 720}, 'depth_est': 'leres', 'depth_est_size': 640,
+           'det_ckpt': 'synthetic', 'det_size': 640, 'pred_score_thr': 0.3, 'refine_crf': False, 'depth_factor': 1}
+    cfgp = tmp_path / "3dkenburns.yaml"
+    cfgp.write_text(yaml.safe_dump(cfg))
+    imgp = str(tmp_path / "kenburns_lion.png")
+    Image.fromarray(synth.image_u8(1080, 1920, 3)[:, :, ::-1]).save(imgp)
+    kpipe = KenBurnsPipeline(str(cfgp))
+    kpipe.max_instances = 2                                      # closed-form weights score every prior alike: cap like infer(max_instances=)
+    img = imread(imgp)                                           # mmcv.imread stand-in
+    kcfg = kpipe.generate_kenburns_config(img, verbose=False, savep=str(tmp_path / "out.mp4"))
+    assert (kcfg.int_height, kcfg.int_width) == (576, 1024) and kcfg['tenRawPoints'].shape == (1, 3, 576 * 1024)
+    assert kcfg.instances.is_empty or kcfg.instances.masks.shape[1:] == (576, 1024)
+    frames = kpipe.autozoom(kcfg, verbose=False)
+    assert len(frames) == 3 and all(f.shape == (576, 1024, 3) and f.dtype == np.uint8 for f in frames)
+    assert kcfg.playback is True
