@@ -25,7 +25,7 @@ import torch
 from . import _lib, ops
 from ._lib import check, f32, i32, i64, ptr, stream_ptr
 from .anime_instances import AnimeInstances
-from .nets import build_inpaint_context, build_inpaint_grid, build_leres, build_refine
+from .nets import build_disparity, build_inpaint_context, build_inpaint_grid, build_leres, build_refine, build_semantics
 from .runtime import CompiledProgram
 from .segmentation import AnimeInsSeg, scaledown_size
 from .weights import StateDictWeights, SynthWeights
@@ -217,9 +217,12 @@ class KenBurnsPipeline:
             self.animeinsseg = AnimeInsSeg(ckpt, device=str(self.device))
 
     def set_depth_estimation(self, depth_est: str):
+        if depth_est == 'default':                       # kenburns_effect.py:547-548: the original 3D-Ken-Burns estimator
+            self._set_default_estimator()
+            return
         if depth_est != 'leres':
-            raise NotImplementedError("depth_est %r: LeReS is the shipped default (configs/3dkenburns.yaml:39); zoe/marigold "
-                                      "need un-vendored sources (SURVEY F3/F4)" % depth_est)
+            raise NotImplementedError("depth_est %r: 'leres' (the shipped yaml) and 'default' (sniklaus Disparity + VGG19-BN) are built; "
+                                      "zoe / marigold need un-vendored sources (SURVEY F3/F4)" % depth_est)
         if self._leres_ws is None:
             p = os.environ.get('CSM_LERES_CKPT', 'models/leres/res101.pth')
             if not os.path.exists(p) and not _synthetic_ok():
@@ -230,6 +233,51 @@ class KenBurnsPipeline:
             else:
                 self._leres_ws = SynthWeights('leres.')
         self._depth_est = self._depth_est_leres
+
+    def _set_default_estimator(self):
+        """anime_3dkenburns/models/__init__.py:33-52: Semantics (torchvision vgg19_bn) + Disparity (network-disparity.pytorch)"""
+        if getattr(self, '_disp_ws', None) is None:
+            pd_, pv = 'models/kenburns/network-disparity.pytorch', 'models/kenburns/vgg19_bn.pth'
+            if os.path.exists(pd_) and os.path.exists(pv):
+                sd = torch.load(pd_, map_location='cpu', weights_only=False)
+                self._disp_ws = StateDictWeights({k.replace('module', 'net'): v for k, v in sd.items()})      # models/__init__.py:42
+                vg = torch.load(pv, map_location='cpu', weights_only=False)
+                from .nets.disparity import VGG
+                ren = {}
+                for e in VGG:                                 # torchvision names features.<i>.* -> the reference module's netVgg.<slice>.<i>.*
+                    if e != 'M':
+                        for i in (e[1], e[1] + 1):
+                            for k, v in vg.items():
+                                if k.startswith('features.%d.' % i):
+                                    ren['netVgg.%d.%d.%s' % (e[0], i, k.split('.', 2)[2])] = v
+                self._sem_ws = StateDictWeights(ren)
+            elif _synthetic_ok() or str(self.cfg.det_ckpt).startswith('synthetic'):
+                self._disp_ws, self._sem_ws = SynthWeights('disparity.'), SynthWeights('semantics.')
+            else:
+                raise FileNotFoundError("%s / %s (the reference downloads them with torch.hub / torchvision; set "
+                                        "CSM_SYNTHETIC_WEIGHTS=1 for closed-form weights)" % (pd_, pv))
+            self._disp_progs = {}
+        self._depth_est = self._depth_est_default
+
+    def _depth_est_default(self, img_tensor, img_d):
+        """disparity_estimation (anime_3dkenburns/models/__init__.py:43-52): bilinear resize to <= 512, VGG19-BN semantics, GridNet;
+        returns the disparity at HALF that resolution (depth_adjustment / Refine bring it back, kenburns_effect.py:49-52, :619-622)"""
+        if img_tensor is None:
+            img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+        H, W = int(img_tensor.shape[2]), int(img_tensor.shape[3])
+        ratio = float(W) / float(H)
+        w, h = min(int(512 * ratio), 512), min(int(512 / ratio), 512)
+        x = torch.nn.functional.interpolate(img_tensor, size=(h, w), mode='bilinear', align_corners=False).contiguous()
+        if (h, w) not in self._disp_progs:
+            self._disp_progs[(h, w)] = (CompiledProgram(build_semantics(self._sem_ws, h, w), self.device),
+                                        CompiledProgram(build_disparity(self._disp_ws, h, w), self.device))
+        sp, dp = self._disp_progs[(h, w)]
+        sb = next(b for b in sp.prog.bufs if b.ext == 1)
+        sem = torch.empty((1, 512, sb.h, sb.w), dtype=torch.float32, device=self.device)
+        sp.run(x, sem)
+        out = torch.empty((1, 1, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=self.device)
+        dp.run(x, sem, out)
+        return out
 
     def set_depth_refinement(self, depth_refinement: str):
         """kenburns_effect.py:820-829: 'default' = the Ken Burns `Refine` net"""

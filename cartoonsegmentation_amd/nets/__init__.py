@@ -4,3 +4,4 @@ from .leres import build_leres  # noqa: F401
 from .rtmdet import build_rtmdet, RTMDetConfig  # noqa: F401
 from .refine import build_refine  # noqa: F401
 from .inpaint import build_inpaint_context, build_inpaint_grid  # noqa: F401
+from .disparity import build_semantics, build_disparity  # noqa: F401

@@ -99,6 +99,7 @@ class Buf:
         self.offset = None
         self.first, self.last = None, None
         self.keep = False          # outputs / persistent tensors are never recycled
+        self.alias = None          # crop_rows(): a view of another buffer's first rows (shares its storage and lifetime)
 
 
 class T:
@@ -169,8 +170,10 @@ class Program:
             if t is None:
                 continue
             b = t.buf
-            b.first = i if b.first is None else b.first
-            b.last = i
+            while b is not None:                       # a row-crop view keeps the buffer it aliases alive
+                b.first = i if b.first is None else b.first
+                b.last = i
+                b = b.alias
         self.ops.append(op)
         return out
 
@@ -288,6 +291,15 @@ class Program:
     def copy(self, x, out):
         return self._emit(OP_COPY, x, None, out)
 
+    def crop_rows(self, x, h):
+        """the first h rows of a single-image map as a VIEW (torch's negative bottom pad): same buffer, smaller height"""
+        assert x.n == 1 and 0 < h <= x.h and x.coff == 0 and x.c == x.buf.c
+        b = Buf(1, h, x.w, x.buf.c)
+        b.alias = x.buf
+        b.first, b.last = x.buf.first, x.buf.last
+        self.bufs.append(b)
+        return T(self, b, 0, x.c)
+
     def gavgpool(self, x):
         out = self.buffer(x.n, 1, 1, x.c)
         return self._emit(OP_GAVGPOOL, x, None, out)
@@ -308,7 +320,7 @@ class Program:
         free, top = [], 0            # free: list of (offset, size)
         by_first, by_last = {}, {}
         for b in self.bufs:
-            if b.ext >= 0 or b.first is None:
+            if b.ext >= 0 or b.first is None or b.alias is not None:
                 continue
             b.size = (b.n * b.h * b.w * b.c + ALIGN - 1) // ALIGN * ALIGN
             by_first.setdefault(b.first, []).append(b)
@@ -337,6 +349,9 @@ class Program:
                     else:
                         merged.append((off, sz))
                 free = merged
+        for b in self.bufs:
+            if b.alias is not None:
+                b.offset = b.alias.offset
         self.workspace_floats = top
         return top
 

@@ -96,8 +96,42 @@ def inpaint_case():
     print('inpaint', float(out['tenExisting'].mean()), float(out['tenImage'].mean()), float(out['tenDisparity'].mean()))
 
 
+def disparity_case():
+    """Semantics (VGG19-BN slices) + Disparity GridNet of anime_3dkenburns/models/disparity_estimation.py.  torchvision is absent:
+    `torchvision.models.vgg19_bn` is supplied with torchvision's published cfg 'E' + batch norm ([EXT]); which of its entries are
+    used, the ceil-mode pools, the input flip / normalisation and the whole GridNet are the reference's own text."""
+    import types
+    nn = torch.nn
+
+    def vgg19_bn(pretrained=False, **kw):
+        layers, c = [], 3
+        for v in [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(c, v, kernel_size=3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+                c = v
+        return types.SimpleNamespace(features=nn.Sequential(*layers))
+    sys.modules['torchvision.models'].vgg19_bn = vgg19_bn
+    sys.modules['torchvision'].models = sys.modules['torchvision.models']
+    ref_loader._bare("anime_3dkenburns"); ref_loader._bare("anime_3dkenburns.models")
+    m = ref_loader.load_by_path("anime_3dkenburns.models.disparity_estimation", "anime_3dkenburns/models/disparity_estimation.py")
+    sem = fill_synthetic(m.Semantics(), 'semantics.')
+    dis = fill_synthetic(m.Disparity(), 'disparity.')
+    for tag, (h, w) in (('96x64', (96, 64)), ('64x128', (64, 128))):
+        g = np.random.default_rng(300 + h)
+        x = g.uniform(0, 1, (1, 3, h, w)).astype(np.float32)
+        with torch.no_grad():
+            s_ = sem(torch.from_numpy(x))
+            d = dis(torch.from_numpy(x), s_)
+        np.savez_compressed(os.path.join(HERE, 'net_disparity_%s.npz' % tag), x=x, sem=s_.numpy(), disp=d.numpy())
+        print('disparity', tag, tuple(s_.shape), float(s_.mean()), tuple(d.shape), float(d.mean()), float(d.std()))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['isnet', 'leres']
+    if 'disparity' in which:
+        disparity_case()
     if 'isnet' in which:
         isnet_cases()
     if 'leres' in which:

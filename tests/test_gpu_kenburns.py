@@ -303,3 +303,23 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert d["weights_broadcast_bytes"] > 1e8 and d["weights_equal_after_broadcast"] is True
     assert d["value"] > 0 and d["scaling"] == "weak" and "roofline" in d
     assert os.path.getsize(tmp_path / "tiles.txt") > 0
+
+
+def test_default_depth_estimator_pipeline():
+    """depth_est='default' + default_depth_refine (the commented 'original 3dkenburns' block of configs/3dkenburns.yaml):
+    VGG19-BN semantics + Disparity GridNet at <= 512, depth adjustment through the resize branch, Refine back to the frame size"""
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd import synth
+    img = synth.image_u8(320, 384, 51)
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='default', default_depth_refine=True, max_size=512, refine_crf=False, focal=192.0,
+                         num_frame=2, mask_refine_kwargs={'refine_method': 'none'})
+    pipe = KenBurnsPipeline(cfg)
+    pipe.max_instances = 2
+    pipe.animeinsseg.set_detect_size(96)
+    coarse = pipe._depth_est(None, torch.from_numpy(img).cuda())
+    assert coarse.shape == (1, 1, 213, 256) and float(coarse.min()) >= 0.0 and torch.isfinite(coarse).all()
+    kc = pipe.generate_kenburns_config(img)
+    assert kc['tenRawDisparity'].shape == (1, 1, 320, 384) and torch.isfinite(kc['tenRawPoints']).all()
+    frames = pipe.autozoom(kc, inpaint=False)
+    assert len(frames) == 2 and frames[0].shape == (320, 384, 3)

@@ -245,3 +245,22 @@ def test_program_run_is_hipgraph_capturable():
     y2 = y.clone()
     cp.run(xin, y); torch.cuda.synchronize()
     assert torch.equal(y, y2) and not torch.equal(y2, eager)
+
+
+@pytest.mark.parametrize("tag,h,w", [("96x64", 96, 64), ("64x128", 64, 128)])
+def test_disparity_estimator_vs_reference_modules(tag, h, w):
+    """`depth_est: default` -- Semantics (VGG19-BN slices) and the Disparity GridNet on the HIP engine against the reference's own
+    modules (tests/golden/make_golden_nets.py disparity; 96x64 takes the odd-height crop of disparity_estimation.py:172)"""
+    from cartoonsegmentation_amd.nets import build_disparity, build_semantics
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    from cartoonsegmentation_amd.weights import SynthWeights
+    g = dict(np.load(os.path.join(GOLDEN, "net_disparity_%s.npz" % tag)))
+    dev = torch.device('cuda')
+    x = torch.from_numpy(g['x']).to(dev)
+    sem = torch.empty(g['sem'].shape, device=dev)
+    CompiledProgram(build_semantics(SynthWeights('semantics.'), h, w), dev).run(x, sem)
+    assert np.abs(sem.cpu().numpy() - g['sem']).max() <= 1e-4 * np.abs(g['sem']).max()
+    d = torch.empty(g['disp'].shape, device=dev)
+    CompiledProgram(build_disparity(SynthWeights('disparity.'), h, w), dev).run(x, torch.from_numpy(g['sem']).to(dev), d)
+    assert np.abs(d.cpu().numpy() - g['disp']).max() <= 1e-4 * np.abs(g['disp']).max()
+    assert float(d.min()) >= 0.0

@@ -75,3 +75,50 @@ def test_inpaint_forward_vs_reference():
     # Jacobi degrid (the HIP build's deterministic semantics): same coverage except a handful of pixels
     o1 = okb.inpaint_forward(g['img'], g['disp'], g['shift'], g['seg'], W, H, W / 2.0, 40.0, ctx, grid, degrid_mode=1)
     assert (o1['existing'] == g['existing']).mean() > 0.99
+
+
+@pytest.mark.parametrize("tag,h,w", [("96x64", 96, 64), ("64x128", 64, 128)])
+def test_disparity_estimator_vs_reference_modules(tag, h, w):
+    """`depth_est: default`: Semantics (VGG19-BN slices, ceil-mode pools, flip + normalise) and the 6 x 4 Disparity GridNet
+    (disparity_estimation.py:80-193) lowered to layer programs vs the reference's own modules; 96x64 takes the odd-height crop"""
+    from cartoonsegmentation_amd.nets import build_disparity, build_semantics
+    g = dict(np.load(os.path.join(GOLDEN, "net_disparity_%s.npz" % tag)))
+    sem = np.zeros_like(g['sem'])
+    onets.run_program(build_semantics(SynthWeights('semantics.'), h, w), [g['x'], sem])
+    assert rel_err(sem, g['sem']) < 1e-5
+    d = np.zeros_like(g['disp'])
+    onets.run_program(build_disparity(SynthWeights('disparity.'), h, w), [g['x'], g['sem'], d])
+    assert rel_err(d, g['disp']) < 1e-5 and d.min() >= 0
+
+
+def test_fast_conv_is_bit_identical_to_the_reference_loop(monkeypatch):
+    """oracle/nets_oracle.c::orc_conv_fast (chain-ordered weights, four chains in flight: what bench.py's cpu_baseline times) vs the
+    plain loop nest orc_conv: every output bit, on groups / stride / dilation / ragged channel counts / split-K / 7x7 / residuals"""
+    from cartoonsegmentation_amd.program import Program
+    rng = np.random.default_rng(9)
+    cases = [dict(cin=40, cout=37, k=3, stride=1, pad=1, dil=1, groups=1, hw=(19, 23)),
+             dict(cin=64, cout=64, k=3, stride=2, pad=1, dil=1, groups=8, hw=(20, 20)),
+             dict(cin=96, cout=130, k=1, stride=1, pad=0, dil=1, groups=1, hw=(9, 11)),
+             dict(cin=32, cout=16, k=3, stride=1, pad=4, dil=4, groups=1, hw=(17, 17)),
+             dict(cin=4, cout=20, k=7, stride=2, pad=3, dil=1, groups=1, hw=(30, 26)),
+             dict(cin=512, cout=24, k=3, stride=1, pad=1, dil=1, groups=1, hw=(6, 6))]          # small map, long K -> split-K
+    for c in cases:
+        p = Program("t")
+        H, W = c['hw']
+        x_ext = p.ext_nchw(1, c['cin'], H, W)
+        x = p.to_nhwc(x_ext)
+        w = rng.normal(0, 0.2, (c['cout'], c['cin'] // c['groups'], c['k'], c['k'])).astype(np.float32)
+        b = rng.normal(0, 0.1, c['cout']).astype(np.float32)
+        y = p.conv(x, w, b, stride=c['stride'], pad=c['pad'], dil=c['dil'], groups=c['groups'], act='silu')
+        y2 = p.conv(y, rng.normal(0, 0.2, (c['cout'], c['cout'], 1, 1)).astype(np.float32), None, act='relu', res=y, res_mode=2)
+        out_ext = p.ext_nchw(1, c['cout'], y2.h, y2.w)
+        p.to_nchw(y2, out_ext)
+        p.plan()
+        xin = rng.normal(0, 1, (1, c['cin'], H, W)).astype(np.float32)
+        o_fast, o_ref = np.zeros((1, c['cout'], y2.h, y2.w), np.float32), np.zeros((1, c['cout'], y2.h, y2.w), np.float32)
+        monkeypatch.delenv("ORC_CONV_REFERENCE", raising=False)
+        onets.run_program(p, [xin, o_fast])
+        monkeypatch.setenv("ORC_CONV_REFERENCE", "1")
+        onets.run_program(p, [xin, o_ref])
+        assert np.array_equal(o_fast, o_ref), c
+        assert np.isfinite(o_ref).all() and np.abs(o_ref).max() > 0
