@@ -46,8 +46,37 @@ __device__ __forceinline__ float csm_expf(float x) {
     return e * __int_as_float(((int)n + 127) << 23);
 }
 
+// natural logarithm of a positive normal float (Cephes logf: mantissa in [sqrt(1/2), sqrt(2)), degree-8 polynomial); restated in the oracle
+__device__ __forceinline__ float csm_logf(float x) {
+    int bits = __float_as_int(x);
+    int e = ((bits >> 23) & 0xff) - 126;
+    float m = __int_as_float((bits & 0x007fffff) | 0x3f000000);        // [0.5, 1)
+    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+    const float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = fmaf(y, m, -1.1514610310e-1f); y = fmaf(y, m, 1.1676998740e-1f); y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f); y = fmaf(y, m, -1.6668057665e-1f); y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f); y = fmaf(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    const float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(z, -0.5f, y);
+    return fmaf(fe, 0.693359375f, m + y);
+}
+// erf, Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7), on the same expf
+__device__ __forceinline__ float csm_erff(float x) {
+    const float ax = fabsf(x);
+    const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+    float p = 1.061405429f;
+    p = fmaf(p, t, -1.453152027f); p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - (p * t) * csm_expf(-(ax * ax));
+    return x < 0.0f ? -r : r;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     switch (act) {
+        case CSM_ACT_SOFTPLUS: return v > 20.0f ? v : csm_logf(1.0f + csm_expf(v));
+        case CSM_ACT_GELU: return (0.5f * v) * (1.0f + csm_erff(v * 0.707106781186547524f));
         case CSM_ACT_RELU: return fmaxf(v, 0.0f);
         case CSM_ACT_SILU: return v / (1.0f + csm_expf(-v));
         case CSM_ACT_PRELU: return v >= 0.0f ? v : v * slope;
@@ -1083,6 +1112,58 @@ __global__ __launch_bounds__(256) void k_eltwise(View a, View b, View out, int a
     out.p[pix * out.ld + c] = apply_act(v, act, slope ? slope[c] : 0.0f);
 }
 
+// ZoeDepth attractor update (attractor.py:117-208, memory_efficient loop): out_k = b_k + agg_i dist(A_i - b_k)
+__global__ __launch_bounds__(256) void k_attractor(View A, View b, View out, const float *__restrict__ par, int flags) {
+    const float alpha = par[0];
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)out.n * out.h * out.w * out.c;
+    if (idx >= total) return;
+    int k = (int)(idx % out.c); int64_t pix = idx / out.c;
+    const float c = b.p[pix * b.ld + k];
+    const float *a = A.p + pix * A.ld;
+    float delta = 0.0f;
+    for (int i = 0; i < A.c; ++i) {
+        const float dx = a[i] - c;
+        float d;
+        if (flags & 1) d = csm_expf(-alpha * (fabsf(dx) * fabsf(dx))) * dx;      // exp_attractor, gamma = 2
+        else d = dx / (1.0f + alpha * (dx * dx));                                // inv_attractor, gamma = 2
+        delta += d;
+    }
+    if (flags & 2) delta = delta / (float)A.c;
+    out.p[pix * out.ld + k] = c + delta;
+}
+
+// ConditionalLogBinomial tail + expectation over the bins (dist_layers.py:46-121, zoedepth_v1.py:196-199); NB <= 256
+__global__ __launch_bounds__(256) void k_logbinom(View pt, View cen, View out, const float *__restrict__ par) {
+    int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)out.n * out.h * out.w;
+    if (pix >= total) return;
+    const float p_eps = par[0], min_temp = par[1], max_temp = par[2];
+    const float *lb = par + 3;
+    const float *q = pt.p + pix * pt.ld;
+    const float p0 = q[0] + p_eps, p1 = q[1] + p_eps, t0 = q[2] + p_eps, t1 = q[3] + p_eps;
+    const float p = p0 / (p0 + p1);
+    float t = t0 / (t0 + t1);
+    t = (max_temp - min_temp) * t + min_temp;
+    const float eps = 1e-4f;                                           // LogBinomial.forward eps
+    const float omx = fminf(fmaxf(1.0f - p, eps), 1.0f), x = fminf(fmaxf(p, eps), 1.0f);
+    const float lx = csm_logf(x), lo = csm_logf(omx);
+    const int K = cen.c;
+    const float *c = cen.p + pix * cen.ld;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        const float y = (lb[k] + (float)k * lx + (float)(K - 1 - k) * lo) / t;
+        mx = fmaxf(mx, y);
+    }
+    float den = 0.0f, num = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float y = (lb[k] + (float)k * lx + (float)(K - 1 - k) * lo) / t;
+        const float e = csm_expf(y - mx);
+        den += e; num += e * c[k];
+    }
+    out.p[pix * out.ld] = num / den;
+}
+
 // global average pool with a fixed, oracle-reproducible reduction tree:
 // 256 strided partial sums (sequential), then a binary tree 128,64,...,1, then / (h*w).
 __global__ __launch_bounds__(256) void k_gavgpool(View in, View out) {
@@ -1409,6 +1490,14 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
             case CSM_OP_GAVGPOOL:
                 if (!(in.c & 31) && !(in.ld & 3) && !(((uintptr_t)in.p) & 15)) k_gavgpool32<<<dim3(in.c / 32, in.n), 256, 0, st>>>(in, out);
                 else k_gavgpool<<<dim3(in.c, in.n), 256, 0, st>>>(in, out);
+                break;
+            case CSM_OP_ATTRACTOR:
+                if (op.aux_off < 0 || in.n != in1.n || in.h != in1.h || in.w != in1.w) { csm::set_error("op %d: attractor operands", i); return CSM_ERR_ARG; }
+                k_attractor<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, weights + op.aux_off, op.flags);
+                break;
+            case CSM_OP_LOGBINOM:
+                if (op.aux_off < 0 || in.c < 4 || in1.c > 256) { csm::set_error("op %d: logbinom operands", i); return CSM_ERR_ARG; }
+                k_logbinom<<<blocks_for((int64_t)out.n * out.h * out.w), 256, 0, st>>>(in, in1, out, weights + op.aux_off);
                 break;
             case CSM_OP_NCHW_TO_NHWC:
                 k_nchw_to_nhwc<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in.p, in.c, out);

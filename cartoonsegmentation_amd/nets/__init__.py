@@ -5,3 +5,4 @@ from .rtmdet import build_rtmdet, RTMDetConfig  # noqa: F401
 from .refine import build_refine  # noqa: F401
 from .inpaint import build_inpaint_context, build_inpaint_grid  # noqa: F401
 from .disparity import build_semantics, build_disparity  # noqa: F401
+from .zoedepth_head import build_zoe_head  # noqa: F401

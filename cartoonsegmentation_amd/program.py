@@ -13,8 +13,8 @@ import numpy as np
 
 # ---- C structs (must match include/csm355.h) -------------------------------------------------
 OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_BILINEAR, OP_NEAREST, OP_ADD, OP_GAVGPOOL, OP_SCALE = 1, 2, 3, 4, 5, 6, 7, 8
-OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_ACT, OP_COPY = 9, 10, 11, 12
-ACT = {None: 0, 'none': 0, 'relu': 1, 'silu': 2, 'prelu': 3, 'hsigmoid': 4, 'sigmoid': 5}
+OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_ACT, OP_COPY, OP_ATTRACTOR, OP_LOGBINOM = 9, 10, 11, 12, 13, 14
+ACT = {None: 0, 'none': 0, 'relu': 1, 'silu': 2, 'prelu': 3, 'hsigmoid': 4, 'sigmoid': 5, 'softplus': 6, 'gelu': 7}
 
 
 class CsmTensorDesc(ctypes.Structure):
@@ -290,6 +290,25 @@ class Program:
 
     def copy(self, x, out):
         return self._emit(OP_COPY, x, None, out)
+
+    def to_nhwc_into(self, x_ext, out):
+        """NCHW ext tensor -> a channel slice of an NHWC buffer (channels beyond the source's are written as zeros)"""
+        return self._emit(OP_NCHW_TO_NHWC, x_ext, None, out)
+
+    def attractor(self, A, b, alpha, attractor_type='inv', kind='mean'):
+        """ZoeDepth bin-centre attractor update (attractor.py): out = b + agg_i dist(A_i - b), gamma = 2"""
+        out = self.buffer(b.n, b.h, b.w, b.c)
+        par = np.array([alpha, 0, 0, 0], np.float32)
+        a_h, a_n = self._w(par, par)
+        flags = (1 if attractor_type == 'exp' else 0) | (2 if kind == 'mean' else 0)
+        return self._emit(OP_ATTRACTOR, A, b, out, aux_off=a_h, flags=flags, nat=dict(aux_off=a_n))
+
+    def logbinom(self, pt, centers, p_eps, min_temp, max_temp, log_binom_table):
+        """ConditionalLogBinomial tail + expectation over the bins -> [n,h,w,1] (stored in a 4-channel buffer)"""
+        out = self.buffer(pt.n, pt.h, pt.w, 4).slice(0, 1)
+        par = np.concatenate([np.array([p_eps, min_temp, max_temp], np.float32), np.asarray(log_binom_table, np.float32)])
+        a_h, a_n = self._w(par, par)
+        return self._emit(OP_LOGBINOM, pt, centers, out, aux_off=a_h, nat=dict(aux_off=a_n))
 
     def crop_rows(self, x, h):
         """the first h rows of a single-image map as a VIEW (torch's negative bottom pad): same buffer, smaller height"""

@@ -156,10 +156,19 @@ enum csm_op_kind {
     CSM_OP_NCHW_TO_NHWC = 9,/* in0 = ext NCHW tensor (c real channels) -> NHWC padded to out.c (zeros) */
     CSM_OP_NHWC_TO_NCHW = 10,
     CSM_OP_ACT = 11,        /* out = act(in0) */
-    CSM_OP_COPY = 12        /* out = in0 (slice copy) */
+    CSM_OP_COPY = 12,       /* out = in0 (slice copy) */
+    /* ZoeDepth metric-bins head (depth_modules/zoedepth/models/layers/attractor.py, dist_layers.py) */
+    CSM_OP_ATTRACTOR = 13,  /* in0 = attractor points A [n,h,w,na], in1 = bin centers b [n,h,w,nb] -> out = b + agg_i dist(A_i - b):
+                               dist = dx / (1 + alpha dx^2) (flags bit 0 = 0, "inv") or exp(-alpha dx^2) dx (bit 0 = 1, "exp");
+                               agg = sum over i in order, / na when flags bit 1 (kind "mean"); aux_off -> {alpha}  (gamma = 2) */
+    CSM_OP_LOGBINOM = 14    /* in0 = pt [n,h,w,4] (softplus'ed p0,p1,t0,t1), in1 = bin centers [n,h,w,nb] -> out [n,h,w,1] =
+                               sum_k softmax_k(logbinomial_k(p) / t) * centers_k  (ConditionalLogBinomial.forward tail + the
+                               weighted sum of zoedepth_v1.py:199); aux_off -> {p_eps, min_temp, max_temp, lb[0..nb)} with
+                               lb[k] = log_binom(nb-1, k) tabulated by the host */
 };
 enum csm_act { CSM_ACT_NONE = 0, CSM_ACT_RELU = 1, CSM_ACT_SILU = 2, CSM_ACT_PRELU = 3, CSM_ACT_HSIGMOID = 4,
-               CSM_ACT_SIGMOID = 5 };
+               CSM_ACT_SIGMOID = 5, CSM_ACT_SOFTPLUS = 6 /* torch.nn.Softplus(): x > 20 ? x : log(1 + exp(x)) */,
+               CSM_ACT_GELU = 7 /* torch.nn.GELU(): 0.5 x (1 + erf(x / sqrt 2)) */ };
 
 typedef struct csm_tensor_desc {
     int64_t offset;      /* floats from the workspace base (ext < 0) or from ext pointer slot `ext` */

@@ -46,9 +46,40 @@ static float orc_expf(float x)
     return e * s;
 }
 
+static float orc_logf(float x)
+{
+    int32_t bits; memcpy(&bits, &x, 4);
+    int e = ((bits >> 23) & 0xff) - 126;
+    int32_t mb = (bits & 0x007fffff) | 0x3f000000;
+    float m; memcpy(&m, &mb, 4);
+    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+    const float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = fmaf(y, m, -1.1514610310e-1f); y = fmaf(y, m, 1.1676998740e-1f); y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f); y = fmaf(y, m, -1.6668057665e-1f); y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f); y = fmaf(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    const float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(z, -0.5f, y);
+    return fmaf(fe, 0.693359375f, m + y);
+}
+
+static float orc_erff(float x)
+{
+    const float ax = fabsf(x);
+    const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+    float p = 1.061405429f;
+    p = fmaf(p, t, -1.453152027f); p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - (p * t) * orc_expf(-(ax * ax));
+    return x < 0.0f ? -r : r;
+}
+
 static float orc_act(float v, int act, float slope)
 {
     switch (act) {
+        case CSM_ACT_SOFTPLUS: return v > 20.0f ? v : orc_logf(1.0f + orc_expf(v));
+        case CSM_ACT_GELU: return (0.5f * v) * (1.0f + orc_erff(v * 0.707106781186547524f));
         case CSM_ACT_RELU: return fmaxf(v, 0.0f);
         case CSM_ACT_SILU: return v / (1.0f + orc_expf(-v));
         case CSM_ACT_PRELU: return v >= 0.0f ? v : v * slope;
@@ -315,6 +346,61 @@ static void orc_eltwise(view_t a, view_t b, view_t out, int act, int mode, const
     }
 }
 
+/* ZoeDepth attractor update (depth_modules/zoedepth/models/layers/attractor.py:117-208, the memory_efficient loop) */
+static void orc_attractor(const csm_op *op, view_t A, view_t b, view_t out, const float *par)
+{
+    const float alpha = par[0];
+    const int64_t M = (int64_t)out.n * out.h * out.w;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m)
+        for (int k = 0; k < out.c; ++k) {
+            const float c = b.p[m * b.ld + k];
+            float delta = 0.0f;
+            for (int i = 0; i < A.c; ++i) {
+                const float dx = A.p[m * A.ld + i] - c;
+                float d;
+                if (op->flags & 1) d = orc_expf(-alpha * (fabsf(dx) * fabsf(dx))) * dx;
+                else d = dx / (1.0f + alpha * (dx * dx));
+                delta += d;
+            }
+            if (op->flags & 2) delta = delta / (float)A.c;
+            out.p[m * out.ld + k] = c + delta;
+        }
+}
+
+/* ConditionalLogBinomial tail + weighted sum (dist_layers.py:46-121, zoedepth_v1.py:196-199) */
+static void orc_logbinom(view_t pt, view_t cen, view_t out, const float *par)
+{
+    const float p_eps = par[0], min_temp = par[1], max_temp = par[2];
+    const float *lb = par + 3;
+    const int K = cen.c;
+    const int64_t M = (int64_t)out.n * out.h * out.w;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        const float *q = pt.p + m * pt.ld;
+        const float p0 = q[0] + p_eps, p1 = q[1] + p_eps, t0 = q[2] + p_eps, t1 = q[3] + p_eps;
+        const float p = p0 / (p0 + p1);
+        float t = t0 / (t0 + t1);
+        t = (max_temp - min_temp) * t + min_temp;
+        const float eps = 1e-4f;
+        const float omx = fminf(fmaxf(1.0f - p, eps), 1.0f), x = fminf(fmaxf(p, eps), 1.0f);
+        const float lx = orc_logf(x), lo = orc_logf(omx);
+        const float *c = cen.p + m * cen.ld;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const float y = (lb[k] + (float)k * lx + (float)(K - 1 - k) * lo) / t;
+            mx = fmaxf(mx, y);
+        }
+        float den = 0.0f, num = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float y = (lb[k] + (float)k * lx + (float)(K - 1 - k) * lo) / t;
+            const float e = orc_expf(y - mx);
+            den += e; num += e * c[k];
+        }
+        out.p[m * out.ld] = num / den;
+    }
+}
+
 /* same fixed reduction tree as k_gavgpool: 256 strided sequential partials, then 128,64,..,1 */
 static void orc_gavgpool(view_t in, view_t out)
 {
@@ -362,6 +448,8 @@ int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
             case CSM_OP_ACT: orc_eltwise(in, in1, out, op->act, 0, S); break;
             case CSM_OP_COPY: orc_eltwise(in, in1, out, 0, 0, NULL); break;
             case CSM_OP_GAVGPOOL: orc_gavgpool(in, out); break;
+            case CSM_OP_ATTRACTOR: orc_attractor(op, in, in1, out, S); break;
+            case CSM_OP_LOGBINOM: orc_logbinom(in, in1, out, S); break;
             case CSM_OP_NCHW_TO_NHWC: {
                 int64_t hw = (int64_t)out.h * out.w;
                 for (int64_t n = 0; n < out.n; ++n)

@@ -128,8 +128,67 @@ def disparity_case():
         print('disparity', tag, tuple(s_.shape), float(s_.mean()), tuple(d.shape), float(d.mean()), float(d.std()))
 
 
+def zoe_head_case():
+    """ZoeDepth.forward (zoedepth_v1.py:124-202) with the shipped ZoeD_M12_N configuration (config_zoedepth.json), its layers loaded
+    from the reference files, and a stand-in `core` that returns seeded feature maps of the shapes MidasCore documents
+    (rel_depth [B,H,W]; out_conv [B,32,H,W]; bottleneck + r4..r1 [B,256,H/32..H/2]): the MiDaS backbone itself comes from torch.hub
+    and is not vendored.  The class statement is executed from the file's text (ref_loader.extract_def)."""
+    import itertools
+    import json
+    nn = torch.nn
+    for n in ("depth_modules", "depth_modules.zoedepth", "depth_modules.zoedepth.models", "depth_modules.zoedepth.models.layers"):
+        ref_loader._bare(n)
+    L = "depth_modules/zoedepth/models/layers/"
+    att = ref_loader.load_by_path("depth_modules.zoedepth.models.layers.attractor", L + "attractor.py")
+    dist = ref_loader.load_by_path("depth_modules.zoedepth.models.layers.dist_layers", L + "dist_layers.py")
+    lb = ref_loader.load_by_path("depth_modules.zoedepth.models.layers.localbins_layers", L + "localbins_layers.py")
+    ns = dict(torch=torch, nn=nn, itertools=itertools, DepthModel=nn.Module, MidasCore=None, load_state_from_resource=None,
+              AttractorLayer=att.AttractorLayer, AttractorLayerUnnormed=att.AttractorLayerUnnormed,
+              ConditionalLogBinomial=dist.ConditionalLogBinomial, Projector=lb.Projector, SeedBinRegressor=lb.SeedBinRegressor,
+              SeedBinRegressorUnnormed=lb.SeedBinRegressorUnnormed)
+    ZoeDepth = ref_loader.extract_def("depth_modules/zoedepth/models/zoedepth/zoedepth_v1.py", "ZoeDepth", ns)
+    conf = json.load(open(os.path.join(ref_loader.REF, "depth_modules/zoedepth/models/zoedepth/config_zoedepth.json")))["model"]
+
+    class Core(nn.Module):
+        output_channels = (256, 256, 256, 256, 256)
+
+        def __init__(self):
+            super().__init__()
+            self.feats = None
+
+        def forward(self, x, denorm=False, return_rel_depth=False):
+            return self.feats[0], list(self.feats[1:])
+    core = Core()
+    model = ZoeDepth(core, **{k: v for k, v in conf.items() if k not in ("name", "version_name")}).eval()
+    kinds = {}
+    for mname, m in model.named_modules():
+        if isinstance(m, nn.Conv2d):
+            kinds[mname + '.weight'] = 'conv_w'; kinds[mname + '.bias'] = 'conv_b'
+    sd = model.state_dict()
+    for name, t in sd.items():
+        if name in kinds:
+            t.copy_(torch.from_numpy(synth_tensor('zoe.' + name, tuple(t.shape), kinds[name])))
+    model.load_state_dict(sd)
+    H, W = 64, 96
+    g = np.random.default_rng(400)
+    h16 = lambda a: a.astype(np.float16).astype(np.float32)          # fp16-representable values: the fixture stores them as float16
+    rel = h16(g.uniform(0.2, 5.0, (1, H, W)))
+    feats = [h16(g.normal(0, 1, (1, 32, H, W)))] + [h16(g.normal(0, 1, (1, 256, H >> s, W >> s))) for s in (5, 4, 3, 2, 1)]
+    core.feats = [torch.from_numpy(rel)] + [torch.from_numpy(f) for f in feats]
+    with torch.no_grad():
+        out = model(torch.zeros(1, 3, H, W), return_final_centers=True)
+    md, bc = out['metric_depth'].numpy(), out['bin_centers'].numpy()
+    f16 = lambda a: a.astype(np.float16)
+    np.savez_compressed(os.path.join(HERE, 'net_zoehead_64x96.npz'), rel=f16(rel), out_conv=f16(feats[0]), btlnck=f16(feats[1]),
+                        r4=f16(feats[2]), r3=f16(feats[3]), r2=f16(feats[4]), r1=f16(feats[5]), metric_depth=md,
+                        bin_centers=bc[:, ::8].copy())
+    print('zoe head', md.shape, float(md.mean()), float(md.std()), float(bc.min()), float(bc.max()))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['isnet', 'leres']
+    if 'zoe' in which:
+        zoe_head_case()
     if 'disparity' in which:
         disparity_case()
     if 'isnet' in which:

@@ -264,3 +264,20 @@ def test_disparity_estimator_vs_reference_modules(tag, h, w):
     CompiledProgram(build_disparity(SynthWeights('disparity.'), h, w), dev).run(x, torch.from_numpy(g['sem']).to(dev), d)
     assert np.abs(d.cpu().numpy() - g['disp']).max() <= 1e-4 * np.abs(g['disp']).max()
     assert float(d.min()) >= 0.0
+
+
+def test_zoedepth_head_vs_reference_text():
+    """ZoeDepth metric-bins head on the HIP engine (1x1 convs with fused softplus / GELU, CSM_OP_ATTRACTOR, CSM_OP_LOGBINOM) vs the
+    fixture from the reference's own class + layers (north_star tolerance 1e-3 relative; measured ~1e-5)"""
+    from cartoonsegmentation_amd.nets import build_zoe_head
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    from cartoonsegmentation_amd.weights import SynthWeights
+    g = dict(np.load(os.path.join(GOLDEN, "net_zoehead_64x96.npz")))
+    H, W = 64, 96
+    dev = torch.device('cuda')
+    f = lambda k: torch.from_numpy(np.ascontiguousarray(g[k].astype(np.float32))).to(dev)
+    ext = [f('rel')[:, None].contiguous(), f('out_conv'), f('btlnck'), f('r4'), f('r3'), f('r2'), f('r1')]
+    out = torch.empty((1, 1, H, W), device=dev)
+    CompiledProgram(build_zoe_head(SynthWeights('zoe.'), 1, H, W, [(H >> s, W >> s) for s in (5, 4, 3, 2, 1)]), dev).run(*ext, out)
+    y = out.cpu().numpy()
+    assert np.abs(y - g['metric_depth']).max() <= 1e-4 * np.abs(g['metric_depth']).max()
