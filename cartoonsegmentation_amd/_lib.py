@@ -40,6 +40,8 @@ def load():
         _lib.csm_autozoom_scratch_floats.restype = ctypes.c_size_t
         _lib.csm_warp_tile_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_warp_tile_header_bytes.restype = ctypes.c_size_t
+        _lib.csm_percentile_scratch_bytes.restype = ctypes.c_size_t
+        _lib.csm_bokeh_depth_scratch_bytes.restype = ctypes.c_size_t
     return _lib
 
 

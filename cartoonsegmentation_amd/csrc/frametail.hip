@@ -1,0 +1,231 @@
+// frametail.hip -- the depth-of-field tail of the Ken Burns frame loop without host round trips (kenburns_effect.py:1042-1067).
+//
+// Per output frame the reference (and this repo's round-1 code) sorts the 1 M depth values to read two percentiles, reads four
+// scalars back, then reads three more for the bokeh depth map: ~230 us of sort kernels plus seven host syncs per frame, 75 frames
+// per video.  Here:
+//   csm_percentile_pair   EXACT order statistics by a 3-pass radix select on the order-preserving integer image of the floats
+//                         (11 + 11 + 10 bits; per-block LDS histograms -> per-block partials -> one small pick kernel per pass;
+//                         the four ranks of the two percentiles travel together) + numpy's linear interpolation rule; the results
+//                         stay in device memory.
+//   csm_colorize_gray_r_dev  colorize(value, cmap='gray_r') reading vmin / vmax from device memory, LUT applied in the kernel.
+//   csm_bokeh_depth_auto  the depth map of bokeh_blur (utils/effects.py:146-163): its three scalar reductions run over the 256-bin
+//                         histogram of the uint8 depth (max d; min and max of dmax - |d - focal| only depend on which values occur).
+// All integer / order work: bit-exact with the sorted formulation (same elements selected), asserted in tests/test_gpu_kenburns.py.
+#include "csm_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kSelBlocks = 64;        // blocks of the histogram passes (partials: kSelBlocks x 4 ranks x 2048 bins; the pick kernel
+                                      // reads them all: with 256 blocks it took 69 us per pass, 3x the histogram itself)
+constexpr int kBins = 2048;
+
+__device__ __forceinline__ unsigned ordered_key(float f) {      // monotone float -> unsigned map (total order incl. negatives)
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+struct SelState {            // device-resident state of the 4 concurrent selections
+    unsigned prefix[4];      // key bits fixed so far (high bits)
+    unsigned rank[4];        // rank still to find among the elements matching the prefix
+};
+
+// pass p: shift / bits of the digit, mask of the already fixed bits
+__device__ __forceinline__ void pass_geom(int p, int &shift, int &bits) {
+    if (p == 0) { shift = 21; bits = 11; } else if (p == 1) { shift = 10; bits = 11; } else { shift = 0; bits = 10; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sel_hist(const float *__restrict__ v, int64_t n, int pass, const SelState *__restrict__ st,
+                                                      unsigned *__restrict__ partial /* [4][kSelBlocks][kBins] */) {
+    __shared__ unsigned h[4][kBins];
+    int shift, bits; pass_geom(pass, shift, bits);
+    const int nb = 1 << bits;
+    unsigned pre[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pre[r] = st->prefix[r];
+    // ranks that share a prefix share a histogram (pass 0: all four)
+    int owner[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { owner[r] = r; for (int q = 0; q < r; ++q) if (pass == 0 || pre[q] == pre[r]) { owner[r] = owner[q]; break; } }
+    for (int i = threadIdx.x; i < 4 * kBins; i += kBlock) (&h[0][0])[i] = 0u;
+    __syncthreads();
+    const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + bits));
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const unsigned k = ordered_key(v[i]);
+        const unsigned d = (k >> shift) & (unsigned)(nb - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (owner[r] == r && (k & himask) == (pre[r] & himask)) atomicAdd(&h[r][d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * kBins; i += kBlock) {
+        const int r = i / kBins, d = i % kBins;
+        if (d < nb) partial[((int64_t)r * gridDim.x + blockIdx.x) * kBins + d] = h[owner[r]][d];
+    }
+}
+
+// one block per rank: column sums of the partials, scan, pick the digit that holds the rank, advance prefix / rank
+__global__ __launch_bounds__(1024) void k_sel_pick(const unsigned *__restrict__ partial, int nblocks, int pass, SelState *__restrict__ st) {
+    __shared__ unsigned col[kBins];
+    __shared__ unsigned scan[1024];
+    int shift, bits; pass_geom(pass, shift, bits);
+    const int nb = 1 << bits, r = blockIdx.x, tid = threadIdx.x;
+    const unsigned rank = st->rank[r];                          // read by everyone BEFORE the barriers; one thread rewrites it at the end
+    for (int d = tid; d < nb; d += 1024) {
+        unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0;               // four independent load streams
+        const unsigned *P = partial + (int64_t)r * nblocks * kBins + d;
+        int b = 0;
+        for (; b + 3 < nblocks; b += 4) {
+            s0 += P[(int64_t)b * kBins]; s1 += P[(int64_t)(b + 1) * kBins]; s2 += P[(int64_t)(b + 2) * kBins]; s3 += P[(int64_t)(b + 3) * kBins];
+        }
+        for (; b < nblocks; ++b) s0 += P[(int64_t)b * kBins];
+        col[d] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    // inclusive scan over nb (<= 2048) counts: two per thread + Hillis-Steele over 1024
+    const unsigned a = 2 * tid < nb ? col[2 * tid] : 0u, b2 = 2 * tid + 1 < nb ? col[2 * tid + 1] : 0u;
+    scan[tid] = a + b2;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned t = tid >= off ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+    }
+    const unsigned before = tid ? scan[tid - 1] : 0u;           // elements in digits < 2 tid
+    // the digit d with  count(< d) <= rank < count(<= d)
+    if (rank >= before && rank < before + a && 2 * tid < nb) { st->prefix[r] |= (unsigned)(2 * tid) << shift; st->rank[r] = rank - before; }
+    else if (rank >= before + a && rank < before + a + b2 && 2 * tid + 1 < nb) { st->prefix[r] |= (unsigned)(2 * tid + 1) << shift; st->rank[r] = rank - before - a; }
+}
+
+__global__ void k_sel_init(SelState *st, unsigned r0, unsigned r1, unsigned r2, unsigned r3) {
+    st->prefix[0] = st->prefix[1] = st->prefix[2] = st->prefix[3] = 0u;
+    st->rank[0] = r0; st->rank[1] = r1; st->rank[2] = r2; st->rank[3] = r3;
+}
+
+// numpy percentile, method 'linear' (numpy 1.26 _lerp): a + (b - a) t for t < 0.5, else b - (b - a)(1 - t); arithmetic in float64 on
+// float32 samples, result rounded to float32 -- what depth_modules/zoedepth/utils/misc.py:118-119 gets from np.percentile
+__global__ void k_sel_finish(const SelState *st, double t_lo, double t_hi, float *out2) {
+    const double a0 = (double)key_to_float(st->prefix[0]), b0 = (double)key_to_float(st->prefix[1]);
+    const double a1 = (double)key_to_float(st->prefix[2]), b1 = (double)key_to_float(st->prefix[3]);
+    const double r0 = t_lo < 0.5 ? a0 + (b0 - a0) * t_lo : b0 - (b0 - a0) * (1.0 - t_lo);
+    const double r1 = t_hi < 0.5 ? a1 + (b1 - a1) * t_hi : b1 - (b1 - a1) * (1.0 - t_hi);
+    out2[0] = (float)r0; out2[1] = (float)r1;
+}
+
+struct Lut256 { uint8_t v[256]; };
+
+__global__ __launch_bounds__(kBlock) void k_colorize_dev(const float *__restrict__ v, uint8_t *__restrict__ out, int64_t n,
+                                                          const float *__restrict__ vmm, Lut256 lut) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float vmin = vmm[0], vmax = vmm[1];
+    float x = vmin != vmax ? (v[i] - vmin) / (vmax - vmin) : 0.0f;
+    // matplotlib Colormap.__call__: xa = x*256; xa==256 -> 255; clip to [-1, 256]; int(); <0 -> under (lut[0]), >255 -> over (lut[255])
+    float xa = x * 256.0f;
+    if (xa == 256.0f) xa = 255.0f;
+    xa = fminf(fmaxf(xa, -1.0f), 256.0f);
+    int k = (int)xa;
+    k = k < 0 ? 0 : (k > 255 ? 255 : k);
+    out[i] = lut.v[k];
+}
+
+// ---- bokeh depth: scalars from the histogram of the uint8 depth --------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_u8_hist(const uint8_t *__restrict__ d, int64_t n, unsigned *__restrict__ partial /* [blocks][256] */) {
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) atomicAdd(&h[d[i]], 1u);
+    __syncthreads();
+    partial[(int64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+// stats3 = {dmax, mn, mx2} exactly as utils/effects.py:146-153 computes them with float32 numpy reductions
+__global__ __launch_bounds__(256) void k_bokeh_stats(const unsigned *__restrict__ partial, int nblocks, float focal, float *__restrict__ stats3) {
+    __shared__ float red[256];
+    __shared__ int present[256];
+    const int tid = threadIdx.x;
+    unsigned c = 0;
+    for (int b = 0; b < nblocks; ++b) c += partial[(int64_t)b * 256 + tid];
+    present[tid] = c != 0u;
+    __syncthreads();
+    red[tid] = present[tid] ? (float)tid : -1.0f;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    const float dmax = red[0];
+    __syncthreads();
+    const float t = dmax - fabsf((float)tid - focal);           // depth = depth.max() - |depth - focal_plane|
+    red[tid] = present[tid] ? t : INFINITY;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] = fminf(red[tid], red[tid + s]); __syncthreads(); }
+    const float mn = red[0];
+    __syncthreads();
+    red[tid] = present[tid] ? t - mn : -INFINITY;               // depth -= depth.min(); depth.max()
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    if (tid == 0) { stats3[0] = dmax; stats3[1] = mn; stats3[2] = red[0]; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bokeh_depth_dev(const uint8_t *__restrict__ d8, float *__restrict__ out, int64_t n, float focal,
+                                                             const float *__restrict__ stats3) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float dmax = stats3[0], mn = stats3[1], mx2 = stats3[2];
+    float v = dmax - fabsf((float)d8[i] - focal);
+    v = v - mn;
+    v = v / mx2;
+    v = 1.0f - v;
+    out[i] = v * 0.0005f;
+}
+
+}  // namespace
+
+extern "C" size_t csm_percentile_scratch_bytes(void) { return sizeof(SelState) + 64 + sizeof(unsigned) * 4 * (size_t)kSelBlocks * kBins; }
+
+extern "C" int csm_percentile_pair(const float *value, int64_t n, double q_lo, double q_hi, float *out2, void *scratch, void *stream) {
+    CSM_REQUIRE(value && out2 && scratch && n > 0 && n < (1ll << 32) && q_lo >= 0.0 && q_lo <= 100.0 && q_hi >= 0.0 && q_hi <= 100.0);
+    hipStream_t st = (hipStream_t)stream;
+    SelState *state = (SelState *)scratch;
+    unsigned *partial = (unsigned *)((char *)scratch + 64);
+    // numpy: virtual index (n - 1) q / 100, lower / upper neighbours, interpolation weight
+    const double v0 = (double)(n - 1) * (q_lo / 100.0), v1 = (double)(n - 1) * (q_hi / 100.0);
+    const int64_t l0 = (int64_t)v0, l1 = (int64_t)v1;
+    const int64_t h0 = l0 + 1 < n ? l0 + 1 : n - 1, h1 = l1 + 1 < n ? l1 + 1 : n - 1;
+    k_sel_init<<<1, 1, 0, st>>>(state, (unsigned)l0, (unsigned)h0, (unsigned)l1, (unsigned)h1);
+    int rc = csm::check_launch("k_sel_init"); if (rc) return rc;
+    for (int pass = 0; pass < 3; ++pass) {
+        k_sel_hist<<<kSelBlocks, kBlock, 0, st>>>(value, n, pass, state, partial);
+        rc = csm::check_launch("k_sel_hist"); if (rc) return rc;
+        k_sel_pick<<<4, 1024, 0, st>>>(partial, kSelBlocks, pass, state);
+        rc = csm::check_launch("k_sel_pick"); if (rc) return rc;
+    }
+    k_sel_finish<<<1, 1, 0, st>>>(state, v0 - (double)l0, v1 - (double)l1, out2);
+    return csm::check_launch("k_sel_finish");
+}
+
+extern "C" int csm_colorize_gray_r_dev(const float *value, uint8_t *out, int64_t n, const float *vmin_vmax_dev, const uint8_t *lut256_host,
+                                       void *stream) {
+    CSM_REQUIRE(value && out && vmin_vmax_dev && lut256_host && n > 0);
+    Lut256 lut;
+    for (int i = 0; i < 256; ++i) lut.v[i] = lut256_host[i];
+    k_colorize_dev<<<csm::cdiv(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(value, out, n, vmin_vmax_dev, lut);
+    return csm::check_launch("k_colorize_dev");
+}
+
+extern "C" size_t csm_bokeh_depth_scratch_bytes(void) { return 64 + sizeof(unsigned) * 64 * 256; }
+
+extern "C" int csm_bokeh_depth_auto(const uint8_t *depth_u8, float *out, int64_t n, float focal_plane, void *scratch, void *stream) {
+    CSM_REQUIRE(depth_u8 && out && scratch && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    float *stats = (float *)scratch;
+    unsigned *partial = (unsigned *)((char *)scratch + 64);
+    k_u8_hist<<<64, kBlock, 0, st>>>(depth_u8, n, partial);
+    int rc = csm::check_launch("k_u8_hist"); if (rc) return rc;
+    k_bokeh_stats<<<1, 256, 0, st>>>(partial, 64, focal_plane, stats);
+    rc = csm::check_launch("k_bokeh_stats"); if (rc) return rc;
+    k_bokeh_depth_dev<<<csm::cdiv(n, kBlock), kBlock, 0, st>>>(depth_u8, out, n, focal_plane, stats);
+    return csm::check_launch("k_bokeh_depth_dev");
+}

@@ -287,19 +287,36 @@ def _percentile_linear(sorted_vals, q):
     return float(_np.float32(r))
 
 
+_TAIL_SCRATCH = {}
+
+
+def _tail_scratch(dev):
+    """per-device scratch of the sync-free frame tail (percentile select state + partial histograms, bokeh stats)"""
+    if dev not in _TAIL_SCRATCH:
+        L = _lib.load()
+        _TAIL_SCRATCH[dev] = (torch.empty(L.csm_percentile_scratch_bytes(), dtype=torch.uint8, device=dev),
+                              torch.empty(L.csm_bokeh_depth_scratch_bytes(), dtype=torch.uint8, device=dev),
+                              torch.empty(2, dtype=torch.float32, device=dev))
+    return _TAIL_SCRATCH[dev]
+
+
 def colorize_gray_r(tenValue):
-    """colorize(value, cmap='gray_r')[..., 0] -> uint8 tensor (same shape, squeezed); vmin/vmax = 2nd / 85th percentile"""
+    """colorize(value, cmap='gray_r')[..., 0] -> uint8 tensor (same shape, squeezed); vmin/vmax = 2nd / 85th percentile
+    (depth_modules/zoedepth/utils/misc.py:97-135).  No sort and no host sync: the percentiles are selected on the device
+    (csm_percentile_pair) and consumed from device memory."""
     global _GRAY_R_LUT
+    import ctypes
     v = _dev(tenValue.reshape(-1), "tenValue")
-    s, _ = torch.sort(v)
-    vmin, vmax = _percentile_linear(s, 2), _percentile_linear(s, 85)
-    if _GRAY_R_LUT is None or _GRAY_R_LUT.device != v.device:
+    L = _lib.load()
+    if _GRAY_R_LUT is None:
         # matplotlib: lut = 1 - linspace(0,1,256) (float64); bytes=True -> (lut*255).astype(uint8)  [truncation, not 255-k]
-        _GRAY_R_LUT = torch.from_numpy(((1.0 - _np.linspace(0.0, 1.0, 256)) * 255).astype(_np.uint8)).to(v.device)
-    idx = torch.empty(v.numel(), dtype=torch.uint8, device=v.device)
-    check(_lib.load().csm_colorize_gray_r(ptr(v), ptr(idx), i64(v.numel()), f32(vmin), f32(vmax), stream_ptr()), "colorize")
-    # kernel returns 255 - k; map k through the exact matplotlib byte LUT
-    return _GRAY_R_LUT[(255 - idx.long())].reshape(tenValue.squeeze().shape)
+        lut = ((1.0 - _np.linspace(0.0, 1.0, 256)) * 255).astype(_np.uint8)
+        _GRAY_R_LUT = (ctypes.c_uint8 * 256)(*[int(x) for x in lut])
+    sel, _, vmm = _tail_scratch(v.device)
+    check(L.csm_percentile_pair(ptr(v), i64(v.numel()), f64(2.0), f64(85.0), ptr(vmm), ptr(sel), stream_ptr()), "percentile_pair")
+    out = torch.empty(v.numel(), dtype=torch.uint8, device=v.device)
+    check(L.csm_colorize_gray_r_dev(ptr(v), ptr(out), i64(v.numel()), ptr(vmm), _GRAY_R_LUT, stream_ptr()), "colorize")
+    return out.reshape(tenValue.squeeze().shape)
 
 
 def bokeh_blur(img, depth, num_samples=32, lightness_factor=10, depth_factor=2, use_cuda=False, focal_plane=None):
@@ -315,16 +332,12 @@ def bokeh_blur(img, depth, num_samples=32, lightness_factor=10, depth_factor=2, 
         raise NotImplementedError("bokeh_blur: the hot path calls it with the uint8 colorized depth and depth_factor=1 "
                                   "(configs/3dkenburns.yaml:47)")
     d8 = d8.contiguous()
-    df = d8.float()
     if focal_plane is None:
         raise NotImplementedError("bokeh_blur without focal_plane is not used by the pipeline")
     fp = float(_np.float32(focal_plane))
-    dmax = float(df.max().item())
-    t = dmax - (df - fp).abs()
-    mn = float(t.min().item())
-    mx2 = float((t - mn).max().item())
     dm = torch.empty((H, W), dtype=torch.float32, device=dev)
-    check(L.csm_bokeh_depth(ptr(d8), ptr(dm), i64(n), f32(dmax), f32(fp), f32(mn), f32(mx2), stream_ptr()), "bokeh_depth")
+    # depth.max(), min / max of depth.max() - |depth - focal| (utils/effects.py:146-153) from the uint8 histogram, on the device
+    check(L.csm_bokeh_depth_auto(ptr(d8), ptr(dm), i64(n), f32(fp), ptr(_tail_scratch(dev)[1]), stream_ptr()), "bokeh_depth")
     hi = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     check(L.csm_bokeh_highlight(ptr(img_d), ptr(hi), i64(n * 3), f32(lightness_factor), stream_ptr()), "bokeh_highlight")
     a, b, c = torch.empty_like(hi), torch.empty_like(hi), torch.empty_like(hi)

@@ -316,6 +316,20 @@ int csm_bokeh_depth(const uint8_t *depth_u8, float *out, int64_t n, float dmax, 
 /* colorize(value, cmap='gray_r')[...,0]  depth_modules/zoedepth/utils/misc.py:97-135 (vmin/vmax = 2nd/85th percentile) */
 int csm_colorize_gray_r(const float *value, uint8_t *out, int64_t n, float vmin, float vmax, void *stream);
 
+/* The same three steps without host round trips (frametail.hip) -- the per-frame tail of kenburns_effect.py:1042-1067:
+ * csm_percentile_pair: out2 (DEVICE) = {np.percentile(value, q_lo), np.percentile(value, q_hi)} (method 'linear'), exact, by a
+ *   3-pass radix select instead of a sort; scratch = csm_percentile_scratch_bytes() device bytes.
+ * csm_colorize_gray_r_dev: csm_colorize_gray_r with vmin / vmax read from device memory and the matplotlib byte LUT (256 HOST
+ *   bytes, index -> grey level) applied in the kernel.
+ * csm_bokeh_depth_auto: csm_bokeh_depth with dmax / mn / mx2 derived on the device from the histogram of depth_u8; scratch =
+ *   csm_bokeh_depth_scratch_bytes() device bytes. */
+size_t csm_percentile_scratch_bytes(void);
+int csm_percentile_pair(const float *value, int64_t n, double q_lo, double q_hi, float *out2, void *scratch, void *stream);
+int csm_colorize_gray_r_dev(const float *value, uint8_t *out, int64_t n, const float *vmin_vmax_dev, const uint8_t *lut256_host,
+                            void *stream);
+size_t csm_bokeh_depth_scratch_bytes(void);
+int csm_bokeh_depth_auto(const uint8_t *depth_u8, float *out, int64_t n, float focal_plane, void *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
