@@ -249,6 +249,61 @@ extern "C" int csm_resize_u8_linear(const uint8_t *src_hwc, int H, int W, int C,
     return csm::check_launch("k_resize_u8_linear");
 }
 
+// cv2.resize(u8 [h,w], (W,H), INTER_LANCZOS4) -> float32 (kenburns_effect.py:572-575 when the 32-aligned LeReS map is LARGER than the
+// frame, k > 1).  [EXT: OpenCV 4.10 resize.cpp restated: source coordinate (d + 0.5) scale - 0.5, 8 taps sx-3..sx+4 with replicate
+// clamping per tap, interpolateLanczos4 coefficients in float -> short Q11 (cvRound), horizontal pass to int, vertical pass, result
+// (v + 2^21) >> 22 saturated.]
+__device__ __forceinline__ void lanczos4_q11(float x, int c[8]) {
+    const double s45 = 0.70710678118654752440084436210485;
+    const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    float coeffs[8], sum = 0.0f;
+    const double y0 = -(x + 3) * 3.14159265358979323846 * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; ++i) {
+        const float y0_ = (x + 3 - i);
+        if (fabsf(y0_) >= 1e-6f) {
+            const double y = -y0_ * 3.14159265358979323846 * 0.25;
+            coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        } else coeffs[i] = 1e30f;
+        sum += coeffs[i];
+    }
+    sum = 1.0f / sum;
+    for (int i = 0; i < 8; ++i) {
+        const float v = coeffs[i] * sum * 2048.0f;
+        int q = (int)rintf(v);
+        c[i] = q > 32767 ? 32767 : (q < -32768 ? -32768 : q);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resize_u8_lanczos4(const uint8_t *__restrict__ src, int h, int w, int H, int W,
+                                                             float *__restrict__ out) {
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    float fx = (float)((x + 0.5) * ((double)w / W) - 0.5), fy = (float)((y + 0.5) * ((double)h / H) - 0.5);
+    int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= (float)sx; fy -= (float)sy;
+    int cx[8], cy[8];
+    lanczos4_q11(fx, cx); lanczos4_q11(fy, cy);
+    int acc = 0;
+    for (int j = 0; j < 8; ++j) {
+        int yy = sy - 3 + j; yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+        int row = 0;
+        for (int i = 0; i < 8; ++i) {
+            int xx = sx - 3 + i; xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+            row += (int)src[(int64_t)yy * w + xx] * cx[i];
+        }
+        acc += row * cy[j];
+    }
+    int v = (acc + (1 << 21)) >> 22;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    out[(int64_t)y * W + x] = (float)v;
+}
+
+extern "C" int csm_resize_u8_lanczos4_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream) {
+    CSM_REQUIRE(src && out && h > 0 && w > 0 && H > 0 && W > 0);
+    k_resize_u8_lanczos4<<<dim3(csm::cdiv(W, 256), H), 256, 0, (hipStream_t)stream>>>(src, h, w, H, W, out);
+    return csm::check_launch("k_resize_u8_lanczos4");
+}
+
 extern "C" int csm_leres_input(const uint8_t *img_hwc, int H, int W, int h, int w, float *out, void *stream) {
     CSM_REQUIRE(img_hwc && out && H > 0 && W > 0 && h > 0 && w > 0);
     Norm3 nm{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}};

@@ -405,8 +405,6 @@ class KenBurnsPipeline:
         H, W = int(imgs_d[0].shape[0]), int(imgs_d[0].shape[1])
         h, w = scaledown_size(H, W, self.cfg.depth_est_size)
         h, w = int(math.ceil(h / 32) * 32), int(math.ceil(w / 32) * 32)
-        if h > H or w > W:
-            raise NotImplementedError("LeReS map larger than the frame needs cv2 INTER_LANCZOS4 (not restated)")
         x = torch.empty((nb, 3, h, w), dtype=torch.float32, device=self.device)
         for bi, im in enumerate(imgs_d):
             check(L.csm_leres_input(ptr(im), i32(H), i32(W), i32(h), i32(w), ptr(x[bi]), stream_ptr()), "leres_input")
@@ -420,7 +418,7 @@ class KenBurnsPipeline:
             q = torch.empty((h, w), dtype=torch.uint8, device=self.device)
             check(L.csm_leres_quantize(ptr(yb), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
             depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
-            check(L.csm_resize_u8_to_f32(ptr(q), i32(h), i32(w), i32(H), i32(W), ptr(depth), stream_ptr()), "resize_u8")
+            self._leres_resize_back(q, h, w, H, W, depth)
             outs.append(_fill_zero_with_min_positive(depth))
         return outs
 
@@ -430,8 +428,6 @@ class KenBurnsPipeline:
         H, W = int(img_d.shape[0]), int(img_d.shape[1])
         h, w = scaledown_size(H, W, self.cfg.depth_est_size)
         h, w = int(math.ceil(h / 32) * 32), int(math.ceil(w / 32) * 32)
-        if h > H or w > W:
-            raise NotImplementedError("LeReS map larger than the frame needs cv2 INTER_LANCZOS4 (not restated)")
         x = torch.empty((1, 3, h, w), dtype=torch.float32, device=self.device)
         check(L.csm_leres_input(ptr(img_d), i32(H), i32(W), i32(h), i32(w), ptr(x), stream_ptr()), "leres_input")
         y = torch.empty((1, 1, h, w), dtype=torch.float32, device=self.device)
@@ -441,8 +437,18 @@ class KenBurnsPipeline:
         q = torch.empty((h, w), dtype=torch.uint8, device=self.device)
         check(L.csm_leres_quantize(ptr(y), i64(h * w), ptr(mnmx), ptr(q), stream_ptr()), "leres_quantize")
         depth = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
-        check(L.csm_resize_u8_to_f32(ptr(q), i32(h), i32(w), i32(H), i32(W), ptr(depth), stream_ptr()), "resize_u8")
+        self._leres_resize_back(q, h, w, H, W, depth)
         return _fill_zero_with_min_positive(depth)
+
+    @staticmethod
+    def _leres_resize_back(q, h, w, H, W, depth):
+        """kenburns_effect.py:571-573: k = depth.shape[0] / ori_h; cv2.resize(depth, (ori_w, ori_h), INTER_LANCZOS4 if k > 1 else
+        INTER_AREA).  k > 1 happens when the 32-aligned LeReS size exceeds the frame (e.g. 600 x 400 -> 608 x 416)."""
+        L = _lib.load()
+        if h / H > 1:
+            check(L.csm_resize_u8_lanczos4_to_f32(ptr(q), i32(h), i32(w), i32(H), i32(W), ptr(depth), stream_ptr()), "resize_lanczos4")
+        else:
+            check(L.csm_resize_u8_to_f32(ptr(q), i32(h), i32(w), i32(H), i32(W), ptr(depth), stream_ptr()), "resize_u8")
 
     def run_instance_segmentation(self, img, scale_down_to_maxsize=True):
         if scale_down_to_maxsize:                                                                                    # :862-863

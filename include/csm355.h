@@ -295,6 +295,8 @@ int csm_depth_range_stats(const float *minmax_raw_dev, float scale, const float 
 int csm_depth_adjust_instance(float *disp, const uint8_t *mask, int H, int W, float *scratch, void *stream);
 /* kenburns_effect.py:572-575: cv2.resize(u8 depth, (W,H), INTER_AREA) (enlarging) -> float32 */
 int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream);
+/* the same line when the 32-aligned LeReS map is larger than the frame (k > 1): cv2.resize(..., INTER_LANCZOS4) -> float32 */
+int csm_resize_u8_lanczos4_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream);
 /* kenburns_effect.py:1069-1070: cv2.getRectSubPix(frame,(patch_w,patch_h),center) + cv2.resize(INTER_LINEAR) to (W,H) */
 int csm_crop_resize_u8(const uint8_t *frame_hwc, int H, int W, int patch_h, int patch_w, float center_x, float center_y,
                        uint8_t *out_hwc, void *stream);

@@ -357,3 +357,38 @@ def test_device_percentiles_and_bokeh_stats_are_exact():
         sc = torch.empty(L.csm_bokeh_depth_scratch_bytes(), dtype=torch.uint8, device='cuda')
         check(L.csm_bokeh_depth_auto(ptr(dd), ptr(got), i64(d8.size), f32(fp), ptr(sc), stream_ptr()))
         assert torch.equal(ref, got), fp
+
+
+def test_lanczos4_resize_back_and_small_frames():
+    """frames whose 32-aligned LeReS size exceeds the frame (600 x 400 -> 608 x 416, k > 1): the reference resizes the uint8 depth
+    back with INTER_LANCZOS4 (kenburns_effect.py:571-573).  HIP == oracle restatement bit for bit [EXT, unpinned]; a constant map
+    stays constant (the Q11 coefficients of every phase sum to 2048 +- rounding, checked to +-1); the pipeline runs."""
+    import ctypes
+    from cartoonsegmentation_amd import _lib, synth
+    from cartoonsegmentation_amd._lib import check, i32, ptr, stream_ptr
+    from oracle import segment as oseg
+    L, O = _lib.load(), oseg.lib()
+    rng = np.random.default_rng(3)
+    for (h, w, H, W) in ((608, 416, 600, 400), (64, 96, 50, 90), (32, 32, 31, 17)):
+        src = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        d = torch.from_numpy(src).cuda()
+        out = torch.empty((H, W), device='cuda'); ref = np.empty((H, W), np.float32)
+        check(L.csm_resize_u8_lanczos4_to_f32(ptr(d), i32(h), i32(w), i32(H), i32(W), ptr(out), stream_ptr()))
+        O.orc_resize_u8_lanczos4_to_f32(oseg._p(src), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(H), ctypes.c_int(W), oseg._p(ref))
+        assert np.array_equal(out.cpu().numpy(), ref)
+        flat = torch.full((h, w), 200, dtype=torch.uint8, device='cuda')
+        check(L.csm_resize_u8_lanczos4_to_f32(ptr(flat), i32(h), i32(w), i32(H), i32(W), ptr(out), stream_ptr()))
+        assert float((out - 200).abs().max()) <= 1.0
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=640, max_size=720, refine_crf=False, focal=200.0,
+                         num_frame=2, mask_refine_kwargs={'refine_method': 'none'})
+    pipe = KenBurnsPipeline(cfg)
+    pipe.max_instances = 1
+    pipe.animeinsseg.set_detect_size(96)
+    os.environ["CSM_AUTOTUNE"] = "0"
+    try:
+        kc = pipe.generate_kenburns_config(synth.image_u8(600, 400, 8))            # default max_size 720 >= image: no frame scaling
+    finally:
+        os.environ.pop("CSM_AUTOTUNE", None)
+    assert kc['tenRawDepth'].shape == (1, 1, 600, 400) and torch.isfinite(kc['tenRawPoints']).all()
