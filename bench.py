@@ -120,24 +120,17 @@ class WarpWorkload(Workload):
                                "achieved_GBps": round(ach, 1), "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4)}}
 
     def roofline(self):
-        """dominant kernel = k_update_output (scatter of 4 corners x 5 channels): 68*P algorithmic bytes"""
-        ops, sc = self.ops, self.scene
-        ps = ops.shift_points(self.pts, self.shift)
-        data = torch.cat([self.rgb, self.dep], 1).contiguous()
-        zee = ops.pointrender_degrid(ops.pointrender_update_zee(ps, self.W, self.H, sc['focal'], sc['baseline']))
-        acc = torch.zeros(1, 5, self.H, self.W, device=ps.device)
-        from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, i64, f64, check
-
-        def launch():
-            check(load().csm_pointrender_update_output(ptr(ps), ptr(data), ptr(zee), i32(1), i32(4), i64(self.N),
-                                                       i32(self.H), i32(self.W), f64(sc['focal']), f64(sc['baseline']),
-                                                       ptr(acc), stream_ptr()))
-        ms = event_time_ms(launch, 50)
-        alg = (12 + 16) * self.N + 8.0 * 5 * self.P
+        """the whole frame chain of csm_warp_frame_tiled (count, scatter, render, holes) against the HBM roof with SURVEY 8(d)'s
+        algorithmic bytes (155 P for N = P, C = 4); `traffic` = PMC bytes summed over the chain's kernels (profiles/traffic.json)"""
+        ms = event_time_ms(self.step, 100, warm=10)
+        alg = self.algorithmic_bytes()
         ach = alg / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "k_update_output<C=4>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": load_traffic("k_update_output"),
-                "algorithmic_bytes_per_launch": alg, "launch_us": round(ms * 1e3, 2)}
+        tiled = getattr(self.wf, 'path', 'tiled') == 'tiled'
+        return {"bound": "hbm", "kernel": "csm_warp_frame_tiled: k_tile_count + k_tile_scatter + k_tile_render + k_tile_holes" if tiled
+                else "csm_warp_frame: k_fill + k_update_zee + k_degrid + k_update_output + k_finalize_frame + k_fill_holes",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": load_traffic("warp_chain_tiled" if tiled else "k_update_output"), "algorithmic_bytes_per_launch": alg,
+                "launch_us": round(ms * 1e3, 2)}
 
     def cpu_baseline(self, seconds):
         from oracle import warp as orc

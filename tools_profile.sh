@@ -1,31 +1,37 @@
 #!/bin/bash
-# usage: tools_profile.sh <tag> [quick] -- GPU validation + measurement pass; writes gpurun_out/<tag>/
+# usage: tools_profile.sh <tag> [quick] -- GPU validation + measurement pass on a gpurun box; writes gpurun_out/<tag>/
+# every rocprofv3 call: --output-format csv (the default rocpd output stalled for minutes here) and a hard timeout
 TAG=${1:-run}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
 export CSM_TUNE_CACHE=/tmp/csm_tiles.txt   # first bench run tunes + saves; the profiled runs reuse the tiles (no tuning launches)
-python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $OUT/smoke.log
-python bench.py 2>/dev/null | tail -1 > $OUT/bench.json; cat $OUT/bench.json
-python bench.py --workload warp --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_warp.json; cat $OUT/bench_warp.json
-python tools/conv_bench.py --sweep 2>/dev/null > $OUT/conv_sweep.txt; tail -1 $OUT/conv_sweep.txt
-python tools/layer_profile.py 2>/dev/null > $OUT/layer_profile.txt; grep "^==" $OUT/layer_profile.txt
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $OUT/pytest_gpu.log; tail -2 $OUT/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $OUT/smoke.log
+timeout 600 python bench.py 2>/dev/null | tail -1 > $OUT/bench_frame.json; head -c 400 $OUT/bench_frame.json; echo
+timeout 300 python bench.py --workload warp --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_warp.json; head -c 300 $OUT/bench_warp.json; echo
+timeout 300 python tools/layer_profile.py 2>/dev/null > $OUT/layer_profile.txt; grep "^==" $OUT/layer_profile.txt
+LP_BATCH=8 timeout 300 python tools/layer_profile.py 2>/dev/null > $OUT/layer_profile_b8.txt; grep "^==" $OUT/layer_profile_b8.txt
+timeout 200 python tools/video_breakdown.py 2>/dev/null | grep rep > $OUT/video_breakdown.txt; cat $OUT/video_breakdown.txt
+timeout 100 python tools/time_autozoom.py 1024 2>/dev/null | grep autozoom | head -1 > $OUT/autozoom.txt; cat $OUT/autozoom.txt
 [ "$2" = "quick" ] && exit 0
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o frame -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+RP="timeout 200 rocprofv3 --kernel-trace --stats --output-format csv"
+$RP -d $OUT/stats -o frame -- python /root/repo/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-variants > $OUT/stats.log 2>&1
 # same workload with the LeReS side stream off: kernels do not overlap, so durations are per-kernel clean (HIP-event comparable)
-CSM_OVERLAP_DEPTH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o frame -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats_serial.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_warp -o warp -- python /root/repo/bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_warp.log 2>&1
+CSM_OVERLAP_DEPTH=0 $RP -d $OUT/stats_serial -o frame -- python /root/repo/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-variants > $OUT/stats_serial.log 2>&1
+$RP -d $OUT/stats_warp -o warp -- python /root/repo/bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_warp.log 2>&1
+CSM_WARP_PATH=atomics $RP -d $OUT/stats_warp_atomics -o warp -- python /root/repo/bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_warp_atomics.log 2>&1
+$RP -d $OUT/stats_video -o video -- python /root/repo/tools/video_breakdown.py > $OUT/stats_video.log 2>&1
+$RP -d $OUT/stats_autozoom -o az -- python /root/repo/tools/time_autozoom.py 1024 > $OUT/stats_autozoom.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o frame -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmcw_$C -o warp -- python /root/repo/bench.py --workload warp --steps 20 --warmup 2 --no-cpu-baseline > $OUT/pmcw_$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o frame -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants > $OUT/pmc_$C.log 2>&1
+  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmcw_$C -o warp -- python /root/repo/bench.py --workload warp --steps 20 --warmup 2 --no-cpu-baseline > $OUT/pmcw_$C.log 2>&1
 done
 python - <<PY
 import csv,glob,collections,json
-out={}
-for f in glob.glob("$OUT/stats*/**/*kernel_stats.csv", recursive=True):
-    print(f); print("".join(l[:170]+"\n" for l in open(f).readlines()[:14]))
+for f in sorted(glob.glob("$OUT/stats*/**/*kernel_stats.csv", recursive=True)):
+    print(f); print("".join(l[:170]+"\n" for l in open(f).readlines()[:12]))
     calls=tot=0
     for r in csv.DictReader(open(f)):
         if "k_conv_" in r["Name"]: calls+=int(r["Calls"]); tot+=int(r["TotalDurationNs"])
@@ -39,6 +45,7 @@ for kind,key in (("FETCH_SIZE","fetch_KB"),("WRITE_SIZE","write_KB")):
         for f in glob.glob("$OUT/%s%s/**/*counter_collection.csv"%(pre,kind), recursive=True):
             for r in csv.DictReader(open(f)):
                 k=r["Kernel_Name"]; k=k[k.find("k_"):][:24] if "k_" in k else k[:24]
+                k=k.split("(")[0].split("<")[0]
                 if k.startswith("k_conv_"): k="k_conv"            # all conv tile instantiations together
                 agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
         for k,(n,v) in agg.items():
@@ -46,10 +53,10 @@ for kind,key in (("FETCH_SIZE","fetch_KB"),("WRITE_SIZE","write_KB")):
 json.dump(tr, open("$OUT/pmc_summary.json","w"), indent=1)
 # HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -- MI355X_MICROARCH.md, HBM)
 traffic={k:int(2*v.get("fetch_KB",0)*1024+v.get("write_KB",0)*1024) for k,v in tr.items() if k.startswith("k_")}
-for k in list(traffic):
-    if k.startswith("k_update_output"): traffic["k_update_output"]=traffic[k]
-traffic["_note"]="HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md; WRITE_SIZE uncalibrated); separate --pmc passes; k_conv = launch-weighted average over all conv launches (k_conv_dma tiles + k_conv_mfma) of the frame workload"
+chain=[k for k in ("k_tile_count","k_tile_scatter","k_tile_render","k_tile_holes") if k in traffic]
+if chain: traffic["warp_chain_tiled"]=sum(traffic[k] for k in chain)
+traffic["_note"]="HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md; WRITE_SIZE uncalibrated); separate --pmc passes; k_conv = launch-weighted average over all conv launches (k_conv_dma / k_conv_patch tiles + k_conv_mfma) of the frame workload (batch 8); warp_chain_tiled = sum over the four kernels of one csm_warp_frame_tiled call"
 json.dump(traffic, open("$OUT/traffic.json","w"), indent=1)
-for k,v in sorted(tr.items(), key=lambda kv:-kv[1].get("fetch_KB",0))[:14]: print(k, v)
+for k,v in sorted(tr.items(), key=lambda kv:-kv[1].get("fetch_KB",0))[:16]: print(k, v)
 PY
-find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +1M -delete
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +1M -delete; find $OUT -name "*agent_info.csv" -delete
