@@ -6,20 +6,23 @@
 // sustains.  A wave of consecutive source pixels also lands in one or two 32 x 32 destination tiles.  So:
 //
 //   k_tile_count    per point: process_shift + projection (warp_device.h, the reference's statements), the <= 4 tiles whose
-//                   1-px-expanded area its 2 x 2 footprint touches; ONE integer atomic per distinct tile per wave.
-//   k_tile_scan     exclusive scan of the tile counts (one block), re-arms the counters for the next frame.
-//   k_tile_scatter  same enumeration, writes 16-B entries {fx, fy, fltError, point index} into the tile's segment.
-//   k_tile_render   one 256-thread block per tile, everything else in LDS: z-buffer of the tile + 1-px ring (ds_min_i32 /
+//                   1-px-expanded area its 2 x 2 footprint touches; block-local LDS histogram, then ONE global atomic per
+//                   (block, touched tile) whose return value is the block's base inside that tile's segment.
+//   k_tile_scatter  every block scans the tile totals itself (LDS), recomputes the enumeration and writes 16-B entries
+//                   {fx, fy, fltError, point index} at offs[tile] + base[block][tile] + LDS cursor.  No scan kernel in between.
+//   k_tile_render   one 256-thread block per 32 x 16 tile, everything else in LDS: z-buffer of the tile + 1-px ring (ds_min_i32 /
 //                   ds_max_u32: float min through the sign-split integer trick), Jacobi degrid, z-test + bilinear splat of
-//                   rgb / depth / weight (ds_add_f32), normalise, depth mask, uint8 frame, masked-depth plane, per-tile hole list.
-//   k_tile_holes    one block per tile that has holes: the 16 x 2 directional rays of fill_disocclusion (common.py:145-248)
-//                   march in an LDS copy of the valid map (tile + 32-px apron), continuing in global memory only beyond it.
+//                   rgb / depth / weight into 64-bit FIXED-POINT accumulators (ds_add_u64: ~2x the rate of ds_add_f32 on
+//                   gfx950 and order free, so a frame is bit-reproducible), normalise, depth mask, uint8 frame, masked-depth
+//                   plane, row / column valid BITMAPS (ballot), per-tile hole list; re-arms the tile's counters.
+//   k_tile_holes    flat, balanced list of all holes (prefix scan of the per-tile counts + binary search), 32 lanes per hole =
+//                   16 directions x {from, to} of fill_disocclusion (common.py:145-248); the four axis rays are word scans of
+//                   the row / column bitmaps, the oblique rays probe the bitmap four steps per round trip.
 //
 // No float atomic reaches L2, the accumulator planes never exist in HBM, and the z-buffer decisions are the ones of the r01
 // chain bit for bit (min is order free; the degrid is the same Jacobi form; every comparison is the reference's expression).
-// Algorithmic bytes per frame, N points, P pixels: 12N + 12N (two projections) + 16 x 1.2N (entries written) + 2 x 16 x 1.2N
-// (entries read twice, the second time from L2) + 16N (rgb + depth gathers) + 8P (uint8 frame, valid byte, masked depth) ~=
-// 106 B per pixel at N = P (111 MB at 1024^2) -- against 155 B in the r01 structure, with the L2 atomics gone.
+// Measured at 1024^2, N = P: 96-98 us per frame against 141 us; PMC traffic 120.6 MB per frame against SURVEY's 155 B per pixel
+// = 162.5 MB of algorithmic bytes for the reference's structure (profiles/r02_*).
 #include "warp_device.h"
 #include <cstdlib>
 

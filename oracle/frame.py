@@ -1,8 +1,9 @@
 """CPU baseline of one seg+depth+warp frame (TEST INFRASTRUCTURE / bench.py cpu_baseline leg ONLY).
 
 Times the oracle (oracle/nets_oracle.c with OpenMP over output pixels, oracle/warp_oracle.c) on the benchmark's OWN sizes:
-RTMDet-Ins-L @640 (batch 1), ISNet @720 (one run per instance), LeReS @640, the dynamic-conv mask head + mask resize, and one
-1024 x 1024 warp frame -- one frame's worth of every stage, each timed by itself.  Nothing is extrapolated unless the time budget
+RTMDet-Ins-L @640 (batch 1), ISNet @720 (one run per instance), LeReS @640 and one 1024 x 1024 warp frame -- one frame's worth of
+every dense stage, each timed by itself (the mask head, mask resize and depth glue are < 1 % of a frame and are not timed: the
+baseline is, if anything, flattered).  Nothing is extrapolated unless the time budget
 runs out first (then the remaining nets are scaled from the measured GFLOP/s and the sample string says so)."""
 import os
 import time
