@@ -370,7 +370,7 @@ __device__ __forceinline__ void dma16(unsigned voff, i32x4 rsrc, unsigned lds_by
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_byte_addr) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -443,12 +443,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     auto issue = [&](int stage) {
         const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
         const unsigned sb = (unsigned)stage * (unsigned)(kStageF * 4);
+#ifndef CSM_X_NODMA
 #pragma unroll
         for (int p = 0; p < GA; ++p)
             dma16(((vmA[p] >> l_tap) & 1u) ? offA[p] + coff : kOob, ra, ldsA + sb + (unsigned)p * 1024u);
 #pragma unroll
         for (int p = 0; p < GB; ++p)
             dma16(offB[p] == kOob ? kOob : offB[p] + l_w, rb, ldsB + sb + (unsigned)p * 1024u);
+#endif
         l_w += (unsigned)a.npad * 128u;
         ++l_tap;
         if (++l_kw == a.kw) { l_kw = 0; if (++l_kh == a.kh) { l_kh = 0; l_tap = 0; ++l_cb; } }
@@ -474,10 +476,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             float4 af[TM], bf[TN];
+#ifdef CSM_X_NOLDSREAD
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = float4{1.f + kb, 2.f, 3.f, 4.f + i};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = float4{1.f, 2.f + j, 3.f + kb, 4.f};
+            (void)S;
+#else
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(S + rowA + i * 1024 + sw[kb]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(S + rowB + j * 1024 + sw[kb]);
+#endif
+#ifdef CSM_X_NOMFMA
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af[i].x), "v"(af[i].y), "v"(af[i].z), "v"(af[i].w));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bf[j].x), "v"(bf[j].y), "v"(bf[j].z), "v"(bf[j].w));
+#else
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -488,15 +504,33 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
                         const float bv = t == 0 ? bf[j].x : (t == 1 ? bf[j].y : (t == 2 ? bf[j].z : bf[j].w));
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                     }
+#endif
         }
     };
 
-    issue(0);
-    for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of `chunk` have landed ...
-        __builtin_amdgcn_s_barrier();                          // ... everybody's have, and everybody is done reading stage st^1
-        if (chunk + 1 < T) issue(st ^ 1);
-        compute(st);
+    if constexpr (NS == 2) {
+        issue(0);
+        for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of `chunk` have landed ...
+#ifndef CSM_X_NOBARRIER
+            __builtin_amdgcn_s_barrier();                          // ... everybody's have, and everybody is done reading stage st^1
+#endif
+            if (chunk + 1 < T) issue(st ^ 1);
+            compute(st);
+        }
+    } else {
+        // NS stages: the loads of chunk + NS - 1 are issued while chunk is consumed, so a load may take NS - 1 chunk times
+        // (L2 misses of the short-K-chunk 1x1 layers) before it stalls the pipe.  vmcnt retires in order: "at most
+        // (NS - 2) * (GA + GB) outstanding" == the pieces of `chunk` have landed.
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+            if (c_begin + s0 < T) issue(s0);
+        for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st = (st + 1 == NS ? 0 : st + 1)) {
+            if (chunk + NS - 2 < T) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * (GA + GB)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                          // everybody is done reading the stage refilled next
+            if (chunk + NS - 1 < T) issue(st == 0 ? NS - 1 : st - 1);
+            compute(st);
+        }
     }
 
     // epilogue: lane holds column li of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*lh
@@ -510,6 +544,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#ifdef CSM_X_NOEPI
+                if (m >= 0) continue;
+#endif
                 if (m >= a.M) continue;
                 float v = acc[i][j][r];
                 if (a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
@@ -1258,20 +1295,20 @@ int launch_conv(const ConvArgs &a, hipStream_t st) {
 }
 
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NS = 2>
 int launch_conv_dma(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgs a = a0;
     a.m_tiles = (a.M + BM - 1) / BM;
-    size_t lds = (size_t)2 * (BM + BN) * 128;
+    size_t lds = (size_t)NS * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma<WM, WN, TM, TN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma<WM, WN, TM, TN, NS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * a.ksplit);
-    k_conv_dma<WM, WN, TM, TN><<<grid, 64 * WM * WN, lds, st>>>(a);
+    k_conv_dma<WM, WN, TM, TN, NS><<<grid, 64 * WM * WN, lds, st>>>(a);
     int rc = csm::check_launch("k_conv_dma");
     if (rc || a.ksplit <= 1) return rc;
     k_splitk_reduce<<<(unsigned)(((int64_t)a.M * a.cout_g + 255) / 256), 256, 0, st>>>(a);
@@ -1328,7 +1365,10 @@ enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CF
        // 3x3 patch re-use kernel (k_conv_patch); _w8 = 8-pixel-wide output tiles for small maps
        CFG_P64x64 = 18, CFG_P128x64 = 19, CFG_P64x128 = 20, CFG_P128x128 = 21, CFG_P256x128 = 22, CFG_P128x32 = 23,
        CFG_P64x64_w8 = 24, CFG_P128x128_w8 = 25, CFG_P128x32_w8 = 26, CFG_P128x128_8w = 27,
-       CFG_COUNT = 28 };
+       // three LDS stages (loads two chunks ahead) and 256 x 64 tiles (N = 64 layers: the B tile is shared by four 64 x 64 wave tiles)
+       CFG_D64x64_s3 = 28, CFG_D128x64_s3 = 29, CFG_D64x128_s3 = 30, CFG_D128x128_s3 = 31, CFG_D128x128_8w_s3 = 32,
+       CFG_D256x128_8w_s3 = 33, CFG_D256x64 = 34, CFG_D256x64_s3 = 35, CFG_P256x64 = 36, CFG_D64x64_s4 = 37,
+       CFG_COUNT = 38 };
 static int g_force_cfg = -1;
 static int g_dbg = 0;
 
@@ -1379,6 +1419,16 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_P128x128_w8: return launch_conv_patch<2, 2, 2, 2, 8>(a, st);
         case CFG_P128x32_w8: return launch_conv_patch<4, 1, 1, 1, 8>(a, st);
         case CFG_P128x128_8w: return launch_conv_patch<2, 4, 2, 1, 16>(a, st);
+        case CFG_D64x64_s3: return launch_conv_dma<2, 2, 1, 1, 3>(a, st);
+        case CFG_D128x64_s3: return launch_conv_dma<2, 2, 2, 1, 3>(a, st);
+        case CFG_D64x128_s3: return launch_conv_dma<2, 2, 1, 2, 3>(a, st);
+        case CFG_D128x128_s3: return launch_conv_dma<2, 2, 2, 2, 3>(a, st);
+        case CFG_D128x128_8w_s3: return launch_conv_dma<2, 4, 2, 1, 3>(a, st);
+        case CFG_D256x128_8w_s3: return launch_conv_dma<4, 2, 2, 2, 3>(a, st);
+        case CFG_D256x64: return launch_conv_dma<4, 1, 2, 2>(a, st);
+        case CFG_D256x64_s3: return launch_conv_dma<4, 1, 2, 2, 3>(a, st);
+        case CFG_P256x64: return launch_conv_patch<4, 1, 2, 2, 16>(a, st);
+        case CFG_D64x64_s4: return launch_conv_dma<2, 2, 1, 1, 4>(a, st);
         default: return launch_conv<32, 2, 2, 1>(a, st);
     }
 }
@@ -1439,7 +1489,7 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                     break;
                 }
                 int cfg = (op.tile > 0 && op.tile <= CFG_COUNT && g_force_cfg < 0) ? op.tile - 1 : choose_cfg(a, op.cout_g);
-                if (cfg >= CFG_P64x64 && !patch_eligible(a)) cfg = CFG_D64x64;
+                if (((cfg >= CFG_P64x64 && cfg <= CFG_P128x128_8w) || cfg == CFG_P256x64) && !patch_eligible(a)) cfg = CFG_D64x64;
                 if (cfg == CFG_NARROW && !narrow_eligible(a)) cfg = CFG_64x16;
                 if (cfg >= CFG_D64x64 && cfg != CFG_NARROW && !dma_eligible(a)) cfg = op.cout_g <= 16 ? CFG_64x16 : (op.cout_g <= 32 ? CFG_128x32 : CFG_64x64);
                 rc = launch_conv_cfg(cfg, a, st);

@@ -356,9 +356,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g,
         const int x = (t % g.ntx) * TW + li % TW, y = (t / g.ntx) * TH + li / TW;
         float fx = (float)x, fy = (float)y;
         int ix = 0, iy = 0;
-        bool ok = false;
+        bool ok = false, oblique = false;
         if ((dbg & 256) && (k == 1 || k == 3)) { ok = false; }
         else if ((dbg & 128) && k != 1 && k != 3) { ok = false; }
+        else if (k != 1 && k != 3) { oblique = true; }
         else if (k == 3) {
             // direction (1, 0): the ray visits (x +- j, y) exactly (integer steps are exact in fp32) -> scan the row bitmap by words
             const unsigned *R = out.vbits + (int64_t)y * g.ntx;
@@ -388,9 +389,29 @@ __global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g,
                 while (bits == 0u && --q >= 0) bits = C[q];
                 ok = bits != 0u; iy = ok ? q * 32 + 31 - __clz((int)bits) : -1; ix = x;
             }
-        } else {
-            for (;;) {                                                          // common.py:186-193 / :197-204
-                constexpr int kAhead = 4;        // speculative steps per trip: the positions do not depend on what is read
+        }
+        // Oblique rays (common.py:186-193 / :197-204) march in rounds of kAhead speculative steps.  Between rounds the 16 directions
+        // of the hole share the shortest COMPLETE from-to distance found so far (the axis rays are complete before the first
+        // round): a ray that has already walked further than that cannot belong to the winning direction -- its endpoints are
+        // within 0.71 px of the unrounded positions and at least steps + 2 unit steps apart -- and gives up.  The winner
+        // (strict lexicographic (dist, k) minimum below) is unchanged; rays along a disocclusion band no longer run to the border.
+        bool done = !oblique;
+        float best_so_far = INFINITY;
+        for (int steps = 0;; steps += 4) {
+            constexpr int kAhead = 4;            // speculative steps per trip: the positions do not depend on what is read
+            {
+                const int ox = __shfl_xor(ix, 16), oy = __shfl_xor(iy, 16);
+                const bool pair_ok = done && ok && (__shfl_xor((int)(done && ok), 16) != 0);
+                const float ddx = (float)(ox - ix), ddy = (float)(oy - iy);
+                float m = pair_ok ? sqrtf(ddx * ddx + ddy * ddy) : INFINITY;
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+                best_so_far = fminf(best_so_far, m);
+            }
+            if (!done && (float)steps >= best_so_far) { done = true; ok = false; }   // dist >= steps + 2 - 1.42 > best
+            const unsigned long long waiting = __ballot(!done);
+            if (((waiting >> (tid & 32)) & 0xFFFFFFFFull) == 0ull) break;
+            if (!done) {
                 int jx[kAhead], jy[kAhead], v[kAhead];
 #pragma unroll
                 for (int j = 0; j < kAhead; ++j) { fx += sx; fy += sy; jx[j] = (int)roundf(fx); jy[j] = (int)roundf(fy); }
@@ -406,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g,
                 if (stop >= 0) {
 #pragma unroll
                     for (int j = 0; j < kAhead; ++j) if (j == stop) { ix = jx[j]; iy = jy[j]; ok = v[j] == 1; }
-                    break;
+                    done = true;
                 }
             }
         }
