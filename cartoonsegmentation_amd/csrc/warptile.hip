@@ -81,83 +81,91 @@ __device__ __forceinline__ PointBins bins_of_point(const float *__restrict__ pts
     return b;
 }
 
+// Binning in ONE pass over the points: every tile owns a fixed-capacity segment entries[t * cap .. t * cap + cap).  A block
+// histograms its kPPB points in LDS (the LDS atomic's return value is the entry's rank inside (block, tile)), the rank-0 lane of
+// every touched tile reserves the block's run in the tile's segment with ONE global atomic, then every lane writes its entries at
+// segment + run start + rank.  No counting pre-pass, no scan, no per-block offset table.  (Round-2 history: a separate count
+// kernel + per-block scan of the totals in the scatter kernel cost 8.7 + 10 us at 1024^2; the first design with one global
+// atomic per distinct tile per wave cost 49 us -- same-line device-scope atomics serialise at the memory side.)
+// Capacity is ~2.5x the expected load (tile_cap below).  Entries beyond it go to a global spill list that every render block
+// filters by tile id: exact for any input, slow only for pathological clouds (thousands of points in one 32 x 16 tile).
+// Which point does (block, slot q of kPPB) handle?  The cloud's first H * W points are the frame's own pixels in row-major order
+// (kenburns_effect.py:928-933; inpainting appends the rest), so when W is a multiple of 32 a block takes a 32 x 32 PATCH of that
+// grid instead of 1024 consecutive points: its footprints then fall into ~4 tiles instead of ~40 (fewer, longer runs per tile and
+// 8x fewer global reservations; measured 16.9 -> 15.4 us for the bin pass, 36.2 -> 35.3 us for the render pass).  Purely a locality choice: any cloud gives the same frame under either mapping.
+struct PointMap { int64_t patched; int patches_x, W; };   // points below `patched` are visited patch-wise
+__host__ __device__ inline PointMap make_point_map(int H, int W, int64_t N) {
+    PointMap m; m.W = W; m.patches_x = W / 32; m.patched = 0;
+    if (W % 32 == 0 && W >= 32) {
+        const int64_t grid = N < (int64_t)H * W ? N : (int64_t)H * W;
+        m.patched = grid / (32 * (int64_t)W) * (32 * (int64_t)W);           // whole 32-row bands
+    }
+    return m;
+}
+__device__ __forceinline__ int64_t point_of(const PointMap &m, int64_t block, int q) {
+    const int64_t lin = block * kPPB + q;
+    if (lin >= m.patched - (m.patched % kPPB)) return lin;                   // (patched is a multiple of 32 W = patches_x * kPPB)
+    const int64_t band = block / m.patches_x; const int px = (int)(block - band * m.patches_x);
+    return (band * 32 + (q >> 5)) * m.W + px * 32 + (q & 31);
+}
+
+constexpr int kTotalStride = 32;       // ints between two tiles' global counters: one 128-B line each (same-line atomics serialise)
+
+// Binning in ONE pass over the points: every tile owns a fixed-capacity segment entries[t * cap .. t * cap + cap).  A block
+// histograms its kPPB points in LDS (the LDS atomic's return value is the entry's rank inside (block, tile)), the rank-0 lane of
+// every touched tile
+// reserves the block's run in the tile's segment with ONE global atomic, then every lane writes its entries at
+// segment + run start + rank.  No counting pre-pass, no scan, no per-block offset table.  (Round-2 history: a separate count
+// kernel + per-block scan of the totals in the scatter kernel cost 8.7 + 10 us at 1024^2; the first design with one global
+// atomic per distinct tile per wave cost 49 us -- same-line device-scope atomics serialise at the memory side.)
+// Capacity is ~2.5x the expected load (tile_cap below).  Entries beyond it go to a global spill list that every render block
+// filters by tile id: exact for any input, slow only for pathological clouds (thousands of points in one 32 x 16 tile).
 template <bool SHIFT>
-__global__ __launch_bounds__(kBlock) void k_tile_count(const float *__restrict__ pts, int64_t N, ProjConst pc, Shift s, TileGeom g,
-                                                        int *__restrict__ tile_total, int *__restrict__ blockbase) {
-    extern __shared__ int hist[];                     // [nt]
+__global__ __launch_bounds__(kBlock) void k_tile_bin(const float *__restrict__ pts, int64_t N, ProjConst pc, Shift s, TileGeom g, int cap,
+                                                      PointMap pm, int *__restrict__ tile_total, Entry *__restrict__ entries,
+                                                      Entry *__restrict__ spill, int *__restrict__ spill_tile, int *__restrict__ spill_count) {
+    extern __shared__ int lds_bin[];                  // hist[nt] | base[nt]
+    int *hist = lds_bin, *base = lds_bin + g.nt;
     for (int t = threadIdx.x; t < g.nt; t += kBlock) hist[t] = 0;
     __syncthreads();
-    const int64_t p0 = (int64_t)blockIdx.x * kPPB + threadIdx.x;
-#pragma unroll 2
-    for (int i = 0; i < kPPT; ++i) {
-        const PointBins b = bins_of_point<SHIFT>(pts, N, p0 + (int64_t)i * kBlock, pc, s, g);
-        if (!b.ok) continue;
-        for (int ty = b.tyl; ty <= b.tyh; ++ty)
-            for (int tx = b.txl; tx <= b.txh; ++tx) atomicAdd(&hist[ty * g.ntx + tx], 1);
-    }
-    __syncthreads();
-    int *bb = blockbase + (int64_t)blockIdx.x * g.nt;
-    for (int t = threadIdx.x; t < g.nt; t += kBlock) {
-        const int c = hist[t];
-        if (c) bb[t] = atomicAdd(tile_total + t, c);
-    }
-}
-
-// exclusive scan of a[0..n) in LDS by one block (n <= 8192): consecutive runs per thread + wave shuffle scan + wave totals.
-// On return a[i] holds the exclusive prefix and the function returns the grand total (all threads).
-__device__ __forceinline__ int block_exclusive_scan(int *a, int n, int *wsum /* [kBlock/64] */) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (n + kBlock - 1) / kBlock;
-    const int b = tid * per, e = b + per < n ? b + per : n;
-    int sum = 0;
-    for (int i = b; i < e; ++i) sum += a[i];
-    int inc = sum;
+    PointBins b[kPPT];
+    int64_t pidx[kPPT];
+    int rank[kPPT][4];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int run = inc - sum, total = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) { const int v = wsum[w]; run += (w < wave) ? v : 0; total += v; }
-    for (int i = b; i < e; ++i) { const int c = a[i]; a[i] = run; run += c; }
-    __syncthreads();
-    return total;
-}
-
-// Scatter pass.  Every block scans the tile totals itself (8 KB of L2 reads and ~1 us, in parallel on all CUs) instead of waiting
-// for a one-block scan kernel (4.8 us + a kernel boundary); block 0 also publishes the offsets for k_tile_render.
-template <bool SHIFT>
-__global__ __launch_bounds__(kBlock) void k_tile_scatter(const float *__restrict__ pts, int64_t N, ProjConst pc, Shift s, TileGeom g,
-                                                          const int *__restrict__ totals, int *__restrict__ offs,
-                                                          const int *__restrict__ blockbase, Entry *__restrict__ entries) {
-    extern __shared__ int cur[];                      // [nt]; entries of tiles this block does not touch are never used
-    __shared__ int wsum[kBlock / 64];
-    for (int t = threadIdx.x; t < g.nt; t += kBlock) cur[t] = totals[t];
-    __syncthreads();
-    const int total = block_exclusive_scan(cur, g.nt, wsum);
-    const int *bb = blockbase + (int64_t)blockIdx.x * g.nt;
-    if (blockIdx.x == 0) {
-        for (int t = threadIdx.x; t < g.nt; t += kBlock) offs[t] = cur[t];
-        if (threadIdx.x == 0) offs[g.nt] = total;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < g.nt; t += kBlock) cur[t] += bb[t];
-    __syncthreads();
-    const int64_t p0 = (int64_t)blockIdx.x * kPPB + threadIdx.x;
-#pragma unroll 2
     for (int i = 0; i < kPPT; ++i) {
-        const int64_t p = p0 + (int64_t)i * kBlock;
-        const PointBins b = bins_of_point<SHIFT>(pts, N, p, pc, s, g);
-        if (!b.ok) continue;
-        Entry e; e.fx = b.fx; e.fy = b.fy; e.err = b.err; e.idx = (int)p;
-        for (int ty = b.tyl; ty <= b.tyh; ++ty)
-            for (int tx = b.txl; tx <= b.txh; ++tx) entries[atomicAdd(&cur[ty * g.ntx + tx], 1)] = e;
+        pidx[i] = point_of(pm, blockIdx.x, i * kBlock + threadIdx.x);
+        b[i] = bins_of_point<SHIFT>(pts, N, pidx[i], pc, s, g);
     }
-}
-
-// N == 0: no scatter pass runs; publish all-zero offsets
-__global__ __launch_bounds__(kBlock) void k_tile_zero_offs(int *__restrict__ offs, int nt) {
-    for (int t = blockIdx.x * kBlock + threadIdx.x; t <= nt; t += gridDim.x * kBlock) offs[t] = 0;
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ty = b[i].tyl + (j >> 1), tx = b[i].txl + (j & 1);
+            // (a ballot-aggregated rank -- one LDS atomic per distinct tile per wave -- measured 3 us SLOWER than the plain atomic)
+            rank[i][j] = (b[i].ok && ty <= b[i].tyh && tx <= b[i].txh) ? atomicAdd(&hist[ty * g.ntx + tx], 1) : -1;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (rank[i][j] == 0) {
+                const int t = (b[i].tyl + (j >> 1)) * g.ntx + b[i].txl + (j & 1);
+                base[t] = atomicAdd(tile_total + (int64_t)t * kTotalStride, hist[t]);
+            }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i) {
+        Entry e; e.fx = b[i].fx; e.fy = b[i].fy; e.err = b[i].err; e.idx = (int)pidx[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (rank[i][j] < 0) continue;
+            const int t = (b[i].tyl + (j >> 1)) * g.ntx + b[i].txl + (j & 1);
+            const int slot = base[t] + rank[i][j];
+            if (slot < cap) entries[(int64_t)t * cap + slot] = e;
+            else { const int q = atomicAdd(spill_count, 1); spill[q] = e; spill_tile[q] = t; }
+        }
+    }
 }
 
 struct FrameOut {
@@ -168,8 +176,11 @@ struct FrameOut {
     float *render;           // [4,P] or null
     unsigned short *holes;   // [nt][TPIX] tile-local pixel ids
     int *hole_count;         // [nt]
-    int *totals;             // [nt] bin counters of k_tile_count (zeroed here for the next frame)
+    int *totals;             // [nt] bin counters of k_tile_bin (zeroed here for the next frame)
     int cpitch;              // half-words per column of cbits (nty rounded up to even)
+    const Entry *spill;      // entries that did not fit their tile's segment, with their tile ids; *spill_count of them
+    const int *spill_tile;
+    int *spill_count;        // re-armed by k_tile_holes (the kernel after the last reader)
 };
 
 __device__ __forceinline__ void lds_min_f32(float *addr, float v) {        // warp_device.h::atomic_min_f32 on LDS
@@ -194,7 +205,7 @@ __device__ __forceinline__ unsigned long long to_fixed(float prod, float scale) 
 }
 __device__ __forceinline__ float from_fixed(unsigned long long q, double inv_scale) { return (float)((double)(long long)q * inv_scale); }
 
-__global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict__ entries, const int *__restrict__ offs,
+__global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict__ entries, int cap,
                                                          const float *__restrict__ rgb, const float *__restrict__ depth, int64_t N,
                                                          int H, int W, TileGeom g, FrameOut out, int dbg) {
     __shared__ float zee[ZH * ZW];
@@ -208,18 +219,40 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
     for (int i = tid; i < 5 * TPIX; i += kBlock) acc[i] = 0ull;
     if (tid == 0) nholes = 0;
     __syncthreads();
-    const int e0 = offs[t], e1 = offs[t + 1];
+    const int total = out.totals[(int64_t)t * kTotalStride];
+    const int e0 = (int)0, e1 = total < cap ? total : cap;
+    entries += (int64_t)t * cap;
+    const int nspill = total > cap ? *out.spill_count : 0;                     // only an overflowing tile has entries on the spill list
     // ---- updateZee (models/utils.py:101-147) on the window ------------------------------------------------------------------
-    for (int e = e0 + tid; e < e1; e += kBlock) {
-        const Entry en = entries[e];
+    auto zee_entry = [&](const Entry &en) {
         int x0, y0, cx, cy; float w[4];
         corner_weights(en.fx, en.fy, x0, y0, w);
-        if (!argmax_corner(w, x0, y0, cx, cy)) continue;
-        if (cx < 0 || cx >= W || cy < 0 || cy >= H) continue;
+        if (!argmax_corner(w, x0, y0, cx, cy)) return;
+        if (cx < 0 || cx >= W || cy < 0 || cy >= H) return;
         const int lx = cx - (tx0 - 1), ly = cy - (ty0 - 1);
-        if (lx < 0 || lx >= ZW || ly < 0 || ly >= ZH) continue;
+        if (lx < 0 || lx >= ZW || ly < 0 || ly >= ZH) return;
         lds_min_f32(&zee[ly * ZW + lx], en.err);
+    };
+    // The first kReg * kBlock entries of the tile (all of them unless the tile is crowded) stay in registers for both passes, and
+    // their colours are requested NOW: the gather's round trip runs under the z pass, the degrid and two barriers instead of in
+    // front of the splat (all blocks of a CU reach the same phase together, so exposed latency is not hidden by other blocks).
+    constexpr int kReg = 4;
+    Entry en[kReg]; bool has[kReg]; float c0[kReg], c1[kReg], c2[kReg], c3[kReg];
+#pragma unroll
+    for (int k = 0; k < kReg; ++k) {
+        const int e = e0 + tid + k * kBlock;
+        has[k] = e < e1;
+        en[k] = has[k] ? entries[e] : Entry{0.0f, 0.0f, 0.0f, 0};
     }
+#pragma unroll
+    for (int k = 0; k < kReg; ++k) {
+        c0[k] = c1[k] = c2[k] = c3[k] = 0.0f;
+        if (has[k]) { const int64_t p = en[k].idx; c0[k] = rgb[p]; c1[k] = rgb[N + p]; c2[k] = rgb[2 * N + p]; c3[k] = depth[p]; }
+    }
+#pragma unroll
+    for (int k = 0; k < kReg; ++k) if (has[k]) zee_entry(en[k]);
+    for (int e = e0 + tid + kReg * kBlock; e < e1; e += kBlock) zee_entry(entries[e]);
+    for (int e = tid; e < nspill; e += kBlock) if (out.spill_tile[e] == t) zee_entry(out.spill[e]);
     __syncthreads();
     // ---- updateDegrid (models/utils.py:152-212), Jacobi form ------------------------------------------------------------------
     for (int i = tid; i < TPIX; i += kBlock) {
@@ -244,10 +277,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
     }
     __syncthreads();
     // ---- updateOutput (models/utils.py:215-313): z-test + bilinear splat, C = rgb + depth, + the ones channel -------------------
-    for (int e = e0 + tid; e < e1 && !(dbg & 2); e += kBlock) {
-        const Entry en = entries[e];
+    auto splat = [&](const Entry &e, bool gather, float v0, float v1, float v2, float v3) {
         int x0, y0; float w[4];
-        corner_weights(en.fx, en.fy, x0, y0, w);
+        corner_weights(e.fx, e.fy, x0, y0, w);
         int li[4]; bool pass[4]; bool any = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -255,12 +287,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
             const int lx = cx - tx0, ly = cy - ty0;
             const bool in = lx >= 0 && lx < TW && ly >= 0 && ly < TH && cx < W && cy < H;      // cx, cy >= 0 follows from lx, ly >= 0
             li[k] = in ? ly * TW + lx : 0;
-            pass[k] = in && ((double)en.err <= (double)zd[li[k]] + 1.0);
+            pass[k] = in && ((double)e.err <= (double)zd[li[k]] + 1.0);
             any = any || pass[k];
         }
-        if (!any) continue;
-        const int64_t p = en.idx;
-        const float v0 = rgb[p], v1 = rgb[N + p], v2 = rgb[2 * N + p], v3 = depth[p];
+        if (!any) return;
+        if (gather) { const int64_t p = e.idx; v0 = rgb[p]; v1 = rgb[N + p]; v2 = rgb[2 * N + p]; v3 = depth[p]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!pass[k]) continue;
@@ -271,6 +302,12 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
             atomicAdd(&acc[3 * TPIX + li[k]], to_fixed(v3 * wk, kScaleD));
             atomicAdd(&acc[4 * TPIX + li[k]], to_fixed(1.0f * wk, kScaleC));
         }
+    };
+    if (!(dbg & 2)) {
+#pragma unroll
+        for (int k = 0; k < kReg; ++k) if (has[k]) splat(en[k], false, c0[k], c1[k], c2[k], c3[k]);
+        for (int e = e0 + tid + kReg * kBlock; e < e1; e += kBlock) splat(entries[e], true, 0.0f, 0.0f, 0.0f, 0.0f);
+        for (int e = tid; e < nspill; e += kBlock) if (out.spill_tile[e] == t) splat(out.spill[e], true, 0.0f, 0.0f, 0.0f, 0.0f);
     }
     __syncthreads();
     // ---- models/utils.py:315 normalise; kenburns_effect.py:1039-1040 depth mask + uint8; hole list for fill_disocclusion --------
@@ -298,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
         if (!okp) out.holes[(int64_t)t * TPIX + atomicAdd(&nholes, 1)] = (unsigned short)i;
     }
     __syncthreads();
-    if (tid == 0) { out.hole_count[t] = nholes; out.totals[t] = 0; }           // the bin counter is re-armed for the next frame
+    if (tid == 0) { out.hole_count[t] = nholes; out.totals[(int64_t)t * kTotalStride] = 0; }           // the bin counter is re-armed for the next frame
     if (tid < TW && tx0 + tid < W) {                                            // 16 x 32 bit transpose: a half-word per column
         unsigned c = 0;
 #pragma unroll
@@ -340,6 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g,
         __syncthreads();
     }
     const int total = prefix[g.nt];
+    if (blockIdx.x == 0 && tid == 0) *out.spill_count = 0;                      // every reader (k_tile_render) has finished
     const int lane32 = tid & 31, k = lane32 & 15;
     const bool to = lane32 >= 16;
     float dx = kDirX[k], dy = kDirY[k];
@@ -459,37 +497,49 @@ __global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g,
 }
 
 // scratch layout (bytes, 16-B aligned sections):
-//   header ints : totals[nt] (zero between frames) | offs[nt+1] | hole_count[nt]
-//   vbits[H * ntx] (u32) | cbits[W * cpitch] (u16) | mdepth[P] (f32) | holes[nt * TPIX] (u16) | blockbase[nblocks * nt] (int) |
-//   entries[4 * N] (16 B)
-struct TileScratch { int *totals, *offs, *hole_count; unsigned *vbits; unsigned short *cbits; float *mdepth; unsigned short *holes;
-                     int *blockbase; Entry *entries; int cpitch; };
+//   header ints : totals[nt * kTotalStride] (one 128-B line per tile; zero between frames) | hole_count[nt] | spill_count (zero between frames)
+//   vbits[H * ntx] (u32) | cbits[W * cpitch] (u16) | mdepth[P] (f32) | holes[nt * TPIX] (u16) | entries[nt * cap] (16 B) |
+//   spill entries[4 N] (16 B) | spill tiles[4 N] (int)
+struct TileScratch { int *totals, *hole_count, *spill_count; unsigned *vbits; unsigned short *cbits; float *mdepth; unsigned short *holes;
+                     Entry *entries, *spill; int *spill_tile; int cpitch, cap; };
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
-inline size_t header_bytes(int nt) { return align16(sizeof(int) * (size_t)(3 * nt + 1)); }
+inline size_t header_bytes(int nt) { return align16(sizeof(int) * ((size_t)nt * kTotalStride + nt + 1)); }
 inline size_t bin_blocks(int64_t N) { return (size_t)((N + kPPB - 1) / kPPB); }
-struct Sizes { size_t vbits, cbits, mdepth, holes, blockbase; int cpitch; };
+// segment capacity per tile: 2.5x the load of a uniform cloud (N / P points per pixel, x 1.21 for the shared 1-px borders), at
+// least 1024, a multiple of 64.  Monotone in N, so a scratch sized for a larger N serves every smaller one.
+inline int tile_cap(int H, int W, int64_t N) {
+    const double per_tile = (double)N * TPIX / ((double)H * W) * 1.21;
+    int64_t c = (int64_t)(per_tile * 2.5) + 63;
+    c -= c % 64;
+    return (int)(c < 1024 ? 1024 : (c > (1 << 24) ? (1 << 24) : c));
+}
+struct Sizes { size_t vbits, cbits, mdepth, holes, entries, spill, spill_tile; int cpitch, cap; };
 inline Sizes section_sizes(int H, int W, int64_t N) {
     const TileGeom g = tile_geom(H, W);
     Sizes z; z.cpitch = g.nty + (g.nty & 1);          // half-words per column, padded to whole 32-row words
+    z.cap = tile_cap(H, W, N);
     z.vbits = align16(4 * (size_t)H * g.ntx);
     z.cbits = align16(2 * (size_t)W * z.cpitch);
     z.mdepth = align16(4 * (size_t)H * W);
     z.holes = align16(2 * (size_t)g.nt * TPIX);
-    z.blockbase = align16(4 * bin_blocks(N) * (size_t)g.nt);
+    z.entries = align16(16 * (size_t)g.nt * z.cap);
+    z.spill = align16(16 * 4 * (size_t)N + 16);
+    z.spill_tile = align16(4 * 4 * (size_t)N + 16);
     return z;
 }
 inline TileScratch carve(void *scratch, int H, int W, int nt, int64_t N) {
     const Sizes z = section_sizes(H, W, N);
     TileScratch s; char *p = (char *)scratch;
-    s.totals = (int *)p; s.offs = s.totals + nt; s.hole_count = s.offs + nt + 1;
+    s.totals = (int *)p; s.hole_count = s.totals + (size_t)nt * kTotalStride; s.spill_count = s.hole_count + nt;
     p += header_bytes(nt);
     s.vbits = (unsigned *)p; p += z.vbits;
     s.cbits = (unsigned short *)p; p += z.cbits;
     s.mdepth = (float *)p; p += z.mdepth;
     s.holes = (unsigned short *)p; p += z.holes;
-    s.blockbase = (int *)p; p += z.blockbase;
-    s.entries = (Entry *)p;
-    s.cpitch = z.cpitch;
+    s.entries = (Entry *)p; p += z.entries;
+    s.spill = (Entry *)p; p += z.spill;
+    s.spill_tile = (int *)p;
+    s.cpitch = z.cpitch; s.cap = z.cap;
     return s;
 }
 
@@ -498,7 +548,7 @@ inline TileScratch carve(void *scratch, int H, int W, int nt, int64_t N) {
 extern "C" size_t csm_warp_tile_scratch_bytes(int H, int W, int64_t N) {
     if (H <= 0 || W <= 0 || N < 0) return 0;
     const Sizes z = section_sizes(H, W, N);
-    return header_bytes(tile_geom(H, W).nt) + z.vbits + z.cbits + z.mdepth + z.holes + z.blockbase + 16 * 4 * (size_t)N + 16;
+    return header_bytes(tile_geom(H, W).nt) + z.vbits + z.cbits + z.mdepth + z.holes + z.entries + z.spill + z.spill_tile;
 }
 
 extern "C" size_t csm_warp_tile_header_bytes(int H, int W) { return (H <= 0 || W <= 0) ? 0 : header_bytes(tile_geom(H, W).nt); }
@@ -525,19 +575,14 @@ extern "C" int csm_warp_frame_tiled(const float *pts, const float *rgb, const fl
     const unsigned nb = (unsigned)bin_blocks(N);
     int rc;
     if (N > 0) {
-        k_tile_count<true><<<nb, kBlock, lds, st>>>(pts, N, pc, s, g, ts.totals, ts.blockbase);
-        rc = csm::check_launch("k_tile_count"); if (rc) return rc;
+        k_tile_bin<true><<<nb, kBlock, 2 * sizeof(int) * (size_t)g.nt, st>>>(pts, N, pc, s, g, ts.cap, make_point_map(H, W, N), ts.totals,
+                                                                              ts.entries, ts.spill, ts.spill_tile, ts.spill_count);
+        rc = csm::check_launch("k_tile_bin"); if (rc) return rc;
     }
-    if (N > 0) {
-        k_tile_scatter<true><<<nb, kBlock, lds, st>>>(pts, N, pc, s, g, ts.totals, ts.offs, ts.blockbase, ts.entries);
-        rc = csm::check_launch("k_tile_scatter"); if (rc) return rc;
-    } else {
-        k_tile_zero_offs<<<8, kBlock, 0, st>>>(ts.offs, g.nt);
-        rc = csm::check_launch("k_tile_zero_offs"); if (rc) return rc;
-    }
-    FrameOut out{frame_u8, ts.vbits, ts.cbits, ts.mdepth, render_filled, ts.holes, ts.hole_count, ts.totals, ts.cpitch};
+    FrameOut out{frame_u8, ts.vbits, ts.cbits, ts.mdepth, render_filled, ts.holes, ts.hole_count, ts.totals, ts.cpitch,
+                 ts.spill, ts.spill_tile, ts.spill_count};
     if (!(g_tile_dbg & 64)) {
-        k_tile_render<<<g.nt, kBlock, 0, st>>>(ts.entries, ts.offs, rgb, depth, N, H, W, g, out, g_tile_dbg);
+        k_tile_render<<<g.nt, kBlock, 0, st>>>(ts.entries, ts.cap, rgb, depth, N, H, W, g, out, g_tile_dbg);
         rc = csm::check_launch("k_tile_render"); if (rc) return rc;
     }
     if (!(g_tile_dbg & 32)) {

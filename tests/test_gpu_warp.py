@@ -186,6 +186,15 @@ def test_tiled_frame_edge_cases(ops):
     fo, eo, fro = orc.warp_frame(pp, np.concatenate([cc, dd], 1), H, W, 35.0, 40.0, np.zeros(3, np.float32), 1)
     assert close_frac(rn.cpu().numpy(), fo, 1e-3, 1e-4) >= 0.999
     assert (np.abs(fr.cpu().numpy().astype(np.int32) - fro.astype(np.int32)) <= 1).mean() >= 0.999
+    # the pile-up overflows the tile's fixed-capacity segment (entries go through the spill list): the frame must be reproducible
+    # bit for bit (order-free fixed-point sums), and the next, ordinary frame on the same scratch must not see stale spill entries
+    fr1, rn1 = fr.clone(), rn.clone()
+    fr, rn = wf(dev(pp), dev(cc), dev(dd), 35.0, 40.0, [0.0, 0.0, 0.0])
+    assert torch.equal(fr, fr1) and torch.equal(rn, rn1)
+    fr, rn = wf(dev(p), dev(rgb), dev(dep), sc['focal'], sc['baseline'], shift)
+    w2 = ops.WarpFrame(H, W, 'cuda', keep_render=True, path='tiled')
+    fr2, rn2 = w2(dev(p), dev(rgb), dev(dep), sc['focal'], sc['baseline'], shift)
+    assert torch.equal(fr, fr2) and torch.equal(rn, rn2)
 
 
 def test_properties_full_size(ops):
