@@ -441,7 +441,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     int l_kh = l_tap / a.kw, l_kw = l_tap - l_kh * a.kw;
     unsigned l_w = (unsigned)(((int64_t)g * Tall + c_begin) * a.npad * 128);     // byte offset of the chunk's weight tile
     auto issue = [&](int stage) {
+#ifdef CSM_X_HOTDMA            // experiment: every chunk re-loads the first chunk's bytes (same instruction stream, all cache hits)
+        const unsigned coff = 0u;
+        l_w = (unsigned)(((int64_t)g * Tall + c_begin) * a.npad * 128);
+#else
         const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
+#endif
         const unsigned sb = (unsigned)stage * (unsigned)(kStageF * 4);
 #ifndef CSM_X_NODMA
 #pragma unroll
