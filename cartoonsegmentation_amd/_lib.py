@@ -38,6 +38,7 @@ def load():
         _lib.csm_fill_disocclusion_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_nms_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_autozoom_scratch_floats.restype = ctypes.c_size_t
+        _lib.csm_autozoom_band_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_warp_tile_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_warp_tile_header_bytes.restype = ctypes.c_size_t
         _lib.csm_percentile_scratch_bytes.restype = ctypes.c_size_t

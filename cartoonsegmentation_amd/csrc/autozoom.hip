@@ -21,6 +21,8 @@
 // HBM-bound: 24 B per pixel and candidate (fill 4, atomic RMW 4, degrid 4+4, z-test reads 4, marks + count 4) on top of the
 // atomics; a chunk of 32 planes at 1024^2 (256 MB for A and B) stays inside the 256 MB Infinity Cache.
 #include "warp_device.h"
+#include <algorithm>
+#include <vector>
 
 namespace {
 using namespace csmwarp;
@@ -239,6 +241,224 @@ __global__ __launch_bounds__(kBlock) void k_az_cover(const float *__restrict__ p
     }
 }
 
+
+// ---- band path -------------------------------------------------------------------------------------------------------------------
+// All candidates of one search share the z shift, and the 16 x 16 grid of common.py:96-108 has 16 distinct y shifts: candidates
+// with the same (sy, sz) differ only in fx (warp_device.h::project_yz / project_x) -- a point lands in the same ROWS for all of
+// them.  So: group the candidates by sy; per group bin the points ONCE by destination row band (BR rows, full width); then one
+// 1024-thread block per (band, group) keeps the band's z-buffer (+ 1-row halo) and its degridded copy in LDS, holds the band's
+// entries {x r, dist, fy, err} in registers, and runs z pass / Jacobi degrid / z-test marks / count for each of the group's
+// candidates without touching HBM: per candidate the chip moves nothing but a 4-byte partial count per band.  (The plane path
+// above streams 24 B per pixel and candidate through L2 atomics and is bound by L2 lane operations: 22.8 us per candidate at
+// 1024^2.)  A band segment that overflows its capacity raises a flag the caller reads together with the counts and falls back
+// to the plane path, so the result is exact for every cloud.
+constexpr int kGroupMax = 16, kPerGroup = 16;          // groups per launch, candidates per group
+constexpr int kBandThreads = 1024;
+constexpr size_t kBandLds = 150 * 1024;                // LDS per block: window + degridded band + as many cached entries as fit
+constexpr int kCountStride = 32;                        // ints between two segment counters (one 128-B line each)
+struct Groups { int ng; float sz; float sy[kGroupMax]; int n[kGroupMax]; float sx[kGroupMax][kPerGroup]; int out[kGroupMax][kPerGroup]; };
+struct BandEntry { float xr, dist, fy, err; };          // x * z/(z + 1e-7), ray factor, projected row coordinate, fltError
+struct BandGeom { int br, nbands, cap, ncache; };       // ncache: entries of a band kept in LDS (the rest is re-read per candidate)
+
+// largest float t with (double)t <= d (NaN stays NaN): turns the reference's mixed-precision tests `(double)e <= (double)z + 1.0`
+// into ONE fp32 compare against a per-pixel threshold -- e <= t  <=>  (double)e <= d, because the floats <= d are exactly those <= t
+__device__ __forceinline__ float round_down_f32(double d) {
+    float t = (float)d;
+    if ((double)t > d) {
+        const unsigned u = __float_as_uint(t);
+        t = t > 0.0f ? __uint_as_float(u - 1u) : (t < 0.0f ? __uint_as_float(u + 1u) : __uint_as_float(0x80000001u));
+    }
+    return t;
+}
+
+// bands whose window rows [b*br - 1, b*br + br] meet the footprint rows [y0, y0 + 1]
+__device__ __forceinline__ void band_range(int y0, int br, int nb, int &lo, int &hi) {
+    const int a = y0 - br;                                                     // b >= ceil((y0 - br) / br)
+    lo = a >= 0 ? (a + br - 1) / br : -((-a) / br);
+    const int c = y0 + 2;                                                      // b <= floor((y0 + 2) / br)
+    hi = c >= 0 ? c / br : -((-c + br - 1) / br);
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > nb - 1 ? nb - 1 : hi;
+}
+
+// (Groups travels through device memory: a 2 KB by-value kernel argument indexed by blockIdx is copied to scratch by hipcc --
+// 588 B of private memory per lane and 6 ms per search in the first version of k_band_cover)
+__global__ __launch_bounds__(kBlock) void k_band_bin(const float *__restrict__ pts, int64_t N, ProjConst pc, const Groups *__restrict__ grp,
+                                                      BandGeom bg, int *__restrict__ seg_count, BandEntry *__restrict__ entries,
+                                                      int *__restrict__ overflow) {
+    extern __shared__ int lds_i[];                     // hist[nbands] | base[nbands]
+    int *hist = lds_i, *base = lds_i + bg.nbands;
+    const int g = blockIdx.y;
+    const float gsy = grp->sy[g], gsz = grp->sz;
+    for (int t = threadIdx.x; t < bg.nbands; t += kBlock) hist[t] = 0;
+    __syncthreads();
+    constexpr int kPPT = 4;
+    BandEntry e[kPPT]; int lo[kPPT], hi[kPPT], rank[kPPT][3];
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i) {
+        const int64_t p = ((int64_t)blockIdx.x * kPPT + i) * kBlock + threadIdx.x;
+        lo[i] = 0; hi[i] = -1;
+        e[i] = BandEntry{0.f, 0.f, 0.f, 0.f};
+        if (p < N) {
+            float x = pts[p], y = pts[N + p], z = pts[2 * N + p];
+            const float r = z / (z + 0.0000001f);                               // common.py:78-81, the x shift is added per candidate
+            x = x * r; y = y * r + gsy; z = z + gsz;
+            float dist, fy, err;
+            if (project_yz(y, z, pc, dist, fy, err) && fy > -4.0f && fy < (float)(pc.H + 4)) {
+                e[i] = BandEntry{x, dist, fy, err};
+                band_range((int)floorf(fy), bg.br, bg.nbands, lo[i], hi[i]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rank[i][j] = lo[i] + j <= hi[i] ? atomicAdd(&hist[lo[i] + j], 1) : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (rank[i][j] == 0) {
+                const int b = lo[i] + j;
+                base[b] = atomicAdd(seg_count + ((int64_t)g * bg.nbands + b) * kCountStride, hist[b]);
+            }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (rank[i][j] < 0) continue;
+            const int b = lo[i] + j, slot = base[b] + rank[i][j];
+            if (slot < bg.cap) entries[((int64_t)g * bg.nbands + b) * bg.cap + slot] = e[i];
+            else *overflow = 1;
+        }
+}
+
+__global__ __launch_bounds__(kBandThreads) void k_band_cover(ProjConst pc, const Groups *__restrict__ grp, BandGeom bg, int *__restrict__ seg_count,
+                                                              const BandEntry *__restrict__ entries, int *__restrict__ partial /* [ng][kPerGroup][nbands] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];   // zee[(br + 2) * W] | zd[br * W] | cached entries
+    const int W = pc.W, H = pc.H, br = bg.br;
+    float *zee = lds_f, *zd = lds_f + (size_t)(br + 2) * W;
+    __shared__ int red[kBandThreads / 64];
+    const int band = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int r0 = band * br;                          // first interior row; window row 0 is image row r0 - 1
+    int *cnt = seg_count + ((int64_t)g * bg.nbands + band) * kCountStride;
+    const int total = *cnt < bg.cap ? *cnt : bg.cap;
+    const BandEntry *E = entries + ((int64_t)g * bg.nbands + band) * bg.cap;
+    BandEntry *ce = reinterpret_cast<BandEntry *>(zd + (size_t)br * W);         // LDS cache of the band's entries (16-B aligned: W % 2 == 0 checked by the host)
+    const int ncache = total < bg.ncache ? total : bg.ncache;
+    for (int i = tid; i < ncache; i += kBandThreads) ce[i] = E[i];
+    const int nwin = (br + 2) * W, nint = br * W;
+    const int ncand = grp->n[g];
+    for (int c = 0; c < ncand; ++c) {
+        const float sx = grp->sx[g][c];
+        for (int i = tid; i < nwin; i += kBandThreads) zee[i] = 1000000.0f;     // models/utils.py:59
+        __syncthreads();                                                        // (also publishes the entry cache on the first trip)
+        // ---- updateZee (models/utils.py:101-147)
+        auto zpass = [&](const BandEntry &e) {
+            const float fx = project_x(e.xr + sx, e.dist, pc);
+            int x0, y0, cx, cy; float w[4];
+            corner_weights(fx, e.fy, x0, y0, w);
+            if (!argmax_corner(w, x0, y0, cx, cy)) return;
+            const int ly = cy - (r0 - 1);
+            if (cx >= 0 && cx < W && cy >= 0 && cy < H && ly >= 0 && ly < br + 2) {
+                float *a = &zee[ly * W + cx];
+                if (e.err >= 0.0f) atomicMin(reinterpret_cast<int *>(a), __float_as_int(e.err));
+                else atomicMax(reinterpret_cast<unsigned int *>(a), __float_as_uint(e.err));
+            }
+        };
+        for (int i = tid; i < total; i += kBandThreads) zpass(i < ncache ? ce[i] : E[i]);
+        __syncthreads();
+        // ---- updateDegrid (models/utils.py:152-212), Jacobi form, + the "certain" pixels (see certain_or)
+        int n = 0;
+        for (int i = tid; i < nint; i += kBandThreads) {
+            const int ly = i / W, x = i - ly * W, y = r0 + ly;
+            if (y >= H) { zd[i] = __uint_as_float(0x7FC00000u); continue; }
+            const float *Zc = zee + (ly + 1) * W + x;
+            const float cz = Zc[0];
+            const bool up = y > 0, dn = y < H - 1, lf = x > 0, rt = x < W - 1;
+            int cnt2 = 0; float sum = 0.0f;
+            // `(double)cz >= (double)a + 1.0`  <=>  a <= the largest float below (double)cz - 1.0 ... NOT the same rounding: the
+            // reference adds 1.0 to a in double, so the test is (double)a <= (double)cz - 1.0 exactly (both sides exact doubles:
+            // a float +- 1.0 is representable in double) -> one threshold per pixel, fp32 compares per neighbour
+            const float thr = round_down_f32((double)cz - 1.0);
+            // loop order of the reference: (1,0) (0,1) (1,1) (1,-1), the +offset end first; a line counts only if both ends are inside
+            if (lf && rt) { const float a = Zc[1], d = Zc[-1]; if (a <= thr && d <= thr) { cnt2 += 2; sum += a; sum += d; } }
+            if (up && dn) { const float a = Zc[W], d = Zc[-W]; if (a <= thr && d <= thr) { cnt2 += 2; sum += a; sum += d; } }
+            if (lf && rt && up && dn) {
+                { const float a = Zc[W + 1], d = Zc[-W - 1]; if (a <= thr && d <= thr) { cnt2 += 2; sum += a; sum += d; } }
+                { const float a = Zc[-W + 1], d = Zc[W - 1]; if (a <= thr && d <= thr) { cnt2 += 2; sum += a; sum += d; } }
+            }
+            const float r = cnt2 > 0 ? fminf(cz, sum / (float)cnt2) : cz;
+            // zd holds the z-test THRESHOLD of the pixel, not the degridded value: err passes  <=>  (double)err <= (double)r + 1.0
+            zd[i] = round_down_f32((double)certain_or(cz, r, n) + 1.0);
+        }
+        __syncthreads();
+        // ---- the z-tests of updateOutput (models/utils.py:268-310): a passing corner with positive weight marks its pixel
+        auto cover = [&](const BandEntry &e) {
+            const float fx = project_x(e.xr + sx, e.dist, pc);
+            int x0, y0; float w[4];
+            corner_weights(fx, e.fy, x0, y0, w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cx = x0 + (q & 1), cy = y0 + (q >> 1), ly = cy - r0;
+                // inside the image and the band's interior rows (cy >= 0 follows from ly >= 0)
+                if ((unsigned)cx >= (unsigned)W || (unsigned)ly >= (unsigned)br || cy >= H) continue;
+                if (!(e.err <= zd[ly * W + cx])) continue;                     // the per-pixel threshold of the degrid pass
+                if (1.0f * w[q] > 0.0f) reinterpret_cast<unsigned *>(zee)[(ly + 1) * W + cx] = kMark;
+            }
+        };
+        for (int i = tid; i < total; i += kBandThreads) cover(i < ncache ? ce[i] : E[i]);
+        __syncthreads();
+        for (int i = tid; i < nint; i += kBandThreads) n += reinterpret_cast<const unsigned *>(zee)[W + i] == kMark ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off);
+        if ((tid & 63) == 0) red[tid >> 6] = n;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+#pragma unroll
+            for (int i = 0; i < kBandThreads / 64; ++i) t += red[i];
+            partial[((int64_t)g * kPerGroup + c) * bg.nbands + band] = t;
+        }
+        __syncthreads();                               // red and the window are rewritten by the next candidate
+    }
+    if (tid == 0) *cnt = 0;                            // the segment counter is re-armed for the next launch
+}
+
+__global__ __launch_bounds__(kBlock) void k_band_sum(const Groups *__restrict__ grp, int nbands, const int *__restrict__ partial,
+                                                      int *__restrict__ counts) {
+    const int g = blockIdx.y, c = blockIdx.x;
+    if (c >= grp->n[g]) return;
+    int t = 0;
+    for (int b = threadIdx.x; b < nbands; b += kBlock) t += partial[((int64_t)g * kPerGroup + c) * nbands + b];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+    __shared__ int part[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s2 = 0; for (int i = 0; i < kBlock / 64; ++i) s2 += part[i]; counts[grp->out[g][c]] = s2; }
+}
+
+inline BandGeom band_geom(int H, int W, int64_t N) {
+    BandGeom bg; bg.br = 0; bg.nbands = 0; bg.cap = 0; bg.ncache = 0;
+    // narrow bands leave LDS for the entry cache: 4 rows up to W = 1228, 2 rows up to W = 3072 (window + degridded band <= 48 / 72 KB)
+    if (W % 2) return bg;                                                     // the entry cache must start 16-B aligned
+    if ((size_t)(2 * 8 + 2) * W * 4 <= 40 * 1024) bg.br = 8;
+    else if ((size_t)(2 * 4 + 2) * W * 4 <= 48 * 1024) bg.br = 4;
+    else if ((size_t)(2 * 2 + 2) * W * 4 <= 72 * 1024) bg.br = 2;
+    else return bg;
+    bg.nbands = (H + bg.br - 1) / bg.br;
+    const double per_band = (double)N * (bg.br + 3) / (double)H;               // uniform cloud: rows y0 in [b br - 2, b br + br]
+    int64_t cap = (int64_t)(per_band * 3.0) + 1023;
+    cap -= cap % 1024;
+    bg.cap = (int)(cap < 4096 ? 4096 : (cap > (1 << 26) ? (1 << 26) : cap));
+    const size_t window = (size_t)(2 * bg.br + 2) * W * 4;
+    const size_t room = (kBandLds - window) / 16;
+    bg.ncache = (int)(room < (size_t)bg.cap ? room : (size_t)bg.cap);
+    return bg;
+}
+inline size_t band_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
 }  // namespace
 
 extern "C" int csm_autozoom_max_chunk(void) { return kMaxChunk; }
@@ -289,6 +509,72 @@ extern "C" int csm_autozoom_coverage(const float *pts, int64_t N, int H, int W, 
             k_az_cover<<<csm::cdiv(N, kBlock), kBlock, 0, st>>>(pts, N, pc, cd, zeeB, zeeA, pitch);
             rc = csm::check_launch("k_az_cover"); if (rc) return rc;
         }
+    }
+    return CSM_OK;
+}
+
+extern "C" int csm_autozoom_band_supported(int H, int W) {
+    if (H <= 0 || W <= 0) return 0;
+    const BandGeom bg = band_geom(H, W, 1);
+    return bg.br > 0 && bg.nbands <= 4096;
+}
+
+// scratch: segment counters [kGroupMax * nbands * kCountStride] (ZEROED by the first launch of every call) | partial counts
+// [kGroupMax * kPerGroup * nbands] | entries [kGroupMax * nbands * cap] (16 B)
+extern "C" size_t csm_autozoom_band_scratch_bytes(int H, int W, int64_t N) {
+    if (!csm_autozoom_band_supported(H, W) || N < 0) return 0;
+    const BandGeom bg = band_geom(H, W, N);
+    return band_align(4 * (size_t)kGroupMax * bg.nbands * kCountStride) + band_align(4 * (size_t)kGroupMax * kPerGroup * bg.nbands) +
+           band_align(sizeof(Groups)) * 64 + 16 * (size_t)kGroupMax * bg.nbands * bg.cap + 256;
+}
+
+extern "C" int csm_autozoom_coverage_bands(const float *pts, int64_t N, int H, int W, double focal, double baseline,
+                                           const float *shifts_xy, float shift_z, int K, void *scratch, int *counts, int *overflow,
+                                           void *stream) {
+    CSM_REQUIRE(scratch && counts && overflow && H > 0 && W > 0 && N >= 0 && K >= 0 && (K == 0 || shifts_xy) && (N == 0 || pts));
+    CSM_REQUIRE((((uintptr_t)scratch) & 15) == 0);
+    if (!csm_autozoom_band_supported(H, W)) return csm::fail_arg("frame too wide for the band path: use csm_autozoom_coverage");
+    hipStream_t st = (hipStream_t)stream;
+    CSM_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
+    if (K == 0) return CSM_OK;
+    const BandGeom bg = band_geom(H, W, N);
+    const ProjConst pc = make_proj(H, W, focal, baseline);
+    char *p = (char *)scratch;
+    int *seg_count = (int *)p; const size_t seg_bytes = band_align(4 * (size_t)kGroupMax * bg.nbands * kCountStride); p += seg_bytes;
+    int *partial = (int *)p; p += band_align(4 * (size_t)kGroupMax * kPerGroup * bg.nbands);
+    char *grp_slots = p; p += band_align(sizeof(Groups)) * 64;                  // one slot per launch batch (64 x 256 candidates)
+    BandEntry *entries = (BandEntry *)p;
+    CSM_HIP(hipMemsetAsync(seg_count, 0, seg_bytes, st));
+    // group the candidates by their y shift (exact float equality), at most kPerGroup per group, kGroupMax groups per launch
+    std::vector<int> order(K);
+    for (int i = 0; i < K; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return shifts_xy[2 * a + 1] < shifts_xy[2 * b + 1]; });
+    static bool attr_set = false;
+    const size_t lds = (size_t)(2 * bg.br + 2) * W * 4 + (size_t)bg.ncache * 16;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_band_cover), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds); attr_set = true; }
+    int i = 0, batch = 0;
+    while (i < K) {
+        if (batch >= 64) return csm::fail_arg("autozoom band path: more than 64 launch batches (K too large): use csm_autozoom_coverage");
+        Groups gr; gr.ng = 0; gr.sz = shift_z;
+        while (i < K && gr.ng < kGroupMax) {
+            const int g = gr.ng++;
+            gr.sy[g] = shifts_xy[2 * order[i] + 1]; gr.n[g] = 0;
+            while (i < K && gr.n[g] < kPerGroup && shifts_xy[2 * order[i] + 1] == gr.sy[g]) {
+                gr.sx[g][gr.n[g]] = shifts_xy[2 * order[i]]; gr.out[g][gr.n[g]] = order[i]; ++gr.n[g]; ++i;
+            }
+        }
+        Groups *grp = reinterpret_cast<Groups *>(grp_slots + (size_t)batch * band_align(sizeof(Groups)));
+        ++batch;
+        CSM_HIP(hipMemcpyAsync(grp, &gr, sizeof(Groups), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
+        if (N > 0) {
+            k_band_bin<<<dim3((unsigned)csm::cdiv(N, kBlock * 4), gr.ng), kBlock, 2 * sizeof(int) * (size_t)bg.nbands, st>>>(
+                pts, N, pc, grp, bg, seg_count, entries, overflow);
+            int rc = csm::check_launch("k_band_bin"); if (rc) return rc;
+        }
+        k_band_cover<<<dim3(bg.nbands, gr.ng), kBandThreads, lds, st>>>(pc, grp, bg, seg_count, entries, partial);
+        int rc = csm::check_launch("k_band_cover"); if (rc) return rc;
+        k_band_sum<<<dim3(kPerGroup, gr.ng), kBlock, 0, st>>>(grp, bg.nbands, partial, counts);
+        rc = csm::check_launch("k_band_sum"); if (rc) return rc;
     }
     return CSM_OK;
 }

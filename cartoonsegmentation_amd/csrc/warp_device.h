@@ -42,6 +42,30 @@ __device__ __forceinline__ bool project(float x, float y, float z, const ProjCon
     return true;
 }
 
+// project() split for callers that evaluate many x shifts of one point (autozoom bands): everything that does not involve x
+// (the rejection tests, dist, fy, err) once, then fx per shift.  Statement for statement the expressions of project(); with
+// -ffp-contract=off  project(x, y, z) == { project_yz(y, z, ...); fx = project_x(x, dist) }  bit for bit.
+__device__ __forceinline__ bool project_yz(float y, float z, const ProjConst &pc, float &dist, float &fy, float &err) {
+    if ((double)z < 0.001) return false;
+    float lvy = 0.0f - y, lvz = 0.0f - z;
+    float az = pc.focal_f - z;
+    // num = ax * 0 + ay * 0 + az * 1 and den = lvx * 0 + lvy * 0 + lvz * 1: the zero products of finite operands add nothing
+    // (x + 0 == x for every x but -0, and az * 1 + 0 of a signed zero only changes the sign of a zero, which no later statement sees)
+    float num = az * 1.0f;
+    float den = lvz * 1.0f;
+    dist = num / den;
+    if ((double)fabsf(den) < 0.001) return false;
+    float iy = y + dist * lvy;
+    fy = (float)(((double)iy + pc.half_h) - 0.5);
+    err = (float)(1000000.0 - (pc.focal_baseline / ((double)z + 0.0000001)));
+    return true;
+}
+__device__ __forceinline__ float project_x(float x, float dist, const ProjConst &pc) {
+    float lvx = 0.0f - x;
+    float ix = x + dist * lvx;
+    return (float)(((double)ix + pc.half_w) - 0.5);
+}
+
 __device__ __forceinline__ void corner_weights(float fx, float fy, int &x0, int &y0, float w[4]) {
     x0 = (int)floorf(fx); y0 = (int)floorf(fy);
     float x1 = (float)(x0 + 1), y1 = (float)(y0 + 1), xf = (float)x0, yf = (float)y0;

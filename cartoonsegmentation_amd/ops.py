@@ -164,10 +164,12 @@ def resize_u8_linear(img, h, w):
     return out
 
 
-def autozoom_coverage(tenPoints, shifts, intWidth, intHeight, fltFocal, fltBaseline, chunk=None):
+def autozoom_coverage(tenPoints, shifts, intWidth, intHeight, fltFocal, fltBaseline, chunk=None, host=True):
     """coverage counts `(tenExisting > 0.0).float().sum()` of render_pointcloud(process_shift(tenPoints, shift_k)) for every
     candidate shift_k = (sx, sy, sz) -- common.py:110-126 -- in batched launches (csm_autozoom_coverage), no colour rendered,
-    no host sync.  All candidates of one search share sz (common.py:92-93).  Returns an int32 device tensor [K]."""
+    ONE host read.  All candidates of one search share sz (common.py:92-93).  Returns the K counts as a Python list (host=True,
+    the default: the read that replaces the reference's <= 256 `.item()` syncs), or a device tensor (host=False; on the band path
+    it has K + 1 entries, the last one being the overflow flag of csm_autozoom_coverage_bands)."""
     import ctypes
     import os
     tenPoints = _dev(tenPoints, "tenPoints")
@@ -175,13 +177,29 @@ def autozoom_coverage(tenPoints, shifts, intWidth, intHeight, fltFocal, fltBasel
     L, K = _lib.load(), len(shifts)
     counts = torch.zeros(max(K, 1), dtype=torch.int32, device=tenPoints.device)
     if K == 0:
-        return counts[:0]
-    sz = {float(torch.tensor(float(s[2]), dtype=torch.float32).item()) for s in shifts}
+        return [] if host else counts[:0]
+    # FloatTensor rounding of the python-float shifts (common.py:74): float64 -> float32, round to nearest even == numpy's astype
+    s32 = _np.asarray([[float(s[0]), float(s[1]), float(s[2])] for s in shifts], dtype=_np.float64).astype(_np.float32)
+    sz = {float(v) for v in s32[:, 2]}
     assert len(sz) == 1, "the candidates of one autozoom search share the z shift"
-    xy = (ctypes.c_float * (2 * K))()
-    t = torch.tensor([[float(s[0]), float(s[1])] for s in shifts], dtype=torch.float32)      # FloatTensor rounding, common.py:74
-    for i in range(K):
-        xy[2 * i], xy[2 * i + 1] = t[i, 0].item(), t[i, 1].item()
+    xy = (ctypes.c_float * (2 * K)).from_buffer_copy(_np.ascontiguousarray(s32[:, :2]).tobytes())
+    path = os.environ.get('CSM_AUTOZOOM_PATH', 'bands')
+    if chunk is None and path == 'bands' and L.csm_autozoom_band_supported(i32(intHeight), i32(intWidth)):
+        # band path: z-buffers in LDS, candidates grouped by y shift.  The overflow flag travels with the counts (one transfer).
+        N = tenPoints.shape[2]
+        out = torch.empty(K + 1, dtype=torch.int32, device=tenPoints.device)
+        scratch = torch.empty((L.csm_autozoom_band_scratch_bytes(i32(intHeight), i32(intWidth), i64(N)) + 3) // 4, dtype=torch.float32,
+                              device=tenPoints.device)
+        zs = f32(sz.pop())
+        check(L.csm_autozoom_coverage_bands(ptr(tenPoints), i64(N), i32(intHeight), i32(intWidth), f64(fltFocal), f64(fltBaseline), xy,
+                                            zs, i32(K), ptr(scratch), ptr(out), ctypes.c_void_p(out.data_ptr() + 4 * K), stream_ptr()),
+              "autozoom_coverage_bands")
+        if not host:
+            return out                                      # [K + 1]: counts, overflow flag (callers that stay on the device check it)
+        vals = out.tolist()
+        if vals[K] == 0:
+            return vals[:K]
+        sz = {zs.value}                                     # a band segment overflowed (pathological cloud): exact plane path below
     chunk = int(chunk or os.environ.get('CSM_AUTOZOOM_CHUNK', L.csm_autozoom_max_chunk()))
     chunk = max(1, min(chunk, L.csm_autozoom_max_chunk(), K))
     scratch = torch.empty(L.csm_autozoom_scratch_floats(i32(intHeight), i32(intWidth), i32(chunk)), dtype=torch.float32,
@@ -189,7 +207,7 @@ def autozoom_coverage(tenPoints, shifts, intWidth, intHeight, fltFocal, fltBasel
     check(L.csm_autozoom_coverage(ptr(tenPoints), i64(tenPoints.shape[2]), i32(intHeight), i32(intWidth), f64(fltFocal),
                                   f64(fltBaseline), xy, f32(sz.pop()), i32(K), i32(chunk), ptr(scratch), ptr(counts), stream_ptr()),
           "autozoom_coverage")
-    return counts[:K]
+    return counts[:K].tolist() if host else counts[:K]
 
 
 def process_autozoom(objSettings, objCommon, return_counts=False):
@@ -213,7 +231,7 @@ def process_autozoom(objSettings, objCommon, return_counts=False):
                 continue
             cands.append((su, sv))
     shifts = [shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, objCommon) for su, sv in cands]
-    counts = autozoom_coverage(objCommon['tenRawPoints'], shifts, W, H, objCommon['fltFocal'], objCommon['fltBaseline']).tolist()
+    counts = autozoom_coverage(objCommon['tenRawPoints'], shifts, W, H, objCommon['fltFocal'], objCommon['fltBaseline'])
     best, bu, bv = 0.0, None, None
     for (su, sv), c in zip(cands, counts):
         if best < c:

@@ -123,6 +123,18 @@ size_t csm_autozoom_scratch_floats(int H, int W, int chunk);
 int csm_autozoom_coverage(const float *pts, int64_t N, int H, int W, double focal, double baseline, const float *shifts_xy,
                           float shift_z, int K, int chunk, float *scratch, int *counts, void *stream);
 
+/* The same counts through the BAND path (autozoom.hip): candidates are grouped by their y shift (host side, exact float
+ * equality), the points of a group are binned once by destination row band, and one block per (band, group) evaluates all the
+ * group's candidates with the band's z-buffer in LDS -- no per-candidate HBM planes.  Same arithmetic, same counts.
+ * counts: DEVICE int32 [K]; overflow: DEVICE int32 [1], set non-zero when a band segment was too small for this cloud -- the
+ * counts are then INVALID and the caller re-runs csm_autozoom_coverage (read it together with the counts, one transfer).
+ * csm_autozoom_band_supported: 0 for frames too wide for the LDS band (then only csm_autozoom_coverage applies).
+ * scratch: csm_autozoom_band_scratch_bytes(H, W, N) device bytes, 16-B aligned (no initialisation needed). */
+int csm_autozoom_band_supported(int H, int W);
+size_t csm_autozoom_band_scratch_bytes(int H, int W, int64_t N);
+int csm_autozoom_coverage_bands(const float *pts, int64_t N, int H, int W, double focal, double baseline, const float *shifts_xy,
+                                float shift_z, int K, void *scratch, int *counts, int *overflow, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Dense networks: a flat "layer program" executed on one stream (no allocation, graph-capturable)
  *

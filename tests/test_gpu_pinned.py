@@ -119,18 +119,37 @@ def test_batched_autozoom_vs_reference_text_and_oracle():
     cj = []
     to_j, _ = okb.autozoom_target(kc, d['rgb'], W, H, common['fltFocal'], common['fltBaseline'], shift=float(d['shift']), degrid_mode=1,
                                   counts_out=cj)
-    for chunk in (None, 5):                                                      # default chunk and a ragged one
+    for path, chunk in (('bands', None), ('planes', None), ('planes', 5)):        # LDS band path; plane path, default and ragged chunk
+        os.environ['CSM_AUTOZOOM_PATH'] = path
         if chunk:
             os.environ['CSM_AUTOZOOM_CHUNK'] = str(chunk)
         try:
             to, cands, counts = ops.process_autozoom(settings, common, return_counts=True)
         finally:
-            os.environ.pop('CSM_AUTOZOOM_CHUNK', None)
-        assert len(counts) == len(d['counts']) and counts == [int(c) for c in cj]
+            os.environ.pop('CSM_AUTOZOOM_CHUNK', None); os.environ.pop('CSM_AUTOZOOM_PATH', None)
+        assert len(counts) == len(d['counts']) and counts == [int(c) for c in cj], (path, chunk)
         assert to == to_j
     c_ref = d['counts']
     assert c_ref[int(np.argmax(counts))] >= c_ref.max() - 0.001 * H * W
     assert np.abs(np.asarray(counts) - c_ref).max() <= 0.005 * H * W
+    # band path on awkward clouds == plane path: N > P with scattered extra points, odd sizes, a pile-up that overflows the band
+    # segments (the flag sends the call to the plane path), and an empty cloud
+    g = np.random.default_rng(11)
+    for (Hh, Ww, n, pile) in ((45, 70, 9000, False), (250, 333, 120000, False), (96, 128, 40000, True), (64, 64, 0, False)):
+        z = g.uniform(30, 80, n).astype(np.float32)
+        spread = 0.02 if pile else 1.2
+        xy = g.uniform(-spread, spread, (2, n)).astype(np.float32) * z * np.array([[Ww / 70.0], [Hh / 70.0]], np.float32)
+        pts = torch.from_numpy(np.stack([xy[0], xy[1], z])[None].astype(np.float32)).cuda()
+        shifts = [(float(a), float(b), -3.5) for b in (-2.0, 0.0, 1.5) for a in (-4.0, -1.0, 0.5, 2.0, 3.0)]
+        res = {}
+        for path in ('bands', 'planes'):
+            os.environ['CSM_AUTOZOOM_PATH'] = path
+            try:
+                res[path] = ops.autozoom_coverage(pts, shifts, Ww, Hh, 35.0, 40.0)
+            finally:
+                os.environ.pop('CSM_AUTOZOOM_PATH', None)
+        assert res['bands'] == res['planes'], (Hh, Ww, n, pile)
+        assert n == 0 or max(res['bands']) > 0
 
 
 def test_frame_scaledown_and_path_input(tmp_path):

@@ -23,8 +23,10 @@ common = {'objDepthrange': (dmin, float(crop.max()), (loc % crop.shape[1], loc /
           'fltFocal': sc['focal'], 'fltBaseline': sc['baseline'], 'tenRawPoints': pts.view(1, 3, -1).contiguous()}
 objFrom = {'fltCenterU': W / 2.0, 'fltCenterV': H / 2.0, 'intCropWidth': int(np.floor(0.97 * W)), 'intCropHeight': int(np.floor(0.97 * H))}
 settings = {'fltShift': 100.0 * W / 1024.0, 'fltZoom': 1.25, 'objFrom': objFrom}
-for chunk in (32, 16, 8, 4):
-    os.environ['CSM_AUTOZOOM_CHUNK'] = str(chunk)
+for chunk in (0, 32, 8):
+    if chunk:
+        os.environ['CSM_AUTOZOOM_CHUNK'] = str(chunk)
+        os.environ['CSM_AUTOZOOM_PATH'] = 'planes'
     to, cands, counts = ops.process_autozoom(settings, common, return_counts=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -32,5 +34,5 @@ for chunk in (32, 16, 8, 4):
         to = ops.process_autozoom(settings, common)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
-    print("autozoom %dx%d chunk %2d: %d candidates, %.2f ms per search (%.1f us per candidate), best coverage %.4f"
+    print("autozoom %dx%d chunk %2d (0 = LDS band path): %d candidates, %.2f ms per search (%.1f us per candidate), best coverage %.4f"
           % (W, H, chunk, len(cands), ms, ms * 1e3 / max(len(cands), 1), max(counts) / (H * W)), flush=True)
