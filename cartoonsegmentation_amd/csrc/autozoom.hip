@@ -22,6 +22,7 @@
 // atomics; a chunk of 32 planes at 1024^2 (256 MB for A and B) stays inside the 256 MB Infinity Cache.
 #include "warp_device.h"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(kBlock) void k_az_cover(const float *__restrict__ p
 // to the plane path, so the result is exact for every cloud.
 constexpr int kGroupMax = 16, kPerGroup = 16;          // groups per launch, candidates per group
 constexpr int kBandThreads = 1024;
-constexpr size_t kBandLds = 150 * 1024;                // LDS per block: window + degridded band + as many cached entries as fit
+static size_t kBandLds = 150 * 1024;                   // LDS per block: window + degridded band + as many cached entries as fit
+                                                        // (CSM_AZ_LDS_KB overrides: a measurement knob)
 constexpr int kCountStride = 32;                        // ints between two segment counters (one 128-B line each)
 struct Groups { int ng; float sz; float sy[kGroupMax]; int n[kGroupMax]; float sx[kGroupMax][kPerGroup]; int out[kGroupMax][kPerGroup]; };
 struct BandEntry { float xr, dist, fy, err; };          // x * z/(z + 1e-7), ray factor, projected row coordinate, fltError
@@ -349,10 +351,10 @@ __global__ __launch_bounds__(kBandThreads) void k_band_cover(ProjConst pc, const
     for (int i = tid; i < ncache; i += kBandThreads) ce[i] = E[i];
     const int nwin = (br + 2) * W, nint = br * W;
     const int ncand = grp->n[g];
+    for (int i = tid; i < nwin; i += kBandThreads) zee[i] = 1000000.0f;         // models/utils.py:59 (later trips: the count sweep)
     for (int c = 0; c < ncand; ++c) {
         const float sx = grp->sx[g][c];
-        for (int i = tid; i < nwin; i += kBandThreads) zee[i] = 1000000.0f;     // models/utils.py:59
-        __syncthreads();                                                        // (also publishes the entry cache on the first trip)
+        __syncthreads();                                                        // window armed (first trip: the entry cache too)
         // ---- updateZee (models/utils.py:101-147)
         auto zpass = [&](const BandEntry &e) {
             const float fx = project_x(e.xr + sx, e.dist, pc);
@@ -409,7 +411,11 @@ __global__ __launch_bounds__(kBandThreads) void k_band_cover(ProjConst pc, const
         };
         for (int i = tid; i < total; i += kBandThreads) cover(i < ncache ? ce[i] : E[i]);
         __syncthreads();
-        for (int i = tid; i < nint; i += kBandThreads) n += reinterpret_cast<const unsigned *>(zee)[W + i] == kMark ? 1 : 0;
+        // count the marks and re-arm the window for the next candidate in one sweep (mark rows are the interior rows 1 .. br)
+        for (int i = tid; i < nwin; i += kBandThreads) {
+            n += reinterpret_cast<const unsigned *>(zee)[i] == kMark ? 1 : 0;   // halo rows never hold a mark
+            zee[i] = 1000000.0f;
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off);
         if ((tid & 63) == 0) red[tid >> 6] = n;
@@ -420,7 +426,6 @@ __global__ __launch_bounds__(kBandThreads) void k_band_cover(ProjConst pc, const
             for (int i = 0; i < kBandThreads / 64; ++i) t += red[i];
             partial[((int64_t)g * kPerGroup + c) * bg.nbands + band] = t;
         }
-        __syncthreads();                               // red and the window are rewritten by the next candidate
     }
     if (tid == 0) *cnt = 0;                            // the segment counter is re-armed for the next launch
 }
@@ -440,6 +445,8 @@ __global__ __launch_bounds__(kBlock) void k_band_sum(const Groups *__restrict__ 
 }
 
 inline BandGeom band_geom(int H, int W, int64_t N) {
+    static bool env_read = false;
+    if (!env_read) { const char *e = getenv("CSM_AZ_LDS_KB"); if (e && atoi(e) >= 64 && atoi(e) <= 156) kBandLds = (size_t)atoi(e) * 1024; env_read = true; }
     BandGeom bg; bg.br = 0; bg.nbands = 0; bg.cap = 0; bg.ncache = 0;
     // narrow bands leave LDS for the entry cache: 4 rows up to W = 1228, 2 rows up to W = 3072 (window + degridded band <= 48 / 72 KB)
     if (W % 2) return bg;                                                     // the entry cache must start 16-B aligned
