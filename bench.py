@@ -126,7 +126,7 @@ class WarpWorkload(Workload):
         alg = self.algorithmic_bytes()
         ach = alg / (ms * 1e-3) / 1e9
         tiled = getattr(self.wf, 'path', 'tiled') == 'tiled'
-        return {"bound": "hbm", "kernel": "csm_warp_frame_tiled: k_tile_count + k_tile_scatter + k_tile_render + k_tile_holes" if tiled
+        return {"bound": "hbm", "kernel": "csm_warp_frame_tiled: k_tile_bin + k_tile_render + k_tile_holes" if tiled
                 else "csm_warp_frame: k_fill + k_update_zee + k_degrid + k_update_output + k_finalize_frame + k_fill_holes",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": load_traffic("warp_chain_tiled" if tiled else "k_update_output"), "algorithmic_bytes_per_launch": alg,

@@ -53,9 +53,9 @@ for kind,key in (("FETCH_SIZE","fetch_KB"),("WRITE_SIZE","write_KB")):
 json.dump(tr, open("$OUT/pmc_summary.json","w"), indent=1)
 # HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -- MI355X_MICROARCH.md, HBM)
 traffic={k:int(2*v.get("fetch_KB",0)*1024+v.get("write_KB",0)*1024) for k,v in tr.items() if k.startswith("k_")}
-chain=[k for k in ("k_tile_count","k_tile_scatter","k_tile_render","k_tile_holes") if k in traffic]
+chain=[k for k in ("k_tile_bin","k_tile_render","k_tile_holes") if k in traffic]
 if chain: traffic["warp_chain_tiled"]=sum(traffic[k] for k in chain)
-traffic["_note"]="HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md; WRITE_SIZE uncalibrated); separate --pmc passes; k_conv = launch-weighted average over all conv launches (k_conv_dma / k_conv_patch tiles + k_conv_mfma) of the frame workload (batch 8); warp_chain_tiled = sum over the four kernels of one csm_warp_frame_tiled call"
+traffic["_note"]="HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md; WRITE_SIZE uncalibrated); separate --pmc passes; k_conv = launch-weighted average over all conv launches (k_conv_dma / k_conv_patch tiles + k_conv_mfma) of the frame workload (batch 8); warp_chain_tiled = sum over the three kernels (k_tile_bin, k_tile_render, k_tile_holes) of one csm_warp_frame_tiled call"
 json.dump(traffic, open("$OUT/traffic.json","w"), indent=1)
 for k,v in sorted(tr.items(), key=lambda kv:-kv[1].get("fetch_KB",0))[:16]: print(k, v)
 PY
