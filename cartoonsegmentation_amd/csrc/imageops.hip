@@ -116,6 +116,74 @@ __global__ __launch_bounds__(256) void k_crop_resize(const uint8_t *__restrict__
     }
 }
 
+// The same arithmetic on a 64 x 4 output tile whose source pixels (<= 8 rows x 80 columns when the patch is not larger than the
+// output, the Ken Burns case) are staged once in LDS as packed BGR words: 48 clamped byte gathers per output pixel become 16 LDS
+// reads (25 -> ~6 us per 1024^2 frame).  A tile whose window does not fit uses the direct path of k_crop_resize.
+__global__ __launch_bounds__(256) void k_crop_resize_tile(const uint8_t *__restrict__ frame, int H, int W, int ph, int pw,
+                                                           float cx, float cy, uint8_t *__restrict__ out) {
+    constexpr int TX = 64, TY = 4, RW = 80, RH = 8;
+    __shared__ unsigned win[RH * RW];
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x * TX, by = blockIdx.y * TY;
+    const int x = bx + (tid & 63), y = by + (tid >> 6);
+    float ox = cx - (float)(pw - 1) * 0.5f, oy = cy - (float)(ph - 1) * 0.5f;
+    const int ix = (int)floorf(ox), iy = (int)floorf(oy);
+    const float a = ox - (float)ix, b = oy - (float)iy;
+    const bool same = (ph == H && pw == W);
+    const int xl = min(bx + TX - 1, W - 1), yl = min(by + TY - 1, H - 1);       // last output pixel of the tile
+    int xmin = bx, xmax = xl, ymin = by, ymax = yl, t0, t1; float tf;
+    if (!same) {
+        cv_src(bx, pw, (double)pw / W, xmin, t1, tf); cv_src(xl, pw, (double)pw / W, t0, xmax, tf);
+        cv_src(by, ph, (double)ph / H, ymin, t1, tf); cv_src(yl, ph, (double)ph / H, t0, ymax, tf);
+    }
+    const int rw = xmax - xmin + 2, rh = ymax - ymin + 2;                       // +1: the second tap of getRectSubPix
+    const bool fits = rw <= RW && rh <= RH;                                     // block-uniform
+    if (fits) {
+        for (int i = tid; i < rh * rw; i += 256) {
+            const int r = i / rw, c = i - r * rw;
+            int yy = iy + ymin + r, xx = ix + xmin + c;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            const uint8_t *f = frame + ((int64_t)yy * W + xx) * 3;
+            win[r * RW + c] = (unsigned)f[0] | ((unsigned)f[1] << 8) | ((unsigned)f[2] << 16);
+        }
+        __syncthreads();
+    }
+    if (x >= W || y >= H) return;
+    int y0 = y, y1 = y, x0 = x, x1 = x; float fy = 0.0f, fx = 0.0f;
+    if (!same) { cv_src(y, ph, (double)ph / H, y0, y1, fy); cv_src(x, pw, (double)pw / W, x0, x1, fx); }
+    if (!fits) {
+        for (int c = 0; c < 3; ++c) {
+            int q = same ? subpix(frame, H, W, c, x, y, ix, iy, a, b)
+                         : cv_lin_u8(subpix(frame, H, W, c, x0, y0, ix, iy, a, b), subpix(frame, H, W, c, x1, y0, ix, iy, a, b),
+                                     subpix(frame, H, W, c, x0, y1, ix, iy, a, b), subpix(frame, H, W, c, x1, y1, ix, iy, a, b), fx, fy);
+            out[((int64_t)y * W + x) * 3 + c] = (uint8_t)q;
+        }
+        return;
+    }
+    const float a11 = (1.0f - a) * (1.0f - b), a12 = a * (1.0f - b), a21 = (1.0f - a) * b, a22 = a * b;
+    auto sub3 = [&](int px, int py, int q[3]) {                                // subpix() of the three channels from the window
+        const unsigned *wp = win + (py - ymin) * RW + (px - xmin);
+        const unsigned w00 = wp[0], w01 = wp[1], w10 = wp[RW], w11 = wp[RW + 1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (float)((w00 >> (8 * c)) & 255u) * a11 + (float)((w01 >> (8 * c)) & 255u) * a12 +
+                            (float)((w10 >> (8 * c)) & 255u) * a21 + (float)((w11 >> (8 * c)) & 255u) * a22;
+            const int r = (int)rintf(v);
+            q[c] = r < 0 ? 0 : (r > 255 ? 255 : r);
+        }
+    };
+    int o[3];
+    if (same) sub3(x, y, o);
+    else {
+        int q00[3], q01[3], q10[3], q11[3];
+        sub3(x0, y0, q00); sub3(x1, y0, q01); sub3(x0, y1, q10); sub3(x1, y1, q11);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = cv_lin_u8(q00[c], q01[c], q10[c], q11[c], fx, fy);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[((int64_t)y * W + x) * 3 + c] = (uint8_t)o[c];
+}
+
 // ---- small fused reductions of the per-frame depth glue (replace ~25 torch kernels per frame; min/max are order-free) ---------
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
@@ -443,8 +511,8 @@ extern "C" int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int
 extern "C" int csm_crop_resize_u8(const uint8_t *frame_hwc, int H, int W, int patch_h, int patch_w, float center_x,
                                   float center_y, uint8_t *out_hwc, void *stream) {
     CSM_REQUIRE(frame_hwc && out_hwc && frame_hwc != out_hwc && H > 0 && W > 0 && patch_h > 0 && patch_w > 0);
-    k_crop_resize<<<dim3(csm::cdiv(W, 256), H), 256, 0, (hipStream_t)stream>>>(frame_hwc, H, W, patch_h, patch_w, center_x,
-                                                                                 center_y, out_hwc);
+    k_crop_resize_tile<<<dim3(csm::cdiv(W, 64), csm::cdiv(H, 4)), 256, 0, (hipStream_t)stream>>>(frame_hwc, H, W, patch_h, patch_w,
+                                                                                                   center_x, center_y, out_hwc);
     return csm::check_launch("k_crop_resize");
 }
 

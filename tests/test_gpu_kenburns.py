@@ -48,9 +48,13 @@ def test_image_ops_bit_exact():
     O.orc_resize_u8_to_f32(oseg._p(qo), ci(96), ci(128), ci(150), ci(200), oseg._p(upo))
     assert np.array_equal(up.cpu().numpy(), upo)
     cr = torch.empty((150, 200, 3), dtype=torch.uint8, device='cuda'); cro = np.empty((150, 200, 3), np.uint8)
-    check(L.csm_crop_resize_u8(ptr(d_img), i32(150), i32(200), i32(145), i32(194), f32(100.0), f32(75.0), ptr(cr), stream_ptr()))
-    O.orc_crop_resize_u8(oseg._p(img), ci(150), ci(200), ci(145), ci(194), cf(100.0), cf(75.0), oseg._p(cro))
-    assert np.array_equal(cr.cpu().numpy(), cro)
+    # crop + resize (kenburns_effect.py:1069-1070): the LDS-tiled kernel on a near-full patch, the full frame at a fractional centre,
+    # a 4x enlargement of a small patch, patches hanging over every border (clamped taps), a 1-px patch
+    for (ph_, pw_, cx_, cy_) in ((145, 194, 100.0, 75.0), (150, 200, 99.3, 74.6), (37, 50, 60.5, 40.25), (120, 160, 3.0, 2.0),
+                                 (120, 160, 198.7, 149.1), (1, 1, 17.0, 9.0), (150, 200, 99.5, 74.5)):
+        check(L.csm_crop_resize_u8(ptr(d_img), i32(150), i32(200), i32(ph_), i32(pw_), f32(cx_), f32(cy_), ptr(cr), stream_ptr()))
+        O.orc_crop_resize_u8(oseg._p(img), ci(150), ci(200), ci(ph_), ci(pw_), cf(cx_), cf(cy_), oseg._p(cro))
+        assert np.array_equal(cr.cpu().numpy(), cro), (ph_, pw_, cx_, cy_)
 
 
 def test_generate_kenburns_config_vs_oracle(pipe_and_cfg):
