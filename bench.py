@@ -120,7 +120,7 @@ class WarpWorkload(Workload):
                                "achieved_GBps": round(ach, 1), "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4)}}
 
     def roofline(self):
-        """the whole frame chain of csm_warp_frame_tiled (count, scatter, render, holes) against the HBM roof with SURVEY 8(d)'s
+        """the whole frame chain of csm_warp_frame_tiled (bin, render, holes) against the HBM roof with SURVEY 8(d)'s
         algorithmic bytes (155 P for N = P, C = 4); `traffic` = PMC bytes summed over the chain's kernels (profiles/traffic.json)"""
         ms = event_time_ms(self.step, 100, warm=10)
         alg = self.algorithmic_bytes()
@@ -194,7 +194,7 @@ class FrameWorkload(Workload):
         return self.out[:self.frames_per_step]
 
     # ---- extra single-GPU measurements (batch 1 = BASELINE configs[1..2], n instances in {1, 8}, det 1024, the video) ----
-    def _fps(self, batch=None, instances=None, det=None, steps=3):
+    def _fps(self, batch=None, instances=None, det=None, steps=3, conv_roofline=False):
         """frames/s of step() under a variant of the configuration (one untimed step builds + tunes whatever is new)"""
         keep = (self.frames_per_step, self.imgs, self.pipe.max_instances, self.pipe.animeinsseg.default_det_size)
         try:
@@ -210,8 +210,12 @@ class FrameWorkload(Workload):
                 self.step()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            return {"frames_per_s": round(steps * self.frames_per_step / dt, 2), "ms_per_frame": round(dt / (steps * self.frames_per_step) * 1e3, 3),
-                    "batch": self.frames_per_step, "instances_found": self.n_inst, "det_size": self.pipe.animeinsseg.default_det_size}
+            res = {"frames_per_s": round(steps * self.frames_per_step / dt, 2), "ms_per_frame": round(dt / (steps * self.frames_per_step) * 1e3, 3),
+                   "batch": self.frames_per_step, "instances_found": self.n_inst, "det_size": self.pipe.animeinsseg.default_det_size}
+            if conv_roofline:                                  # the same conv-population roofline as the headline, for this variant
+                r = self.roofline()
+                res.update(conv_tflops=r["achieved"], conv_frac_of_mfma_peak=r["frac"], conv_avg_launch_us=r["avg_launch_us"])
+            return res
         finally:
             self.frames_per_step, self.imgs, self.pipe.max_instances = keep[0], keep[1], keep[2]
             self.pipe.animeinsseg.set_detect_size(keep[3])
@@ -272,7 +276,7 @@ class FrameWorkload(Workload):
         return out
 
     def variants(self):
-        v = {"batch1": self._fps(batch=1), "batch16": self._fps(batch=16), "instances1": self._fps(instances=1),
+        v = {"batch1": self._fps(batch=1, conv_roofline=True), "batch16": self._fps(batch=16, conv_roofline=True), "instances1": self._fps(instances=1),
              "instances8": self._fps(instances=8), "det1024_batch4": self._fps(batch=4, det=1024), "video": self._video(),
              "warp_chain": self._warp_points()}
         v["reference_shaped_ratio"] = "1 seg + 1 depth + 75 warps: see video (inpaint_and_75_frames_ms vs config_ms)"
@@ -331,6 +335,8 @@ class FrameWorkload(Workload):
         n_launch, alg_bytes = 0, 0
         for (name, cp, ext), b in zip(progs, before):
             per_step = cp.runs - b
+            if per_step == 0:                                      # a program of another variant (other batch / det size): not part of this step
+                continue
             cp.run(*ext)
             ms = None
             for _ in range(3):

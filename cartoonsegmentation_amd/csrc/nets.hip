@@ -1274,6 +1274,44 @@ __global__ __launch_bounds__(256) void k_nhwc_to_nchw(View in, float *__restrict
     dst[idx] = in.p[(n * hw + p) * in.ld + c];
 }
 
+// LDS-tiled forms for wide tensors (the 64 / 69-channel planes around the inpainting splat: 270-290 MB each).  The one-element-
+// per-lane kernels above read (resp. write) 64 different cache lines per wave and ran at 1.25 TB/s (read + write); here a block
+// moves 64 pixels x C channels through LDS, global accesses on both sides are contiguous runs (pixels of one channel plane /
+// channels of consecutive pixels), the [c][65] pitch keeps both LDS phases conflict-free.
+constexpr int kTrPix = 64;
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc_tile(const float *__restrict__ src, int csrc, View out) {
+    extern __shared__ float tr[];                      // [out.c][kTrPix + 1]
+    const int64_t hw = (int64_t)out.h * out.w;
+    const int64_t tiles = (hw + kTrPix - 1) / kTrPix;
+    const int64_t n = blockIdx.x / tiles, p0 = (blockIdx.x - n * tiles) * kTrPix;
+    const int C = out.c;
+    for (int i = threadIdx.x; i < C * kTrPix; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        tr[c * (kTrPix + 1) + p] = (c < csrc && p0 + p < hw) ? src[(n * csrc + c) * hw + p0 + p] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * kTrPix; i += 256) {
+        const int p = i / C, c = i - p * C;
+        if (p0 + p < hw) out.p[(n * hw + p0 + p) * out.ld + c] = tr[c * (kTrPix + 1) + p];
+    }
+}
+__global__ __launch_bounds__(256) void k_nhwc_to_nchw_tile(View in, float *__restrict__ dst) {
+    extern __shared__ float tr[];                      // [in.c][kTrPix + 1]
+    const int64_t hw = (int64_t)in.h * in.w;
+    const int64_t tiles = (hw + kTrPix - 1) / kTrPix;
+    const int64_t n = blockIdx.x / tiles, p0 = (blockIdx.x - n * tiles) * kTrPix;
+    const int C = in.c;
+    for (int i = threadIdx.x; i < C * kTrPix; i += 256) {
+        const int p = i / C, c = i - p * C;
+        tr[c * (kTrPix + 1) + p] = p0 + p < hw ? in.p[(n * hw + p0 + p) * in.ld + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * kTrPix; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        if (p0 + p < hw) dst[(n * C + c) * hw + p0 + p] = tr[c * (kTrPix + 1) + p];
+    }
+}
+
 template <int MT, int WM, int WN, int TN, bool FULLK>
 int launch_conv_k(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = MT * WM, BN = MT * WN * TN;
@@ -1555,10 +1593,18 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 k_logbinom<<<blocks_for((int64_t)out.n * out.h * out.w), 256, 0, st>>>(in, in1, out, weights + op.aux_off);
                 break;
             case CSM_OP_NCHW_TO_NHWC:
-                k_nchw_to_nhwc<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in.p, in.c, out);
+                if (out.c >= 8 && out.c <= 240)
+                    k_nchw_to_nhwc_tile<<<(unsigned)(out.n * (((int64_t)out.h * out.w + kTrPix - 1) / kTrPix)), 256,
+                                          sizeof(float) * (size_t)out.c * (kTrPix + 1), st>>>(in.p, in.c, out);
+                else
+                    k_nchw_to_nhwc<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in.p, in.c, out);
                 break;
             case CSM_OP_NHWC_TO_NCHW:
-                k_nhwc_to_nchw<<<blocks_for((int64_t)in.n * in.h * in.w * in.c), 256, 0, st>>>(in, out.p);
+                if (in.c >= 8 && in.c <= 240)
+                    k_nhwc_to_nchw_tile<<<(unsigned)(in.n * (((int64_t)in.h * in.w + kTrPix - 1) / kTrPix)), 256,
+                                          sizeof(float) * (size_t)in.c * (kTrPix + 1), st>>>(in, out.p);
+                else
+                    k_nhwc_to_nchw<<<blocks_for((int64_t)in.n * in.h * in.w * in.c), 256, 0, st>>>(in, out.p);
                 break;
             default:
                 csm::set_error("op %d: unknown kind %d", i, op.kind);
