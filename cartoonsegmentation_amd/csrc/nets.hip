@@ -1148,9 +1148,16 @@ __global__ __launch_bounds__(256) void k_eltwise(View a, View b, View out, int a
     int64_t total = (int64_t)out.n * out.h * out.w * out.c;
     if (idx >= total) return;
     int c = (int)(idx % out.c); int64_t pix = idx / out.c;
-    float v = a.p[pix * a.ld + c];
-    if (mode == 1) v = v + b.p[pix * b.ld + c];
-    else if (mode == 2) { int64_t n = pix / ((int64_t)out.h * out.w); v = v * b.p[n * b.ld + c]; }
+    float v;
+    if (mode == 3) {        // add with a CROPPED first operand: a is up to one row / column larger than out (torch's negative pad)
+        const int64_t hw = (int64_t)out.h * out.w; const int64_t n = pix / hw, r = pix - n * hw;
+        const int y = (int)(r / out.w), x = (int)(r - (int64_t)y * out.w);
+        v = a.p[((n * a.h + y) * a.w + x) * a.ld + c] + b.p[pix * b.ld + c];
+    } else {
+        v = a.p[pix * a.ld + c];
+        if (mode == 1) v = v + b.p[pix * b.ld + c];
+        else if (mode == 2) { int64_t n = pix / ((int64_t)out.h * out.w); v = v * b.p[n * b.ld + c]; }
+    }
     out.p[pix * out.ld + c] = apply_act(v, act, slope ? slope[c] : 0.0f);
 }
 
@@ -1570,7 +1577,11 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 k_nearest<<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, out);
                 break;
             case CSM_OP_ADD:
-                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act, 1, nullptr);
+                if (in.h < out.h || in.w < out.w || in.h > out.h + 1 || in.w > out.w + 1 || in1.h != out.h || in1.w != out.w) {
+                    csm::set_error("op %d: add: the first operand may exceed the output by at most one row / column", i); return CSM_ERR_ARG;
+                }
+                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act,
+                                                                                            (in.h != out.h || in.w != out.w) ? 3 : 1, nullptr);
                 break;
             case CSM_OP_SCALE:
                 k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act, 2, nullptr);

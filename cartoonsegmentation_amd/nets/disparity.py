@@ -78,14 +78,11 @@ def build_disparity(ws, H, W):
                 col[r] = lat
                 continue
             below = col[r + 1]
-            if below.w * 2 != lat.w:
-                raise NotImplementedError("Disparity GridNet: odd feature-map WIDTH (the reference's [0,-1] crop) is not built; "
-                                          "use a width that stays even down to 1/32")
-            if below.h * 2 == lat.h:
+            if below.h * 2 == lat.h and below.w * 2 == lat.w:
                 col[r] = upsample(p, ws, '%dx%d - %dx%d' % (r + 1, c, r, c), (ROWS[r + 1], ROWS[r], ROWS[r]), below, res=lat)
-            else:                                                  # pad [0,0,0,-1]: drop the last row of the up-sampled map
+            else:                                                  # pad [0,0,0,-1] / [0,-1,0,0]: drop the last row / column of the up-sampled map
                 up = upsample(p, ws, '%dx%d - %dx%d' % (r + 1, c, r, c), (ROWS[r + 1], ROWS[r], ROWS[r]), below)
-                col[r] = p.add(p.crop_rows(up, lat.h), lat)
+                col[r] = p.add(up, lat)
     d = basic(p, ws, 'netDisparity', 'conv-relu-conv', (32, 32, 1), col[0])
     d = p.act(d, 'relu')                                           # threshold(input, 0.0, 0.0)
     p.to_nchw(d, out_ext)

@@ -273,8 +273,11 @@ class Program:
         return self._emit(OP_NEAREST, x, None, out)
 
     def add(self, a, b, act=None, out=None):
+        """a + b.  `a` may be one row and / or one column LARGER than b: its first b.h x b.w pixels are used (the reference's
+        `pad(tenUp, [0, -1, 0, -1])` crops, disparity_estimation.py:172-173) -- the kernel indexes a with its own pitch"""
+        assert a.n == b.n and a.c == b.c and b.h <= a.h <= b.h + 1 and b.w <= a.w <= b.w + 1, (a.shape, b.shape)
         if out is None:
-            out = self.buffer(a.n, a.h, a.w, a.c)
+            out = self.buffer(b.n, b.h, b.w, b.c)
         return self._emit(OP_ADD, a, b, out, act=ACT[act])
 
     def act(self, x, act, out=None, slope=None):

@@ -337,8 +337,11 @@ static void orc_eltwise(view_t a, view_t b, view_t out, int act, int mode, const
     const int64_t M = (int64_t)out.n * out.h * out.w;
     for (int64_t m = 0; m < M; ++m) {
         int64_t n = m / ((int64_t)out.h * out.w);
+        /* the first operand of an add may be up to one row / column larger than the output (torch's negative pad crop) */
+        const int64_t r = m - n * (int64_t)out.h * out.w;
+        const int64_t ma = (n * a.h + r / out.w) * a.w + r % out.w;
         for (int c = 0; c < out.c; ++c) {
-            float v = a.p[m * a.ld + c];
+            float v = a.p[(mode == 1 ? ma : m) * a.ld + c];
             if (mode == 1) v = v + b.p[m * b.ld + c];
             else if (mode == 2) v = v * b.p[n * b.ld + c];
             out.p[m * out.ld + c] = orc_act(v, act, slope ? slope[c] : 0.0f);

@@ -118,7 +118,7 @@ def disparity_case():
     m = ref_loader.load_by_path("anime_3dkenburns.models.disparity_estimation", "anime_3dkenburns/models/disparity_estimation.py")
     sem = fill_synthetic(m.Semantics(), 'semantics.')
     dis = fill_synthetic(m.Disparity(), 'disparity.')
-    for tag, (h, w) in (('96x64', (96, 64)), ('64x128', (64, 128))):
+    for tag, (h, w) in (('96x64', (96, 64)), ('64x128', (64, 128)), ('72x88', (72, 88))):      # 72x88: odd rows AND odd columns on the way down
         g = np.random.default_rng(300 + h)
         x = g.uniform(0, 1, (1, 3, h, w)).astype(np.float32)
         with torch.no_grad():

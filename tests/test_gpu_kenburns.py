@@ -327,6 +327,13 @@ def test_default_depth_estimator_pipeline():
     assert kc['tenRawDisparity'].shape == (1, 1, 320, 384) and torch.isfinite(kc['tenRawPoints']).all()
     frames = pipe.autozoom(kc, inpaint=False)
     assert len(frames) == 2 and frames[0].shape == (320, 384, 3)
+    # a PORTRAIT frame: 680 x 400 -> the estimator runs at 512 x 301, whose feature maps are odd in width on the way down (the
+    # reference's [0,-1] column crops, disparity_estimation.py:172-173; bit-checked against the reference modules in test_gpu_nets)
+    img = synth.image_u8(680, 400, 52)
+    coarse = pipe._depth_est(None, torch.from_numpy(img).cuda())
+    assert coarse.shape == (1, 1, 256, 151) and float(coarse.min()) >= 0.0 and torch.isfinite(coarse).all()
+    kc = pipe.generate_kenburns_config(img)
+    assert kc["tenRawDisparity"].shape == (1, 1, 512, 301) and torch.isfinite(kc["tenRawPoints"]).all()      # max_size 512 scales the frame
 
 
 def test_device_percentiles_and_bokeh_stats_are_exact():

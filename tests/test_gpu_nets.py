@@ -247,7 +247,7 @@ def test_program_run_is_hipgraph_capturable():
     assert torch.equal(y, y2) and not torch.equal(y2, eager)
 
 
-@pytest.mark.parametrize("tag,h,w", [("96x64", 96, 64), ("64x128", 64, 128)])
+@pytest.mark.parametrize("tag,h,w", [("96x64", 96, 64), ("64x128", 64, 128), ("72x88", 72, 88)])
 def test_disparity_estimator_vs_reference_modules(tag, h, w):
     """`depth_est: default` -- Semantics (VGG19-BN slices) and the Disparity GridNet on the HIP engine against the reference's own
     modules (tests/golden/make_golden_nets.py disparity; 96x64 takes the odd-height crop of disparity_estimation.py:172)"""

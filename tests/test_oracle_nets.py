@@ -77,10 +77,10 @@ def test_inpaint_forward_vs_reference():
     assert (o1['existing'] == g['existing']).mean() > 0.99
 
 
-@pytest.mark.parametrize("tag,h,w", [("96x64", 96, 64), ("64x128", 64, 128)])
+@pytest.mark.parametrize("tag,h,w", [("96x64", 96, 64), ("64x128", 64, 128), ("72x88", 72, 88)])
 def test_disparity_estimator_vs_reference_modules(tag, h, w):
     """`depth_est: default`: Semantics (VGG19-BN slices, ceil-mode pools, flip + normalise) and the 6 x 4 Disparity GridNet
-    (disparity_estimation.py:80-193) lowered to layer programs vs the reference's own modules; 96x64 takes the odd-height crop"""
+    (disparity_estimation.py:80-193) lowered to layer programs vs the reference's own modules; 96x64 takes the odd-height crop, 72x88 odd heights and widths (the [0,-1] crops of :172-173)"""
     from cartoonsegmentation_amd.nets import build_disparity, build_semantics
     g = dict(np.load(os.path.join(GOLDEN, "net_disparity_%s.npz" % tag)))
     sem = np.zeros_like(g['sem'])
