@@ -67,11 +67,27 @@ class Workload:
                                 for _ in range(world)]
 
     def step_and_gather(self):
-        """one frame on this rank, then the per-rank gather of the uint8 output to rank 0"""
+        """one step on this rank, then the per-rank gather of the uint8 output to rank 0.  The gather runs
+        asynchronously on the communicator's stream from one of two staging copies of the frames, so step s + 1 computes while
+        the frames of step s travel; finish_gathers() (inside the timed region) waits for whatever is still in flight."""
         frame = self.step()
         if self.dist is not None:
-            self.dist.gather(frame.view(self.frames_per_step, self.H, self.W, 3), self.gather_list, dst=0)
+            if not hasattr(self, '_stage'):
+                self._stage = [torch.empty((self.frames_per_step, self.H, self.W, 3), dtype=torch.uint8, device=frame.device) for _ in range(2)]
+                self._work, self._parity = [None, None], 0
+            p = self._parity
+            self._parity ^= 1
+            if self._work[p] is not None:
+                self._work[p].wait()                           # the previous gather from this staging buffer (two steps ago)
+            self._stage[p].copy_(frame.view(self.frames_per_step, self.H, self.W, 3))
+            self._work[p] = self.dist.gather(self._stage[p], self.gather_list, dst=0, async_op=True)
         return frame
+
+    def finish_gathers(self):
+        for p, w in enumerate(getattr(self, '_work', [])):
+            if w is not None:
+                w.wait()
+                self._work[p] = None
 
     def extra(self):
         return {}
@@ -445,12 +461,14 @@ def main():
         wl.step_and_gather()                  # ranks != 0 now hold real weights: build whatever their first step skipped -- untimed
     for _ in range(a.warmup):
         wl.step_and_gather()
+    wl.finish_gathers()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         wl.step_and_gather()
+    wl.finish_gathers()                                # every step's frames are on rank 0 before the clock stops
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
