@@ -31,21 +31,27 @@ __device__ __forceinline__ float key_to_float(unsigned k) {
 struct SelState {            // device-resident state of the 4 concurrent selections
     unsigned prefix[4];      // key bits fixed so far (high bits)
     unsigned rank[4];        // rank still to find among the elements matching the prefix
+    unsigned ticket;         // blocks of the last pick pass that are done (the last one computes the result); 0 between calls
 };
+struct SelInit { unsigned rank[4]; };                     // the four ranks of a call (arguments of the first histogram pass)
 
 // pass p: shift / bits of the digit, mask of the already fixed bits
 __device__ __forceinline__ void pass_geom(int p, int &shift, int &bits) {
     if (p == 0) { shift = 21; bits = 11; } else if (p == 1) { shift = 10; bits = 11; } else { shift = 0; bits = 10; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_sel_hist(const float *__restrict__ v, int64_t n, int pass, const SelState *__restrict__ st,
+__global__ __launch_bounds__(kBlock) void k_sel_hist(const float *__restrict__ v, int64_t n, int pass, SelState *__restrict__ st, SelInit init,
                                                       unsigned *__restrict__ partial /* [4][kSelBlocks][kBins] */) {
     __shared__ unsigned h[4][kBins];
     int shift, bits; pass_geom(pass, shift, bits);
     const int nb = 1 << bits;
     unsigned pre[4];
+    // pass 0 does not read the state (no bits are fixed yet): block 0 INITIALISES it for the pick kernel that follows -- what
+    // used to be a separate one-thread launch (a launch costs ~4.8 us on this stack whatever it does)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pre[r] = st->prefix[r];
+    for (int r = 0; r < 4; ++r) pre[r] = pass == 0 ? 0u : st->prefix[r];
+    if (pass == 0 && blockIdx.x == 0 && threadIdx.x < 4) { st->prefix[threadIdx.x] = 0u; st->rank[threadIdx.x] = init.rank[threadIdx.x]; }
+    if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 4) st->ticket = 0u;
     // ranks that share a prefix share a histogram (pass 0: all four)
     int owner[4];
 #pragma unroll
@@ -90,7 +96,10 @@ __global__ __launch_bounds__(kBlock) void k_sel_hist(const float *__restrict__ v
 }
 
 // one block per rank: column sums of the partials, scan, pick the digit that holds the rank, advance prefix / rank
-__global__ __launch_bounds__(1024) void k_sel_pick(const unsigned *__restrict__ partial, int nblocks, int pass, SelState *__restrict__ st) {
+__device__ __forceinline__ void sel_finish(const volatile SelState *st, double t_lo, double t_hi, float *out2);
+
+__global__ __launch_bounds__(1024) void k_sel_pick(const unsigned *__restrict__ partial, int nblocks, int pass, SelState *__restrict__ st,
+                                                    double t_lo, double t_hi, float *__restrict__ out2) {
     __shared__ unsigned col[kBins];
     __shared__ unsigned scan[1024];
     int shift, bits; pass_geom(pass, shift, bits);
@@ -125,18 +134,24 @@ __global__ __launch_bounds__(1024) void k_sel_pick(const unsigned *__restrict__ 
     }
     const unsigned before = tid ? scan[tid - 1] : 0u;           // elements in digits < 2 tid
     // the digit d with  count(< d) <= rank < count(<= d)
-    if (rank >= before && rank < before + a && 2 * tid < nb) { st->prefix[r] |= (unsigned)(2 * tid) << shift; st->rank[r] = rank - before; }
-    else if (rank >= before + a && rank < before + a + b2 && 2 * tid + 1 < nb) { st->prefix[r] |= (unsigned)(2 * tid + 1) << shift; st->rank[r] = rank - before - a; }
-}
-
-__global__ void k_sel_init(SelState *st, unsigned r0, unsigned r1, unsigned r2, unsigned r3) {
-    st->prefix[0] = st->prefix[1] = st->prefix[2] = st->prefix[3] = 0u;
-    st->rank[0] = r0; st->rank[1] = r1; st->rank[2] = r2; st->rank[3] = r3;
+    if (rank >= before && rank < before + a && 2 * tid < nb) { st->prefix[r] |= (unsigned)(2 * tid) << shift; st->rank[r] = rank - before; __threadfence(); }
+    else if (rank >= before + a && rank < before + a + b2 && 2 * tid + 1 < nb) { st->prefix[r] |= (unsigned)(2 * tid + 1) << shift; st->rank[r] = rank - before - a; __threadfence(); }
+    if (pass != 2) return;
+    // last pass: the block that finishes last turns the four order statistics into the two percentiles (was a fourth launch)
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            sel_finish(st, t_lo, t_hi, out2);
+            st->ticket = 0u;
+        }
+    }
 }
 
 // numpy percentile, method 'linear' (numpy 1.26 _lerp): a + (b - a) t for t < 0.5, else b - (b - a)(1 - t); arithmetic in float64 on
 // float32 samples, result rounded to float32 -- what depth_modules/zoedepth/utils/misc.py:118-119 gets from np.percentile
-__global__ void k_sel_finish(const SelState *st, double t_lo, double t_hi, float *out2) {
+__device__ __forceinline__ void sel_finish(const volatile SelState *st, double t_lo, double t_hi, float *out2) {
     const double a0 = (double)key_to_float(st->prefix[0]), b0 = (double)key_to_float(st->prefix[1]);
     const double a1 = (double)key_to_float(st->prefix[2]), b1 = (double)key_to_float(st->prefix[3]);
     const double r0 = t_lo < 0.5 ? a0 + (b0 - a0) * t_lo : b0 - (b0 - a0) * (1.0 - t_lo);
@@ -162,6 +177,8 @@ __global__ __launch_bounds__(kBlock) void k_colorize_dev(const float *__restrict
 }
 
 // ---- bokeh depth: scalars from the histogram of the uint8 depth --------------------------------------------------------------
+// histogram of the uint8 depth in per-block partials.  (Folding the statistics into this kernel through a last-block ticket was
+// measured: 31 us against 10 + 11 us for the two launches -- the one block that reads all partials serialises the tail.)
 __global__ __launch_bounds__(kBlock) void k_u8_hist(const uint8_t *__restrict__ d, int64_t n, unsigned *__restrict__ partial /* [blocks][256] */) {
     __shared__ unsigned h[256];
     h[threadIdx.x] = 0u;
@@ -238,16 +255,15 @@ extern "C" int csm_percentile_pair(const float *value, int64_t n, double q_lo, d
     const double v0 = (double)(n - 1) * (q_lo / 100.0), v1 = (double)(n - 1) * (q_hi / 100.0);
     const int64_t l0 = (int64_t)v0, l1 = (int64_t)v1;
     const int64_t h0 = l0 + 1 < n ? l0 + 1 : n - 1, h1 = l1 + 1 < n ? l1 + 1 : n - 1;
-    k_sel_init<<<1, 1, 0, st>>>(state, (unsigned)l0, (unsigned)h0, (unsigned)l1, (unsigned)h1);
-    int rc = csm::check_launch("k_sel_init"); if (rc) return rc;
+    SelInit init; init.rank[0] = (unsigned)l0; init.rank[1] = (unsigned)h0; init.rank[2] = (unsigned)l1; init.rank[3] = (unsigned)h1;
+    int rc;
     for (int pass = 0; pass < 3; ++pass) {
-        k_sel_hist<<<kSelBlocks, kBlock, 0, st>>>(value, n, pass, state, partial);
+        k_sel_hist<<<kSelBlocks, kBlock, 0, st>>>(value, n, pass, state, init, partial);
         rc = csm::check_launch("k_sel_hist"); if (rc) return rc;
-        k_sel_pick<<<4, 1024, 0, st>>>(partial, kSelBlocks, pass, state);
+        k_sel_pick<<<4, 1024, 0, st>>>(partial, kSelBlocks, pass, state, v0 - (double)l0, v1 - (double)l1, out2);
         rc = csm::check_launch("k_sel_pick"); if (rc) return rc;
     }
-    k_sel_finish<<<1, 1, 0, st>>>(state, v0 - (double)l0, v1 - (double)l1, out2);
-    return csm::check_launch("k_sel_finish");
+    return CSM_OK;
 }
 
 extern "C" int csm_colorize_gray_r_dev(const float *value, uint8_t *out, int64_t n, const float *vmin_vmax_dev, const uint8_t *lut256_host,

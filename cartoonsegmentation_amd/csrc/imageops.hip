@@ -529,9 +529,13 @@ namespace {
 // round(d * dir * (s - n/2) * min(H, W)) with d = the caller's depth plane; bokeh_blur feeds d <= 0.0005 (utils/effects.py:153),
 // i.e. |offset| <= 0.008 min(H, W), and R is picked for that.  A sample that falls outside the staged window anyway (any other
 // depth plane) is fetched from global memory: same result for every input, only slower.
-template <int R>
+// FINISH: the third pass of bokeh_blur also applies utils/effects.py:172,179-180 -- uint8(pow((diag + rhom) / 2, 1 / lightness) * 255)
+// with diag = this pass's INPUT at the pixel (the window centre) and rhom = its result -- and writes the uint8 frame instead of
+// the float plane: one launch, one 12 MB write and two 12 MB reads less per frame.
+template <int R, bool FINISH>
 __global__ __launch_bounds__(256) void k_bokeh_pass_tile(const float *__restrict__ img, const float *__restrict__ depth,
-                                                          float *__restrict__ out, int H, int W, int nsamples, float dx, float dy) {
+                                                          float *__restrict__ out, uint8_t *__restrict__ out_u8, float inv_lf,
+                                                          int H, int W, int nsamples, float dx, float dy) {
     constexpr int TX = 32, TY = 8, WW = TX + 2 * R, WH = TY + 2 * R;
     __shared__ float4 win[WH * WW];
     const int tid = threadIdx.x;
@@ -551,8 +555,10 @@ __global__ __launch_bounds__(256) void k_bokeh_pass_tile(const float *__restrict
     const int lx = tid & 31, ly = tid >> 5;
     const int x = bx + lx, y = by + ly;
     float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+    float4 ctr_keep = float4{0.0f, 0.0f, 0.0f, 0.0f};
     if (x < W && y < H) {
         const float4 ctr = win[(ly + R) * WW + lx + R];
+        ctr_keep = ctr;
         const int im_size = min(H, W), off = nsamples / 2;
         const float ddx = dx * ctr.w, ddy = dy * ctr.w;
         float weight = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
@@ -571,14 +577,29 @@ __global__ __launch_bounds__(256) void k_bokeh_pass_tile(const float *__restrict
         r1 = weight != 0.0f ? c1 / weight : ctr.y;
         r2 = weight != 0.0f ? c2 / weight : ctr.z;
     }
-    __syncthreads();                                   // the window is dead: reuse it to write whole 96-float row segments
-    float *stage = reinterpret_cast<float *>(win);
-    stage[tid * 3] = r0; stage[tid * 3 + 1] = r1; stage[tid * 3 + 2] = r2;
-    __syncthreads();
-    const int row_floats = (W - bx < TX ? W - bx : TX) * 3;
-    for (int i = tid; i < TY * TX * 3; i += 256) {
-        const int ry = i / (TX * 3), rx = i - ry * (TX * 3);
-        if (by + ry < H && rx < row_floats) out[((int64_t)(by + ry) * W + bx) * 3 + rx] = stage[i];
+    __syncthreads();                                   // the window is dead: reuse it to write whole row segments
+    const int row_vals = (W - bx < TX ? W - bx : TX) * 3;
+    if (FINISH) {
+        uint8_t *stage8 = reinterpret_cast<uint8_t *>(win);
+        if (x < W && y < H) {
+            const float4 c = ctr_keep;
+            stage8[tid * 3] = (uint8_t)(powf((c.x + r0) / 2.0f, inv_lf) * 255.0f);
+            stage8[tid * 3 + 1] = (uint8_t)(powf((c.y + r1) / 2.0f, inv_lf) * 255.0f);
+            stage8[tid * 3 + 2] = (uint8_t)(powf((c.z + r2) / 2.0f, inv_lf) * 255.0f);
+        }
+        __syncthreads();
+        for (int i = tid; i < TY * TX * 3; i += 256) {
+            const int ry = i / (TX * 3), rx = i - ry * (TX * 3);
+            if (by + ry < H && rx < row_vals) out_u8[((int64_t)(by + ry) * W + bx) * 3 + rx] = stage8[i];
+        }
+    } else {
+        float *stage = reinterpret_cast<float *>(win);
+        stage[tid * 3] = r0; stage[tid * 3 + 1] = r1; stage[tid * 3 + 2] = r2;
+        __syncthreads();
+        for (int i = tid; i < TY * TX * 3; i += 256) {
+            const int ry = i / (TX * 3), rx = i - ry * (TX * 3);
+            if (by + ry < H && rx < row_vals) out[((int64_t)(by + ry) * W + bx) * 3 + rx] = stage[i];
+        }
     }
 }
 
@@ -625,17 +646,32 @@ __global__ __launch_bounds__(256) void k_colorize_gray_r(const float *__restrict
 
 }  // namespace
 
-extern "C" int csm_bokeh_pass(const float *img_hwc, const float *depth, float *out_hwc, int H, int W, int nsamples, float dx, float dy,
-                              void *stream) {
-    CSM_REQUIRE(img_hwc && depth && out_hwc && img_hwc != out_hwc && H > 0 && W > 0 && nsamples > 0);
+static int bokeh_pass_launch(const float *img, const float *depth, float *out, uint8_t *out_u8, float inv_lf, int H, int W, int nsamples,
+                             float dx, float dy, hipStream_t st) {
     // halo for bokeh_blur's depth scale (see the kernel): |offset| <= round(0.0005 * (nsamples / 2) * min(H, W)), +1 for safety
     const int reach = (int)(0.0005 * (double)((nsamples + 1) / 2) * (double)(H < W ? H : W) + 0.5) + 1;
     const dim3 grid((unsigned)csm::cdiv(W, 32), (unsigned)csm::cdiv(H, 8));
-    hipStream_t st = (hipStream_t)stream;
-    if (reach <= 9) k_bokeh_pass_tile<9><<<grid, 256, 0, st>>>(img_hwc, depth, out_hwc, H, W, nsamples, dx, dy);
-    else if (reach <= 16) k_bokeh_pass_tile<16><<<grid, 256, 0, st>>>(img_hwc, depth, out_hwc, H, W, nsamples, dx, dy);
-    else k_bokeh_pass_tile<20><<<grid, 256, 0, st>>>(img_hwc, depth, out_hwc, H, W, nsamples, dx, dy);
+    if (out_u8) {
+        if (reach <= 9) k_bokeh_pass_tile<9, true><<<grid, 256, 0, st>>>(img, depth, out, out_u8, inv_lf, H, W, nsamples, dx, dy);
+        else if (reach <= 16) k_bokeh_pass_tile<16, true><<<grid, 256, 0, st>>>(img, depth, out, out_u8, inv_lf, H, W, nsamples, dx, dy);
+        else k_bokeh_pass_tile<20, true><<<grid, 256, 0, st>>>(img, depth, out, out_u8, inv_lf, H, W, nsamples, dx, dy);
+    } else {
+        if (reach <= 9) k_bokeh_pass_tile<9, false><<<grid, 256, 0, st>>>(img, depth, out, out_u8, inv_lf, H, W, nsamples, dx, dy);
+        else if (reach <= 16) k_bokeh_pass_tile<16, false><<<grid, 256, 0, st>>>(img, depth, out, out_u8, inv_lf, H, W, nsamples, dx, dy);
+        else k_bokeh_pass_tile<20, false><<<grid, 256, 0, st>>>(img, depth, out, out_u8, inv_lf, H, W, nsamples, dx, dy);
+    }
     return csm::check_launch("k_bokeh_pass");
+}
+
+extern "C" int csm_bokeh_pass(const float *img_hwc, const float *depth, float *out_hwc, int H, int W, int nsamples, float dx, float dy,
+                              void *stream) {
+    CSM_REQUIRE(img_hwc && depth && out_hwc && img_hwc != out_hwc && H > 0 && W > 0 && nsamples > 0);
+    return bokeh_pass_launch(img_hwc, depth, out_hwc, nullptr, 1.0f, H, W, nsamples, dx, dy, (hipStream_t)stream);
+}
+extern "C" int csm_bokeh_pass_finish(const float *diag_hwc, const float *depth, uint8_t *out_hwc_u8, int H, int W, int nsamples, float dx, float dy,
+                                     float lightness, void *stream) {
+    CSM_REQUIRE(diag_hwc && depth && out_hwc_u8 && H > 0 && W > 0 && nsamples > 0 && lightness != 0.0f);
+    return bokeh_pass_launch(diag_hwc, depth, nullptr, out_hwc_u8, (float)(1.0 / (double)lightness), H, W, nsamples, dx, dy, (hipStream_t)stream);
 }
 extern "C" int csm_bokeh_highlight(const uint8_t *img_hwc, float *out_hwc, int64_t n, float lightness, void *stream) {
     CSM_REQUIRE(img_hwc && out_hwc && n > 0);

@@ -313,7 +313,7 @@ def _tail_scratch(dev):
     if dev not in _TAIL_SCRATCH:
         L = _lib.load()
         _TAIL_SCRATCH[dev] = (torch.empty(L.csm_percentile_scratch_bytes(), dtype=torch.uint8, device=dev),
-                              torch.empty(L.csm_bokeh_depth_scratch_bytes(), dtype=torch.uint8, device=dev),
+                              torch.zeros(L.csm_bokeh_depth_scratch_bytes(), dtype=torch.uint8, device=dev),   # completion counter starts at 0
                               torch.empty(2, dtype=torch.float32, device=dev))
     return _TAIL_SCRATCH[dev]
 
@@ -358,11 +358,12 @@ def bokeh_blur(img, depth, num_samples=32, lightness_factor=10, depth_factor=2, 
     check(L.csm_bokeh_depth_auto(ptr(d8), ptr(dm), i64(n), f32(fp), ptr(_tail_scratch(dev)[1]), stream_ptr()), "bokeh_depth")
     hi = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     check(L.csm_bokeh_highlight(ptr(img_d), ptr(hi), i64(n * 3), f32(lightness_factor), stream_ptr()), "bokeh_highlight")
-    a, b, c = torch.empty_like(hi), torch.empty_like(hi), torch.empty_like(hi)
+    a, b = torch.empty_like(hi), torch.empty_like(hi)
     PI = _math.pi
-    for src, dst, (dx, dy) in ((hi, a, (0, 1)), (a, b, (_math.cos(-PI / 6), _math.sin(-PI / 6))),
-                               (b, c, (_math.cos(-PI * 5 / 6), _math.sin(-PI * 5 / 6)))):
+    for src, dst, (dx, dy) in ((hi, a, (0, 1)), (a, b, (_math.cos(-PI / 6), _math.sin(-PI / 6)))):
         check(L.csm_bokeh_pass(ptr(src), ptr(dm), ptr(dst), i32(H), i32(W), i32(num_samples), f32(dx), f32(dy), stream_ptr()), "bokeh_pass")
     out = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-    check(L.csm_bokeh_finish(ptr(b), ptr(c), ptr(out), i64(n * 3), f32(lightness_factor), stream_ptr()), "bokeh_finish")
+    # third pass + ((diag + rhom) / 2) ** (1 / lightness) * 255 -> uint8 (utils/effects.py:172,179-180) in one kernel
+    check(L.csm_bokeh_pass_finish(ptr(b), ptr(dm), ptr(out), i32(H), i32(W), i32(num_samples), f32(_math.cos(-PI * 5 / 6)),
+                                  f32(_math.sin(-PI * 5 / 6)), f32(lightness_factor), stream_ptr()), "bokeh_pass_finish")
     return out

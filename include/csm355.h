@@ -322,6 +322,10 @@ int csm_bokeh_pass(const float *img_hwc, const float *depth, float *out_hwc, int
                    void *stream);
 /* (img/255)^lightness  utils/effects.py:155-156 ; n = H*W*3 */
 int csm_bokeh_highlight(const uint8_t *img_hwc, float *out_hwc, int64_t n, float lightness, void *stream);
+/* the third pass of bokeh_blur fused with its finish: out = uint8(((diag + pass(diag)) / 2)^(1/lightness) * 255), the same
+ * operations in the same order as csm_bokeh_pass followed by csm_bokeh_finish (no float plane is written) */
+int csm_bokeh_pass_finish(const float *diag_hwc, const float *depth, uint8_t *out_hwc_u8, int H, int W, int nsamples, float dx, float dy,
+                          float lightness, void *stream);
 /* ((diag+rhom)/2)^(1/lightness)*255 -> uint8  utils/effects.py:172,179-180 */
 int csm_bokeh_finish(const float *diag_hwc, const float *rhom_hwc, uint8_t *out_hwc, int64_t n, float lightness, void *stream);
 /* depth map of bokeh_blur  utils/effects.py:146-153,162-163: out = (1 - ((dmax - |d - focal|) - mn) / mx2) * 0.0005 ;

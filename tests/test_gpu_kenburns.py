@@ -149,13 +149,20 @@ def test_bokeh_and_colorize_vs_oracle_and_reference():
     assert np.array_equal(d8, okb.colorize_gray_r(g['depth_f']))                  # == oracle (numpy-1.26 percentile rule)
     dd = np.abs(d8.astype(np.int32) - g['depth_u8'].astype(np.int32))
     assert dd.max() <= 1 and (dd == 0).mean() > 0.98                              # reference colorize under numpy 2.2
-    from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, f32, check
+    from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, i64, f32, check
     imf = torch.from_numpy((g['img'].astype(np.float32) / 255)).cuda().contiguous()
     dn = torch.from_numpy(g['dn']).cuda()
     one = torch.empty_like(imf)
     check(load().csm_bokeh_pass(ptr(imf), ptr(dn), ptr(one), i32(240), i32(320), i32(32), f32(np.cos(-np.pi / 6)), f32(np.sin(-np.pi / 6)),
                                 stream_ptr()))
     assert np.array_equal(one.cpu().numpy(), g['one_pass'])                      # kernel_bokeh: bit-exact vs the reference text
+    # the fused third pass (csm_bokeh_pass_finish) == csm_bokeh_pass followed by csm_bokeh_finish, byte for byte
+    two = torch.empty_like(imf); sep = torch.empty((240, 320, 3), dtype=torch.uint8, device='cuda'); fus = torch.empty_like(sep)
+    ddx, ddy = f32(np.cos(-np.pi * 5 / 6)), f32(np.sin(-np.pi * 5 / 6))
+    check(load().csm_bokeh_pass(ptr(one), ptr(dn), ptr(two), i32(240), i32(320), i32(32), ddx, ddy, stream_ptr()))
+    check(load().csm_bokeh_finish(ptr(one), ptr(two), ptr(sep), i64(240 * 320 * 3), f32(13.0), stream_ptr()))
+    check(load().csm_bokeh_pass_finish(ptr(one), ptr(dn), ptr(fus), i32(240), i32(320), i32(32), ddx, ddy, f32(13.0), stream_ptr()))
+    assert torch.equal(sep, fus)
     for tag, fp in (("fp100", 100.0), ("fp17", 17.25)):
         out = ops.bokeh_blur(torch.from_numpy(g['img']).cuda(), torch.from_numpy(g['depth_u8']).cuda(), 32, 13, depth_factor=1,
                              use_cuda=True, focal_plane=fp).cpu().numpy()
@@ -365,7 +372,7 @@ def test_device_percentiles_and_bokeh_stats_are_exact():
         dmax = float(df.max().item()); t = dmax - (df - fp).abs(); mn = float(t.min().item()); mx2 = float((t - mn).max().item())
         ref, got = torch.empty((300, 400), device='cuda'), torch.empty((300, 400), device='cuda')
         check(L.csm_bokeh_depth(ptr(dd), ptr(ref), i64(d8.size), f32(dmax), f32(fp), f32(mn), f32(mx2), stream_ptr()))
-        sc = torch.empty(L.csm_bokeh_depth_scratch_bytes(), dtype=torch.uint8, device='cuda')
+        sc = torch.zeros(L.csm_bokeh_depth_scratch_bytes(), dtype=torch.uint8, device="cuda")         # the completion counter starts at 0
         check(L.csm_bokeh_depth_auto(ptr(dd), ptr(got), i64(d8.size), f32(fp), ptr(sc), stream_ptr()))
         assert torch.equal(ref, got), fp
 
