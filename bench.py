@@ -293,7 +293,8 @@ class FrameWorkload(Workload):
 
     def variants(self):
         v = {"batch1": self._fps(batch=1, conv_roofline=True), "batch16": self._fps(batch=16, conv_roofline=True), "instances1": self._fps(instances=1),
-             "instances8": self._fps(instances=8), "det1024_batch4": self._fps(batch=4, det=1024), "video": self._video(),
+             "instances8": self._fps(instances=8), "instances100_batch1": self._fps(batch=1, instances=100, steps=2),
+             "det1024_batch4": self._fps(batch=4, det=1024), "video": self._video(),
              "warp_chain": self._warp_points()}
         v["reference_shaped_ratio"] = "1 seg + 1 depth + 75 warps: see video (inpaint_and_75_frames_ms vs config_ms)"
         return v
