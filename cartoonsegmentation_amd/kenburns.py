@@ -336,17 +336,31 @@ class KenBurnsPipeline:
         68 channels -> median-5 clean-up -> GridNet -> colour + disparity.  mean/std are scalar torch reductions."""
         W, H, f, b = objCommon['intWidth'], objCommon['intHeight'], objCommon['fltFocal'], objCommon['fltBaseline']
         ctx_p, grid_p = self._inpaint_programs(H, W)
-        _, _, pts, _ = ops.disparity_to_points(tenDisparity, f, b, eps=0.0000001)
-        pts = pts.view(1, 3, -1)
-        tenMean = [tenImage.mean([1, 2, 3], True), tenDisparity.mean([1, 2, 3], True)]
-        tenStd = [tenImage.std([1, 2, 3], False, True), tenDisparity.std([1, 2, 3], False, True)]
-        ni = (tenImage - tenMean[0]) / (tenStd[0] + 0.0000001)
-        nd = (tenDisparity - tenMean[1]) / (tenStd[1] + 0.0000001)
-        x = torch.cat([ni, nd], 1).contiguous()
-        ctx = torch.empty((1, 64, H, W), dtype=torch.float32, device=self.device)
-        ctx_p.run(x, ctx)
+        # Everything up to the splat depends on the RAW image / disparity only, and process_kenburns inpaints the same pair at two
+        # shifts (kenburns_effect.py:441-453, :1003-1013): the point cloud, the normalisation and the context features (two 1024^2
+        # convolutions + a 64-channel layout change) are computed once per (image, disparity) pair and reused -- same program,
+        # same inputs, same bits as recomputing them.
+        key = (tenImage.data_ptr(), tenDisparity.data_ptr(), tenImage._version, tenDisparity._version, H, W)
+        shared = getattr(objCommon, '_inpaint_shared', None)
+        if shared is None or shared[0] != key:
+            _, _, pts, _ = ops.disparity_to_points(tenDisparity, f, b, eps=0.0000001)
+            pts = pts.view(1, 3, -1)
+            tenMean = [tenImage.mean([1, 2, 3], True), tenDisparity.mean([1, 2, 3], True)]
+            tenStd = [tenImage.std([1, 2, 3], False, True), tenDisparity.std([1, 2, 3], False, True)]
+            ni = (tenImage - tenMean[0]) / (tenStd[0] + 0.0000001)
+            nd = (tenDisparity - tenMean[1]) / (tenStd[1] + 0.0000001)
+            x = torch.cat([ni, nd], 1).contiguous()
+            ctx = torch.empty((1, 64, H, W), dtype=torch.float32, device=self.device)
+            ctx_p.run(x, ctx)
+            feat = torch.cat([ni, nd, ctx], 1).view(1, 68, -1)
+            shared = (key, pts, tenMean, tenStd, nd, feat)
+            try:
+                objCommon._inpaint_shared = shared
+            except AttributeError:                                              # a plain dict config: no caching
+                pass
+        _, pts, tenMean, tenStd, nd, feat = shared
         ps = (pts + tenShift).contiguous()
-        render, existing = ops.render_pointcloud(ps, torch.cat([ni, nd, ctx], 1).view(1, 68, -1), W, H, f, b)
+        render, existing = ops.render_pointcloud(ps, feat, W, H, f, b)
         if segmasks is not None:
             s = torch.cat([segmasks, nd], 1).view(1, segmasks.shape[1] + 1, -1)
             segmasks, _ = ops.render_pointcloud(ps, s, W, H, f, b)
@@ -637,6 +651,7 @@ class KenBurnsPipeline:
                     shift = ops.shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, objCommon)
                     tenShift = torch.tensor(shift, dtype=torch.float32).view(1, 3, 1).to(self.device)
                     self.inpaint(1.1 * tenShift, None, objCommon, verbose)
+                objCommon._inpaint_shared = None                   # the features shared by the two passes (285 MB at 1024^2) are dead now
             pts, rgb, dep = objCommon['tenInpaPoints'].contiguous(), objCommon.inpainted_img.contiguous(), objCommon['tenInpaDepth'].contiguous()
             for k, fltStep in enumerate(steps):
                 fltFrom = 1.0 - fltStep
