@@ -8,7 +8,7 @@ from cartoonsegmentation_amd.program import Program
 from cartoonsegmentation_amd.runtime import CompiledProgram
 LAYERS = [(16, 360, 360, 32, 64), (16, 360, 360, 64, 32), (16, 360, 360, 64, 16), (16, 360, 360, 32, 32), (16, 360, 360, 16, 32), (16, 360, 360, 16, 16),
           (1, 1024, 1024, 32, 32), (1, 512, 512, 64, 64), (1, 256, 256, 96, 96), (1, 1024, 1024, 72, 32), (16, 180, 180, 32, 32), (16, 180, 180, 16, 16)]
-CFGS = [int(c) for c in os.environ.get('CFGS', '12 23 26 38 39 6 18 24').split()]
+CFGS = [int(c) for c in os.environ.get('CFGS', '12 23 26 6 18 24').split()]
 from cartoonsegmentation_amd import _lib
 L = _lib.load()
 print("cfgs", CFGS)
