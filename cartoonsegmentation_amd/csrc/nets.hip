@@ -25,6 +25,7 @@
 #include <map>
 #include <mutex>
 #include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -1707,28 +1708,51 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
             auto hit = g_tile_cache.find(key);
             if (hit != g_tile_cache.end()) { op.tile = hit->second; ++tuned; continue; }
         }
+        // one timed run of `op` with the tile in op.tile: min over `n` repetitions after one warm-up (which also sets the LDS attribute)
+        auto time_tile = [&](int n, float &tmin) -> int {
+            tmin = 1e30f;
+            for (int r = 0; r <= n; ++r) {
+                hipError_t he = hipEventRecord(ev[0], st);
+                int rc2 = CSM_OK;
+                if (he == hipSuccess) rc2 = run_ops(&op, 1, tensors, n_tensors, weights, workspace, ext, n_ext, st, nullptr);
+                if (rc2) return rc2;
+                if (he == hipSuccess) he = hipEventRecord(ev[1], st);
+                if (he == hipSuccess) he = hipEventSynchronize(ev[1]);
+                if (he != hipSuccess) { csm::set_error("conv_autotune timing: %s", hipGetErrorString(he)); return CSM_ERR_HIP; }
+                float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+                if (r > 0 && ms < tmin) tmin = ms;
+            }
+            return CSM_OK;
+        };
         float best = 1e30f; int best_cfg = -1;
+        std::vector<std::pair<float, int>> timed;
         for (size_t c = 0; c < sizeof(cand_all) / sizeof(int); ++c) {
             if (cand_bn[c] >= 2 * npad && cand_bn[c] > 32) continue;      // tile much wider than the output: never wins
             if (cand_all[c] >= CFG_P64x64 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
             if (cand_bn[c] == 4 && (op.cout_g > 4 || op.groups != 1 || op.ksplit > 1)) continue;
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
-            if (cand_bn[c] == 32 && op.cout_g > 64) continue;
+            if (cand_bn[c] == 32 && op.cout_g > 64 && (op.cout_g % 64) != 32) continue;   // (96, 160 ... outputs: 32-wide tiles waste no MFMA columns)
             op.tile = cand_all[c] + 1;
-            float tmin = 1e30f;
-            for (int r = 0; r <= reps; ++r) {                              // r == 0 warms up (and sets the LDS attribute)
-                hipError_t he = hipEventRecord(ev[0], st);
-                if (he == hipSuccess) rc = run_ops(&op, 1, tensors, n_tensors, weights, workspace, ext, n_ext, st, nullptr);
-                if (rc) break;
-                if (he == hipSuccess) he = hipEventRecord(ev[1], st);
-                if (he == hipSuccess) he = hipEventSynchronize(ev[1]);
-                if (he != hipSuccess) { csm::set_error("conv_autotune timing: %s", hipGetErrorString(he)); rc = CSM_ERR_HIP; break; }
-                float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
-                if (r > 0 && ms < tmin) tmin = ms;
-            }
+            float tmin;
+            rc = time_tile(reps, tmin);
             if (rc) break;
-            if (tmin < best) { best = tmin; best_cfg = cand_all[c]; }
+            timed.emplace_back(tmin, cand_all[c]);
         }
+        if (rc) break;
+        // the three fastest are within a few percent of each other on many layers and one sample of three is noisy: time them again
+        // (twice the repetitions, minimum of both rounds) before choosing
+        std::sort(timed.begin(), timed.end());
+        static const int retime = getenv("CSM_TUNE_RETIME") ? atoi(getenv("CSM_TUNE_RETIME")) : 1;
+        if (!retime && !timed.empty()) { best = timed[0].first; best_cfg = timed[0].second; }
+        for (size_t k = 0; retime && k < timed.size() && k < 3 && rc == CSM_OK; ++k) {
+            op.tile = timed[k].second + 1;
+            float tmin;
+            rc = time_tile(2 * reps, tmin);
+            if (rc) break;
+            if (tmin < timed[k].first) timed[k].first = tmin;
+            if (timed[k].first < best) { best = timed[k].first; best_cfg = timed[k].second; }
+        }
+        if (rc) break;
         op.tile = best_cfg >= 0 ? best_cfg + 1 : 0;
         { std::lock_guard<std::mutex> lk(g_tile_mutex); g_tile_cache[key] = op.tile; }
         ++tuned;
