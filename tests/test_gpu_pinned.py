@@ -150,6 +150,24 @@ def test_batched_autozoom_vs_reference_text_and_oracle():
                 os.environ.pop('CSM_AUTOZOOM_PATH', None)
         assert res['bands'] == res['planes'], (Hh, Ww, n, pile)
         assert n == 0 or max(res['bands']) > 0
+    # BASELINE's full size: the 1024 x 1024 frame cloud (N = P), a 6 x 6 sub-grid of the search's shifts, both paths, equal counts
+    from cartoonsegmentation_amd import synth
+    S = 1024
+    sc = synth.warp_scene(S, S, 7)
+    disp = torch.from_numpy(sc['disp']).cuda()
+    disp = disp / disp.max() * sc['baseline']
+    _, _, pts, _ = ops.disparity_to_points(disp, sc['focal'], sc['baseline'])
+    pts = pts.view(1, 3, -1).contiguous()
+    lin = np.linspace(-9.0, 9.0, 6)
+    shifts = [(float(a), float(b), -6.5) for b in lin for a in lin]
+    res = {}
+    for path in ('bands', 'planes'):
+        os.environ['CSM_AUTOZOOM_PATH'] = path
+        try:
+            res[path] = ops.autozoom_coverage(pts, shifts, S, S, sc['focal'], sc['baseline'])
+        finally:
+            os.environ.pop('CSM_AUTOZOOM_PATH', None)
+    assert res['bands'] == res['planes'] and min(res['bands']) > 0.9 * S * S
 
 
 def test_frame_scaledown_and_path_input(tmp_path):
