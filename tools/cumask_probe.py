@@ -45,6 +45,9 @@ def one(s, cp, ts):
     return f
 print("batch %d: one stream (rtmdet + isnet + leres) %.2f ms" % (N, wall(seq)), flush=True)
 print("two plain streams %.2f ms" % wall(two(torch.cuda.Stream(), torch.cuda.Stream())), flush=True)
+print("rtmdet+isnet stream HIGH priority, leres normal %.2f ms" % wall(two(torch.cuda.Stream(priority=-1), torch.cuda.Stream())), flush=True)
+print("leres stream HIGH priority, rtmdet+isnet normal %.2f ms" % wall(two(torch.cuda.Stream(), torch.cuda.Stream(priority=-1))), flush=True)
+if os.environ.get("PROBE_NO_MASKS"): sys.exit(0)
 splits = {"xcd 0-3 | 4-7 (bit i -> xcd i % 8)": (lambda i: i % 8 < 4, lambda i: i % 8 >= 4),
           "even | odd xcds": (lambda i: i % 2 == 0, lambda i: i % 2 == 1),
           "low | high half of every xcd (bit i -> cu i // 8)": (lambda i: i // 8 < 16, lambda i: i // 8 >= 16),
