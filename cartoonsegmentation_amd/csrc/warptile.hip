@@ -123,8 +123,10 @@ constexpr int kTotalStride = 32;       // ints between two tiles' global counter
 template <bool SHIFT>
 __global__ __launch_bounds__(kBlock) void k_tile_bin(const float *__restrict__ pts, int64_t N, ProjConst pc, Shift s, TileGeom g, int cap,
                                                       PointMap pm, int *__restrict__ tile_total, Entry *__restrict__ entries,
-                                                      Entry *__restrict__ spill, int *__restrict__ spill_tile, int *__restrict__ spill_count) {
+                                                      Entry *__restrict__ spill, int *__restrict__ spill_tile, int *__restrict__ spill_count,
+                                                      int *__restrict__ hole_total) {
     extern __shared__ int lds_bin[];                  // hist[nt] | base[nt]
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hole_total = 0;   // the previous frame's k_tile_holes is done (stream order); k_tile_render re-fills it
     int *hist = lds_bin, *base = lds_bin + g.nt;
     for (int t = threadIdx.x; t < g.nt; t += kBlock) hist[t] = 0;
     __syncthreads();
@@ -174,8 +176,8 @@ struct FrameOut {
     unsigned short *cbits;   // [W][cpitch] the same map transposed, 16 rows per half-word: read as 32-bit words (x, y/32)
     float *mdepth;           // [P]   render[3] * (existing > 0)   (kenburns_effect.py:1039)
     float *render;           // [4,P] or null
-    unsigned short *holes;   // [nt][TPIX] tile-local pixel ids
-    int *hole_count;         // [nt]
+    unsigned *holes;         // flat list of all holes of the frame, (y << 16) | x, in tile-completion order (capacity H * W)
+    int *hole_count;         // [1] running total: every tile with holes reserves its run with one atomic; re-armed by the next frame
     int *totals;             // [nt] bin counters of k_tile_bin (zeroed here for the next frame)
     int cpitch;              // half-words per column of cbits (nty rounded up to even)
     const Entry *spill;      // entries that did not fit their tile's segment, with their tile ids; *spill_count of them
@@ -212,7 +214,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
     __shared__ float zd[TPIX];
     __shared__ unsigned long long acc[5 * TPIX];
     __shared__ unsigned rowbits[TH];
-    __shared__ int nholes;
+    __shared__ int nholes, hole_base;
+    __shared__ unsigned short hole_px[TPIX];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int tx0 = (t % g.ntx) * TW, ty0 = (t / g.ntx) * TH;
     for (int i = tid; i < ZH * ZW; i += kBlock) zee[i] = 1000000.0f;        // models/utils.py:59
@@ -332,10 +335,20 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
         out.mdepth[o] = m;
         if (out.render) { out.render[o] = r0; out.render[plane + o] = r1; out.render[2 * plane + o] = r2; out.render[3 * plane + o] = r3; }
         out.frame[o * 3 + 0] = to_u8(r0); out.frame[o * 3 + 1] = to_u8(r1); out.frame[o * 3 + 2] = to_u8(r2);
-        if (!okp) out.holes[(int64_t)t * TPIX + atomicAdd(&nholes, 1)] = (unsigned short)i;
+        if (!okp) hole_px[atomicAdd(&nholes, 1)] = (unsigned short)i;
     }
     __syncthreads();
-    if (tid == 0) { out.hole_count[t] = nholes; out.totals[(int64_t)t * kTotalStride] = 0; }           // the bin counter is re-armed for the next frame
+    // the tile's holes join the frame's flat list: one global atomic per tile that has holes (a few hundred per frame, spread over
+    // the kernel) instead of per-tile lists + a 2048-entry prefix scan in every block of k_tile_holes (5.8 of its 16.9 us)
+    if (tid == 0) {
+        hole_base = nholes > 0 ? atomicAdd(out.hole_count, nholes) : 0;
+        out.totals[(int64_t)t * kTotalStride] = 0;                              // the bin counter is re-armed for the next frame
+    }
+    __syncthreads();
+    for (int i = tid; i < nholes; i += kBlock) {
+        const int li = hole_px[i];
+        out.holes[hole_base + i] = ((unsigned)(ty0 + li / TW) << 16) | (unsigned)(tx0 + li % TW);
+    }
     if (tid < TW && tx0 + tid < W) {                                            // 16 x 32 bit transpose: a half-word per column
         unsigned c = 0;
 #pragma unroll
@@ -348,35 +361,15 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
 __constant__ float kDirX[16] = {-1, 0, 1, 1, -1, 1, 2, 2, -2, -1, 1, 2, 3, 3, 3, 3};   // common.py:168
 __constant__ float kDirY[16] = {1, 1, 1, 0, 2, 2, 1, -1, 3, 3, 3, 3, 2, 1, -1, -2};    // common.py:169
 
-// fill_disocclusion (common.py:145-248).  Holes are taken from the per-tile lists through a flat index (every block scans the
-// tile hole counts in LDS and binary-searches its holes): all groups of 32 lanes carry the same load wherever the holes are --
-// the r01 kernel's balance without its global append counter.  32 lanes per hole = 16 directions x {from, to}; every lane marches
+// fill_disocclusion (common.py:145-248).  Holes come from the frame's flat list (k_tile_render appends every tile's holes with one
+// atomic per tile): all groups of 32 lanes carry the same load wherever the holes are.  32 lanes per hole = 16 directions x {from, to}; every lane marches
 // ONE ray through the valid BITMAP (128 KB at 1024^2: cache resident) with 4 speculative steps per round trip; the two axis
 // directions, whose rays run the length of a disoccluded border strip, scan the row / column bitmap a word (32 px) at a time --
 // their steps are exact integers in fp32, so the visited pixels are the same.  A 16-lane lexicographic (distance, direction)
 // minimum then picks the direction exactly like the reference's sequential loop (shortest distance, first direction wins ties).
 __global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g, FrameOut out, int dbg) {
-    extern __shared__ int prefix[];                                              // [nt + 1] exclusive prefix of hole_count
-    __shared__ int wsum[kBlock / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {
-        const int per = (g.nt + kBlock - 1) / kBlock;
-        const int b = tid * per, e = b + per < g.nt ? b + per : g.nt;
-        int sum = 0;
-        for (int i = b; i < e; ++i) sum += out.hole_count[i];
-        int inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int run = inc - sum;
-#pragma unroll
-        for (int w2 = 0; w2 < kBlock / 64; ++w2) run += (w2 < wave) ? wsum[w2] : 0;
-        for (int i = b; i < e; ++i) { prefix[i] = run; run += out.hole_count[i]; }
-        if (tid == kBlock - 1) prefix[g.nt] = run;
-        __syncthreads();
-    }
-    const int total = prefix[g.nt];
+    const int tid = threadIdx.x;
+    const int total = *out.hole_count;                                          // the frame's flat hole list (k_tile_render)
     if (blockIdx.x == 0 && tid == 0) *out.spill_count = 0;                      // every reader (k_tile_render) has finished
     const int lane32 = tid & 31, k = lane32 & 15;
     const bool to = lane32 >= 16;
@@ -387,11 +380,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g,
     const int64_t plane = (int64_t)H * W;
     const int groups = gridDim.x * (kBlock >> 5);
     for (int h = blockIdx.x * (kBlock >> 5) + (tid >> 5); h < total; h += groups) {
-        int lo = 0, hi = g.nt;                                                  // largest t with prefix[t] <= h
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= h) lo = mid; else hi = mid; }
-        const int t = lo;
-        const int li = out.holes[(int64_t)t * TPIX + (h - prefix[t])];
-        const int x = (t % g.ntx) * TW + li % TW, y = (t / g.ntx) * TH + li / TW;
+        const unsigned packed = out.holes[h];
+        const int x = (int)(packed & 0xFFFFu), y = (int)(packed >> 16);
         float fx = (float)x, fy = (float)y;
         int ix = 0, iy = 0;
         bool ok = false, oblique = false;
@@ -497,13 +487,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g,
 }
 
 // scratch layout (bytes, 16-B aligned sections):
-//   header ints : totals[nt * kTotalStride] (one 128-B line per tile; zero between frames) | hole_count[nt] | spill_count (zero between frames)
-//   vbits[H * ntx] (u32) | cbits[W * cpitch] (u16) | mdepth[P] (f32) | holes[nt * TPIX] (u16) | entries[nt * cap] (16 B) |
+//   header ints : totals[nt * kTotalStride] (one 128-B line per tile; zero between frames) | hole total | spill_count (zero between frames)
+//   vbits[H * ntx] (u32) | cbits[W * cpitch] (u16) | mdepth[P] (f32) | holes[P] (u32, flat list) | entries[nt * cap] (16 B) |
 //   spill entries[4 N] (16 B) | spill tiles[4 N] (int)
-struct TileScratch { int *totals, *hole_count, *spill_count; unsigned *vbits; unsigned short *cbits; float *mdepth; unsigned short *holes;
+struct TileScratch { int *totals, *hole_count, *spill_count; unsigned *vbits; unsigned short *cbits; float *mdepth; unsigned *holes;
                      Entry *entries, *spill; int *spill_tile; int cpitch, cap; };
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
-inline size_t header_bytes(int nt) { return align16(sizeof(int) * ((size_t)nt * kTotalStride + nt + 1)); }
+inline size_t header_bytes(int nt) { return align16(sizeof(int) * ((size_t)nt * kTotalStride + 64)); }
 inline size_t bin_blocks(int64_t N) { return (size_t)((N + kPPB - 1) / kPPB); }
 // segment capacity per tile: 2.5x the load of a uniform cloud (N / P points per pixel, x 1.21 for the shared 1-px borders), at
 // least 1024, a multiple of 64.  Monotone in N, so a scratch sized for a larger N serves every smaller one.
@@ -521,7 +511,7 @@ inline Sizes section_sizes(int H, int W, int64_t N) {
     z.vbits = align16(4 * (size_t)H * g.ntx);
     z.cbits = align16(2 * (size_t)W * z.cpitch);
     z.mdepth = align16(4 * (size_t)H * W);
-    z.holes = align16(2 * (size_t)g.nt * TPIX);
+    z.holes = align16(4 * (size_t)H * W);
     z.entries = align16(16 * (size_t)g.nt * z.cap);
     z.spill = align16(16 * 4 * (size_t)N + 16);
     z.spill_tile = align16(4 * 4 * (size_t)N + 16);
@@ -530,12 +520,12 @@ inline Sizes section_sizes(int H, int W, int64_t N) {
 inline TileScratch carve(void *scratch, int H, int W, int nt, int64_t N) {
     const Sizes z = section_sizes(H, W, N);
     TileScratch s; char *p = (char *)scratch;
-    s.totals = (int *)p; s.hole_count = s.totals + (size_t)nt * kTotalStride; s.spill_count = s.hole_count + nt;
+    s.totals = (int *)p; s.hole_count = s.totals + (size_t)nt * kTotalStride; s.spill_count = s.hole_count + 32;   // own 128-B lines
     p += header_bytes(nt);
     s.vbits = (unsigned *)p; p += z.vbits;
     s.cbits = (unsigned short *)p; p += z.cbits;
     s.mdepth = (float *)p; p += z.mdepth;
-    s.holes = (unsigned short *)p; p += z.holes;
+    s.holes = (unsigned *)p; p += z.holes;
     s.entries = (Entry *)p; p += z.entries;
     s.spill = (Entry *)p; p += z.spill;
     s.spill_tile = (int *)p;
@@ -571,13 +561,14 @@ extern "C" int csm_warp_frame_tiled(const float *pts, const float *rgb, const fl
     const TileScratch ts = carve(scratch, H, W, g.nt, N);
     const ProjConst pc = make_proj(H, W, focal, baseline);
     const Shift s{sx, sy, sz};
-    const size_t lds = sizeof(int) * (size_t)(g.nt + 1);
     const unsigned nb = (unsigned)bin_blocks(N);
     int rc;
     if (N > 0) {
         k_tile_bin<true><<<nb, kBlock, 2 * sizeof(int) * (size_t)g.nt, st>>>(pts, N, pc, s, g, ts.cap, make_point_map(H, W, N), ts.totals,
-                                                                              ts.entries, ts.spill, ts.spill_tile, ts.spill_count);
+                                                                              ts.entries, ts.spill, ts.spill_tile, ts.spill_count, ts.hole_count);
         rc = csm::check_launch("k_tile_bin"); if (rc) return rc;
+    } else {
+        CSM_HIP(hipMemsetAsync(ts.hole_count, 0, sizeof(int), st));
     }
     FrameOut out{frame_u8, ts.vbits, ts.cbits, ts.mdepth, render_filled, ts.holes, ts.hole_count, ts.totals, ts.cpitch,
                  ts.spill, ts.spill_tile, ts.spill_count};
@@ -588,7 +579,7 @@ extern "C" int csm_warp_frame_tiled(const float *pts, const float *rgb, const fl
     if (!(g_tile_dbg & 32)) {
         static int hb = 0;
         if (!hb) { const char *e = getenv("CSM_TILE_HOLE_BLOCKS"); hb = e ? atoi(e) : 1024; if (hb < 1) hb = 1024; }
-        k_tile_holes<<<hb, kBlock, lds, st>>>(H, W, g, out, g_tile_dbg);
+        k_tile_holes<<<hb, kBlock, 0, st>>>(H, W, g, out, g_tile_dbg);
         rc = csm::check_launch("k_tile_holes"); if (rc) return rc;
     }
     return CSM_OK;
