@@ -54,7 +54,11 @@ struct Entry { float fx, fy, err; int idx; };        // 16 B
 // it reserves a run in the tile's segment with ONE global atomic (blocks x ~6 tiles, spread over all counters) and remembers
 // the run's start in blockbase[block][tile].  After the scan the scatter pass seeds LDS cursors from tile_off + blockbase and
 // hands out slots with LDS atomics.
-constexpr int kPPT = 4, kPPB = kBlock * kPPT;         // points per thread / per block
+#ifndef KPPT
+#define KPPT 2       // measured at 1024^2 (whole chain): 1 -> 57.9 us, 2 -> 57.6, 4 -> 61.1, 8 -> 68.1 (more, shorter latency chains)
+#endif
+constexpr int kPPT = KPPT, kPPB = kBlock * kPPT;      // points per thread / per block
+constexpr int kPatchH = kPPB / 32;                    // a block's patch of the source grid: 32 columns x kPatchH rows
 
 struct PointBins { float fx, fy, err; int txl, txh, tyl, tyh; bool ok; };
 
@@ -90,23 +94,23 @@ __device__ __forceinline__ PointBins bins_of_point(const float *__restrict__ pts
 // Capacity is ~2.5x the expected load (tile_cap below).  Entries beyond it go to a global spill list that every render block
 // filters by tile id: exact for any input, slow only for pathological clouds (thousands of points in one 32 x 16 tile).
 // Which point does (block, slot q of kPPB) handle?  The cloud's first H * W points are the frame's own pixels in row-major order
-// (kenburns_effect.py:928-933; inpainting appends the rest), so when W is a multiple of 32 a block takes a 32 x 32 PATCH of that
-// grid instead of 1024 consecutive points: its footprints then fall into ~4 tiles instead of ~40 (fewer, longer runs per tile and
+// (kenburns_effect.py:928-933; inpainting appends the rest), so when W is a multiple of 32 a block takes a 32-column x kPatchH-row PATCH
+// of that grid instead of kPPB consecutive points: its footprints then fall into ~4 tiles instead of ~20-40 (fewer, longer runs per tile and
 // 8x fewer global reservations; measured 16.9 -> 15.4 us for the bin pass, 36.2 -> 35.3 us for the render pass).  Purely a locality choice: any cloud gives the same frame under either mapping.
 struct PointMap { int64_t patched; int patches_x, W; };   // points below `patched` are visited patch-wise
 __host__ __device__ inline PointMap make_point_map(int H, int W, int64_t N) {
     PointMap m; m.W = W; m.patches_x = W / 32; m.patched = 0;
     if (W % 32 == 0 && W >= 32) {
         const int64_t grid = N < (int64_t)H * W ? N : (int64_t)H * W;
-        m.patched = grid / (32 * (int64_t)W) * (32 * (int64_t)W);           // whole 32-row bands
+        m.patched = grid / (kPatchH * (int64_t)W) * (kPatchH * (int64_t)W);   // whole kPatchH-row bands
     }
     return m;
 }
 __device__ __forceinline__ int64_t point_of(const PointMap &m, int64_t block, int q) {
     const int64_t lin = block * kPPB + q;
-    if (lin >= m.patched - (m.patched % kPPB)) return lin;                   // (patched is a multiple of 32 W = patches_x * kPPB)
+    if (lin >= m.patched) return lin;                                         // (patched is a multiple of kPatchH W = patches_x * kPPB)
     const int64_t band = block / m.patches_x; const int px = (int)(block - band * m.patches_x);
-    return (band * 32 + (q >> 5)) * m.W + px * 32 + (q & 31);
+    return (band * kPatchH + (q >> 5)) * m.W + px * 32 + (q & 31);
 }
 
 constexpr int kTotalStride = 32;       // ints between two tiles' global counters: one 128-B line each (same-line atomics serialise)
