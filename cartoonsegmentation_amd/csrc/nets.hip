@@ -87,6 +87,16 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember which devices a kernel has been prepared on
+static inline bool first_use_on_device(unsigned &mask) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned bit = 1u << (d & 31);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
+
 struct View {           // NHWC view
     float *p;
     int n, h, w, c, ld;
@@ -103,6 +113,7 @@ struct ConvArgs {
     int m_tiles;
     int ksplit;                        // >1: blockIdx.z = g*ksplit + s, raw partial sums go to `partial`
     float *partial;                    // [M][ksplit*cout] (groups == 1 only)
+    int serial;                        // ksplit > 1 only: 1 = one block walks all runs and combines them in registers (SER kernels)
     int dbg;                           // tuning aid: 1 = no global loads, 2 = no MFMA, 4 = no LDS stores, 8 = no epilogue stores
 };
 
@@ -138,7 +149,12 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #else
 #define CSM_DBG(a) 0
 #endif
-template <int MT, int WM, int WN, int TN, bool FULLK>
+// SER (split-K executed serially): csm_op.ksplit = S cuts K into S runs of chunks, each its own fmaf chain, summed ((p0+p1)+p2)...
+// -- that is part of the NUMERICAL contract and follows the per-sample shape only.  How the runs are EXECUTED is a speed decision:
+// S blocks along grid z writing raw partials + k_splitk_reduce (small grids: batch 1), or -- SER -- one block that walks all S
+// runs and combines them in registers at the run boundaries (`tot = tot + acc; acc = 0`: the same fp32 additions in the same
+// order), so a batched program produces the bits of the single-frame program without the partial-sum traffic.
+template <int MT, int WM, int WN, int TN, bool FULLK, bool SER = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_mfma(ConvArgs a) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = MT * WM, BN = MT * WN * TN;
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
     int mt, ntile, zz;
     block_to_tile(mt, ntile, zz);
     const int m0 = mt * BM, n0 = ntile * BN;
-    const int g = zz / a.ksplit, ks = zz - g * a.ksplit;
+    const int g = SER ? zz : zz / a.ksplit, ks = SER ? 0 : zz - g * a.ksplit;
     const int ho = a.out.h, wo = a.out.w;
     const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
 
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
         vmask[it] = vm;
     }
     const int Tall = a.kh * a.kw * a.ncb;
-    const int c_begin = (int)(((int64_t)ks * Tall) / a.ksplit), T = (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
+    const int c_begin = SER ? 0 : (int)(((int64_t)ks * Tall) / a.ksplit), T = SER ? Tall : (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
     // loader state = the NEXT chunk to fetch (block-uniform -> SGPRs).  Chunk order = the chain order: 32-channel block outer,
     // taps row-major inner (so that a 3x3 kernel can keep one block's input patch in LDS for all its taps, k_conv_patch).
     const int ntaps = a.kh * a.kw;
@@ -294,7 +310,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
     };
 
     int cb = c_begin / ntaps, ctap = c_begin - cb * ntaps;      // position of the chunk being multiplied
+    float tot[SER ? TN : 1][SER ? NACC : 1];
+    int run = 0, next_b = SER ? (int)((int64_t)Tall / a.ksplit) : 0;          // SER: first chunk of the next run
     auto compute = [&](int chunk) {
+        if constexpr (SER) {
+            if (chunk == next_b) {                                             // block-uniform: S - 1 times per block
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < NACC; ++r) { tot[tn][r] = run == 0 ? acc[tn][r] : tot[tn][r] + acc[tn][r]; acc[tn][r] = 0.0f; }
+                ++run; next_b = (int)(((int64_t)(run + 1) * Tall) / a.ksplit);
+            }
+        }
         const int buf = chunk & 1;
         const float *A = lds + buf * kStage + (MT * wm + li) * kLdsLd + (MT == 32 ? 4 : 2) * lh;
         const float *B = lds + buf * kStage + (BM + MT * TN * wn + li) * kLdsLd + (MT == 32 ? 4 : 2) * lh;
@@ -339,8 +366,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
             int m = m0 + MT * wm + row;
             if (m >= a.M) continue;
             float v = acc[tn][r];
+            if constexpr (SER) v = tot[tn][r] + v;
             if (CSM_DBG(a) & 8) { if (v == 123.456f) a.out.p[0] = v; continue; }
-            if (a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
+            if (!SER && a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
             if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
             v = apply_act(v, a.act, slope);
             if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
@@ -371,8 +399,9 @@ __device__ __forceinline__ void dma16(unsigned voff, i32x4 rsrc, unsigned lds_by
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_byte_addr) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int NS>
+template <int WM, int WN, int TM, int TN, int NS, bool SER = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
+    static_assert(!SER || NS == 2, "the serial split-K walk is built for the two-stage pipeline");
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;          // DMA pieces (8 rows) per wave per chunk
@@ -388,11 +417,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     int mt, ntile, zz;
     block_to_tile(mt, ntile, zz);
     const int m0 = mt * BM, n0 = ntile * BN;
-    const int g = zz / a.ksplit, ks = zz - g * a.ksplit;
+    const int g = SER ? zz : zz / a.ksplit, ks = SER ? 0 : zz - g * a.ksplit;
     const int ho = a.out.h, wo = a.out.w;
     const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
     const int Tall = a.kh * a.kw * a.ncb;
-    const int c_begin = (int)(((int64_t)ks * Tall) / a.ksplit), T = (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
+    const int c_begin = SER ? 0 : (int)(((int64_t)ks * Tall) / a.ksplit), T = SER ? Tall : (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
 
     // buffer descriptors (raw, range-checked): activations view and this op's packed weights
     i32x4 ra, rb;
@@ -477,7 +506,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) sw[kb] = ((2 * kb + lh) ^ ((li >> 1) & 7)) * 4;
     const int rowA = (32 * TM * wm + li) * 32, rowB = (BM + 32 * TN * wn + li) * 32;
-    auto compute = [&](int stage) {
+    f32x16 tot[SER ? TM : 1][SER ? TN : 1];
+    int run = 0, next_b = SER ? (int)((int64_t)Tall / a.ksplit) : 0;          // SER: first chunk of the next run
+    auto compute = [&](int stage, int chunk) {
+        if constexpr (SER) {
+            if (chunk == next_b) {                                             // block-uniform: S - 1 times per block
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { tot[i][j][r] = run == 0 ? acc[i][j][r] : tot[i][j][r] + acc[i][j][r]; acc[i][j][r] = 0.0f; }
+                ++run; next_b = (int)(((int64_t)(run + 1) * Tall) / a.ksplit);
+            }
+        }
         const float *S = lds + stage * kStageF;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -522,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
             __builtin_amdgcn_s_barrier();                          // ... everybody's have, and everybody is done reading stage st^1
 #endif
             if (chunk + 1 < T) issue(st ^ 1);
-            compute(st);
+            compute(st, chunk);
         }
     } else {
         // NS stages: the loads of chunk + NS - 1 are issued while chunk is consumed, so a load may take NS - 1 chunk times
@@ -535,7 +577,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // everybody is done reading the stage refilled next
             if (chunk + NS - 1 < T) issue(st == 0 ? NS - 1 : st - 1);
-            compute(st);
+            compute(st, chunk);
         }
     }
 
@@ -555,7 +597,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 #endif
                 if (m >= a.M) continue;
                 float v = acc[i][j][r];
-                if (a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
+                if constexpr (SER) v = tot[i][j][r] + v;
+                if (!SER && a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
                 if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
                 v = apply_act(v, a.act, slope);
                 if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
@@ -573,7 +616,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 // (the chain order is block-major for exactly this reason): the A fragment of output pixel (y, x) under tap (kh, kw) is patch
 // pixel (y+kh, x+kw).  Patch: 2 stages (the next block's patch is fetched during the first tap of the current one); weights:
 // 2 stages, one tile per tap.  Same 128-B rows / XOR swizzle / buffer-range-check zero fill / raw barrier as k_conv_dma.
-template <int WM, int WN, int TM, int TN, int TW>
+template <int WM, int WN, int TM, int TN, int TW, bool SER = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int tiles_x, int tiles_y) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
@@ -593,11 +636,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
     block_to_tile(mt, ntile, zz);
     const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, n = mt / (tiles_x * tiles_y);
     const int n0 = ntile * BN;
-    const int g = zz / a.ksplit, ks = zz - g * a.ksplit;
+    const int g = SER ? zz : zz / a.ksplit, ks = SER ? 0 : zz - g * a.ksplit;
     const int ho = a.out.h, wo = a.out.w;
     const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
     const int Tall = 9 * a.ncb;
-    const int c_begin = (int)(((int64_t)ks * Tall) / a.ksplit), T = (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
+    const int c_begin = SER ? 0 : (int)(((int64_t)ks * Tall) / a.ksplit), T = SER ? Tall : (int)(((int64_t)(ks + 1) * Tall) / a.ksplit);
 
     i32x4 ra, rb;
     {
@@ -666,7 +709,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) swb[kb] = ((2 * kb + lh) ^ ((li >> 1) & 7)) * 4;
     const int rowB = (32 * TN * wn + li) * 32;
+    f32x16 tot[SER ? TM : 1][SER ? TN : 1];
+    int run = 0, next_b = SER ? (int)((int64_t)Tall / a.ksplit) : 0;          // SER: first chunk of the next run
     auto compute = [&](int cb, int tap, int bstage) {
+        if constexpr (SER) {
+            if (9 * cb + tap == next_b) {                                      // block-uniform: S - 1 times per block
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { tot[i][j][r] = run == 0 ? acc[i][j][r] : tot[i][j][r] + acc[i][j][r]; acc[i][j][r] = 0.0f; }
+                ++run; next_b = (int)(((int64_t)(run + 1) * Tall) / a.ksplit);
+            }
+        }
         const float *SP = lds + (cb & 1) * kPatchF;
         const float *SB = lds + 2 * kPatchF + bstage * kBF;
         const int kh = tap / 3, toff = kh * PW + (tap - 3 * kh);
@@ -736,7 +792,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
                 const int nn = ncol[j];
                 if (nn >= a.cout_g) continue;
                 float v = acc[i][j][r];
-                if (a.ksplit > 1) { a.partial[(m * a.ksplit + ks) * a.cout_g + nn] = v; continue; }
+                if constexpr (SER) v = tot[i][j][r] + v;
+                if (!SER && a.ksplit > 1) { a.partial[(m * a.ksplit + ks) * a.cout_g + nn] = v; continue; }
                 if (a.res_mode == 1) v += a.res.p[m * a.res.ld + cout_off + nn];
                 v = apply_act(v, a.act, slope[j]);
                 if (a.res_mode == 2) v += a.res.p[m * a.res.ld + cout_off + nn];
@@ -935,11 +992,9 @@ static size_t narrow_lds(const ConvArgs &a, int TH, int *rh_out, int *rw_out) {
 
 template <int NOUT, int TH>
 static int launch_narrow_t(const ConvArgs &a, size_t lds, int rh, int rw, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned prepared = 0;
+    if (first_use_on_device(prepared))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_narrow<NOUT, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
     int tiles_x = (a.out.w + 31) / 32, tiles_y = (a.out.h + TH - 1) / TH;
     k_conv_narrow<NOUT, TH><<<(unsigned)(tiles_x * tiles_y * a.out.n), 32 * TH, lds, st>>>(a, tiles_x, tiles_y, rh, rw);
     return csm::check_launch("k_conv_narrow");
@@ -1320,72 +1375,82 @@ __global__ __launch_bounds__(256) void k_nhwc_to_nchw_tile(View in, float *__res
     }
 }
 
-template <int MT, int WM, int WN, int TN, bool FULLK>
+static int launch_reduce(const ConvArgs &a, hipStream_t st) {
+    k_splitk_reduce<<<(unsigned)(((int64_t)a.M * a.cout_g + 255) / 256), 256, 0, st>>>(a);
+    return csm::check_launch("k_splitk_reduce");
+}
+
+template <int MT, int WM, int WN, int TN, bool FULLK, bool SER>
 int launch_conv_k(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = MT * WM, BN = MT * WN * TN;
     ConvArgs a = a0;
     a.m_tiles = (a.M + BM - 1) / BM;
     size_t lds = (size_t)2 * (BM + BN) * kLdsLd * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_mfma<MT, WM, WN, TN, FULLK>),
+    static unsigned prepared = 0;
+    if (first_use_on_device(prepared))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_mfma<MT, WM, WN, TN, FULLK, SER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * a.ksplit);
-    k_conv_mfma<MT, WM, WN, TN, FULLK><<<grid, 64 * WM * WN, lds, st>>>(a);
+    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * (SER ? 1 : a.ksplit));
+    k_conv_mfma<MT, WM, WN, TN, FULLK, SER><<<grid, 64 * WM * WN, lds, st>>>(a);
     int rc = csm::check_launch("k_conv_mfma");
-    if (rc || a.ksplit <= 1) return rc;
-    k_splitk_reduce<<<(unsigned)(((int64_t)a.M * a.cout_g + 255) / 256), 256, 0, st>>>(a);
-    return csm::check_launch("k_splitk_reduce");
+    if (rc || SER || a.ksplit <= 1) return rc;
+    return launch_reduce(a, st);
 }
 
 template <int MT, int WM, int WN, int TN>
 int launch_conv(const ConvArgs &a, hipStream_t st) {
-    return (a.cin_g & 31) == 0 ? launch_conv_k<MT, WM, WN, TN, true>(a, st) : launch_conv_k<MT, WM, WN, TN, false>(a, st);
+    const bool full = (a.cin_g & 31) == 0;
+    if (a.ksplit > 1 && a.serial) return full ? launch_conv_k<MT, WM, WN, TN, true, true>(a, st) : launch_conv_k<MT, WM, WN, TN, false, true>(a, st);
+    return full ? launch_conv_k<MT, WM, WN, TN, true, false>(a, st) : launch_conv_k<MT, WM, WN, TN, false, false>(a, st);
 }
 
-
-template <int WM, int WN, int TM, int TN, int NS = 2>
-int launch_conv_dma(const ConvArgs &a0, hipStream_t st) {
+template <int WM, int WN, int TM, int TN, int NS, bool SER>
+int launch_conv_dma_t(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgs a = a0;
     a.m_tiles = (a.M + BM - 1) / BM;
     size_t lds = (size_t)NS * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma<WM, WN, TM, TN, NS>),
+    static unsigned prepared = 0;
+    if (first_use_on_device(prepared))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma<WM, WN, TM, TN, NS, SER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * a.ksplit);
-    k_conv_dma<WM, WN, TM, TN, NS><<<grid, 64 * WM * WN, lds, st>>>(a);
+    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * (SER ? 1 : a.ksplit));
+    k_conv_dma<WM, WN, TM, TN, NS, SER><<<grid, 64 * WM * WN, lds, st>>>(a);
     int rc = csm::check_launch("k_conv_dma");
-    if (rc || a.ksplit <= 1) return rc;
-    k_splitk_reduce<<<(unsigned)(((int64_t)a.M * a.cout_g + 255) / 256), 256, 0, st>>>(a);
-    return csm::check_launch("k_splitk_reduce");
+    if (rc || SER || a.ksplit <= 1) return rc;
+    return launch_reduce(a, st);
 }
 
-template <int WM, int WN, int TM, int TN, int TW>
-int launch_conv_patch(const ConvArgs &a0, hipStream_t st) {
+template <int WM, int WN, int TM, int TN, int NS = 2>
+int launch_conv_dma(const ConvArgs &a, hipStream_t st) {
+    if constexpr (NS == 2)
+        if (a.ksplit > 1 && a.serial) return launch_conv_dma_t<WM, WN, TM, TN, 2, true>(a, st);
+    return launch_conv_dma_t<WM, WN, TM, TN, NS, false>(a, st);
+}
+
+template <int WM, int WN, int TM, int TN, int TW, bool SER>
+int launch_conv_patch_t(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
     constexpr int NW = WM * WN, NPP = ((((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW) * NW;   // pieces, padded to the wave count
     ConvArgs a = a0;
     const int tiles_x = (a.out.w + TW - 1) / TW, tiles_y = (a.out.h + TH - 1) / TH;
     a.m_tiles = tiles_x * tiles_y * a.out.n;
     size_t lds = ((size_t)2 * NPP * 8 * 32 + (size_t)2 * BN * 32) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch<WM, WN, TM, TN, TW>),
+    static unsigned prepared = 0;
+    if (first_use_on_device(prepared))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch<WM, WN, TM, TN, TW, SER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * a.ksplit);
-    k_conv_patch<WM, WN, TM, TN, TW><<<grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y);
+    dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * (SER ? 1 : a.ksplit));
+    k_conv_patch<WM, WN, TM, TN, TW, SER><<<grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y);
     int rc = csm::check_launch("k_conv_patch");
-    if (rc || a.ksplit <= 1) return rc;
-    k_splitk_reduce<<<(unsigned)(((int64_t)a.M * a.cout_g + 255) / 256), 256, 0, st>>>(a);
-    return csm::check_launch("k_splitk_reduce");
+    if (rc || SER || a.ksplit <= 1) return rc;
+    return launch_reduce(a, st);
+}
+
+template <int WM, int WN, int TM, int TN, int TW>
+int launch_conv_patch(const ConvArgs &a, hipStream_t st) {
+    if (a.ksplit > 1 && a.serial) return launch_conv_patch_t<WM, WN, TM, TN, TW, true>(a, st);
+    return launch_conv_patch_t<WM, WN, TM, TN, TW, false>(a, st);
 }
 
 static bool narrow_eligible(const ConvArgs &a) {
@@ -1421,7 +1486,9 @@ enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CF
        CFG_D256x128_8w_s3 = 33, CFG_D256x64 = 34, CFG_D256x64_s3 = 35, CFG_P256x64 = 36, CFG_D64x64_s4 = 37,
        CFG_COUNT = 38 };
 static int g_force_cfg = -1;
+static int g_force_serial = -1;    // tests: -1 = rule / tuned, 0 = parallel split-K, 1 = serial split-K
 static int g_dbg = 0;
+constexpr int kTileSerial = 64;
 
 static void read_force_env() {
     static bool env_read = false;
@@ -1539,7 +1606,13 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                     if (rc) return rc;
                     break;
                 }
-                int cfg = (op.tile > 0 && op.tile <= CFG_COUNT && g_force_cfg < 0) ? op.tile - 1 : choose_cfg(a, op.cout_g);
+                // csm_op.tile = 1 + configuration (+ kTileSerial: split-K runs walked by one block).  Untuned ops: serial once the
+                // batch supplies enough output tiles by itself (speed only: both executions give the same bits)
+                const int tcfg = op.tile & (kTileSerial - 1);
+                const bool tuned = tcfg > 0 && tcfg <= CFG_COUNT && g_force_cfg < 0;
+                a.serial = a.ksplit > 1 && (g_force_serial >= 0 ? g_force_serial != 0 : tuned ? (op.tile & kTileSerial) != 0
+                                            : (int64_t)((a.M + 63) / 64) * ((op.cout_g + 63) / 64) >= 512);
+                int cfg = tuned ? tcfg - 1 : choose_cfg(a, op.cout_g);
                 if (((cfg >= CFG_P64x64 && cfg <= CFG_P128x128_8w) || cfg == CFG_P256x64) && !patch_eligible(a)) cfg = CFG_D64x64;
                 if (cfg == CFG_NARROW && !narrow_eligible(a)) cfg = CFG_64x16;
                 if (cfg >= CFG_D64x64 && cfg != CFG_NARROW && !dma_eligible(a)) cfg = op.cout_g <= 16 ? CFG_64x16 : (op.cout_g <= 32 ? CFG_128x32 : CFG_64x64);
@@ -1732,11 +1805,14 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
             if (cand_bn[c] == 4 && (op.cout_g > 4 || op.groups != 1 || op.ksplit > 1)) continue;
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
             if (cand_bn[c] == 32 && op.cout_g > 64 && (op.cout_g % 64) != 32) continue;   // (96, 160 ... outputs: 32-wide tiles waste no MFMA columns)
-            op.tile = cand_all[c] + 1;
-            float tmin;
-            rc = time_tile(reps, tmin);
+            for (int ser = 0; ser <= (op.ksplit > 1 ? 1 : 0) && rc == CSM_OK; ++ser) {     // split-K layers: both executions
+                op.tile = cand_all[c] + 1 + (ser ? kTileSerial : 0);
+                float tmin;
+                rc = time_tile(reps, tmin);
+                if (rc) break;
+                timed.emplace_back(tmin, op.tile - 1);
+            }
             if (rc) break;
-            timed.emplace_back(tmin, cand_all[c]);
         }
         if (rc) break;
         // the three fastest are within a few percent of each other on many layers and one sample of three is noisy: time them again
@@ -1784,7 +1860,7 @@ extern "C" int csm_conv_tile_cache_load(const char *path) {
         std::array<int, 16> key; int tile = 0; bool ok = true;
         for (int &v : key) ok = ok && fscanf(f, "%d", &v) == 1;
         if (!ok || fscanf(f, "%d", &tile) != 1) break;
-        if (tile >= 0 && tile <= CFG_COUNT) { std::lock_guard<std::mutex> lk(g_tile_mutex); g_tile_cache[key] = tile; ++n; }
+        if (tile >= 0 && (tile & (kTileSerial - 1)) <= CFG_COUNT && tile < 2 * kTileSerial) { std::lock_guard<std::mutex> lk(g_tile_mutex); g_tile_cache[key] = tile; ++n; }
     }
     fclose(f);
     return n;
@@ -1794,5 +1870,11 @@ extern "C" int csm_conv_tile_cache_load(const char *path) {
 // (ConvArgs::dbg).  Not part of the stable ABI.
 extern "C" int csm_debug_force_conv_cfg(int cfg) {
     if (cfg >= 0) { g_force_cfg = cfg & 0xff; g_dbg = cfg >> 8; } else { g_force_cfg = -1; g_dbg = 0; }
+    return CSM_OK;
+}
+
+// tests: force how split-K layers are executed (-1 = tuned / rule, 0 = S blocks + reduce kernel, 1 = one block walks the runs)
+extern "C" int csm_debug_force_splitk_serial(int mode) {
+    g_force_serial = mode < 0 ? -1 : (mode ? 1 : 0);
     return CSM_OK;
 }

@@ -74,9 +74,10 @@ class _B:
         """folded (w, b) of an mmcv ConvModule conv(bias=False) + BN; wname / bnname: parameter-name aliases (shared modules)"""
         return conv_bn(_Alias(self.ws, name, wname, bnname), name + '.conv', name + '.bn', cout, cin, k, eps=self.eps(name))
 
-    def cm(self, name, x, cout, k, stride=1, act='silu', out=None, res=None, res_mode=0, wname=None, bnname=None, params=None):
-        """mmcv ConvModule: conv(bias=False) + BN + act"""
-        w, b = params if params is not None else self.cm_params(name, x.c, cout, k, wname, bnname)
+    def cm(self, name, x, cout, k, stride=1, act='silu', out=None, res=None, res_mode=0, wname=None, bnname=None, params=None, cin=None):
+        """mmcv ConvModule: conv(bias=False) + BN + act.  cin: the checkpoint's input-channel count when the NHWC tensor carries zero
+        padding channels (the 3-channel image sits in a 4-channel buffer; Program.conv pads the weights to match)"""
+        w, b = params if params is not None else self.cm_params(name, x.c if cin is None else cin, cout, k, wname, bnname)
         return self.p.conv(x, w, b, stride=stride, pad=k // 2, act=act, out=out, res=res, res_mode=res_mode)
 
     def dwcm(self, name, x, k, act='silu'):
@@ -159,7 +160,7 @@ def build_rtmdet(ws, n, h, w, cfg=None):
     oc = cfg.feat_channels
     MF = p.buffer(n, h // 8, w // 8, 3 * oc)                    # MaskFeatModule fusion input
 
-    t = B.cm('backbone.stem.0', x, arch[0][0] // 2, 3, stride=2)
+    t = B.cm('backbone.stem.0', x, arch[0][0] // 2, 3, stride=2, cin=3)
     t = B.cm('backbone.stem.1', t, arch[0][0] // 2, 3)
     t = B.cm('backbone.stem.2', t, arch[0][0], 3)
     outs_to = {1: TD0.slice(c3, 2 * c3), 2: TD1.slice(c4, 2 * c4)}

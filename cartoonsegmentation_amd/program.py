@@ -66,8 +66,9 @@ def pack_conv_weights(w, groups):
     return np.ascontiguousarray(packed).reshape(-1), sg, cin_sg, cout_sg
 
 
-# split-K rule (part of the numerical contract of a lowered program): below KSPLIT_BELOW 64x64 output tiles, cut K so that about
-# KSPLIT_TARGET blocks exist
+# split-K rule (part of the numerical contract of a lowered program): below KSPLIT_BELOW 64x64 output tiles PER SAMPLE, cut K so that
+# about KSPLIT_TARGET blocks exist at batch 1.  The rule sees one sample's shape only, so a sample's bits do not depend on the batch it
+# runs in; whether the runs become separate blocks or are walked by one block is decided on the device (csm_op.tile, speed only).
 KSPLIT_BELOW = int(os.environ.get('CSM_KSPLIT_BELOW', '512'))
 KSPLIT_TARGET = int(os.environ.get('CSM_KSPLIT_TARGET', '768'))
 
@@ -213,7 +214,7 @@ class Program:
             a_h, a_n = self._w(slope, slope)
         self.flops += 2 * x.n * ho * wo * cout * cin_g * kh * kw
         self.conv_bytes += 4 * (x.n * x.h * x.w * x.c + x.n * ho * wo * cout + w.size)
-        ksplit, scr = (1 if stem else self.choose_ksplit(x.n * ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups)), None
+        ksplit, scr = (1 if stem else self.choose_ksplit(ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups)), None
         if ksplit > 1:
             scr = self.buffer(x.n, ho, wo, ksplit * cout)
         return self._emit(OP_CONV, x, res, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, groups=sg, cin_g=cin_sg,
@@ -224,7 +225,8 @@ class Program:
     split_k = True
 
     def choose_ksplit(self, M, N, T, groups):
-        """small feature maps: not enough 64x64 output tiles to fill 256 CUs -> cut K (part of the numerical contract)"""
+        """small feature maps (M = output pixels of ONE sample): not enough 64x64 output tiles to fill 256 CUs -> cut K
+        (part of the numerical contract, hence independent of the batch size)"""
         if not self.split_k or groups != 1 or N <= 4:      # N <= 4: k_conv_narrow, one output pixel per lane, needs no split
             return 1
         tiles = ((M + 63) // 64) * ((N + 63) // 64)

@@ -152,7 +152,9 @@ int csm_autozoom_coverage_bands(const float *pts, int64_t N, int H, int W, doubl
  * aligned sub-block of 8 channels, channel order 0,4,1,5,2,6,3,7 (the v_mfma_f32_32x32x2_f32 lane order):
  * acc = fmaf(x, w, acc)
  * -- or `ksplit` such chains over consecutive K runs, summed in order (see csm_op.ksplit; the host picks
- * ksplit > 1 for small feature maps so that all 256 CUs get work).
+ * ksplit > 1 for small feature maps so that all 256 CUs get work at batch 1).  ksplit follows the PER-SAMPLE shape only, so
+ * a batch-n program computes, for every sample, the bits of the batch-1 program.  How the runs are executed (S blocks +
+ * a reduce kernel, or one block that walks the runs and adds them in registers) is a speed choice with identical results.
  * Epilogue order: (+residual if res_mode==1) -> activation -> (+residual if res_mode==2).
  * SiLU/sigmoid use the polynomial expf documented in DESIGN.md.
  * ---------------------------------------------------------------------------------- */
@@ -203,8 +205,9 @@ typedef struct csm_op {
                                 [s*T/ksplit, (s+1)*T/ksplit); each run is its own fmaf chain (run 0 starts at the bias,
                                 the others at 0) and the runs are added in order ((p0+p1)+p2)...  1 = single chain */
     int32_t scratch;         /* tensor id of the [n,h,w,ksplit*cout] partial-sum buffer when ksplit > 1, else -1 */
-    int32_t tile;            /* CONV: 0 = built-in tile rule, k > 0 = tile configuration k-1 (speed only: every configuration
-                                produces the same bits); filled in by csm_conv_autotune */
+    int32_t tile;            /* CONV: 0 = built-in tile rule; low 6 bits k > 0 = tile configuration k-1, bit 6 (64) = split-K runs
+                                walked serially by one block instead of ksplit blocks + reduce (speed only: every configuration
+                                and both split-K executions produce the same bits); filled in by csm_conv_autotune */
 } csm_op;
 
 /* Measure every eligible tile configuration of every CONV op on the device (HIP events on `stream`, `reps` timed launches
@@ -224,6 +227,8 @@ int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
                     const float *weights, float *workspace, void *const *ext, int n_ext, void *stream);
 /* Tuning aid (not stable ABI): force the conv tile configuration index, -1 = built-in cost model. */
 int csm_debug_force_conv_cfg(int cfg);
+/* Test aid (not stable ABI): how ksplit > 1 layers are executed: -1 = tuned / built-in rule, 0 = parallel, 1 = serial. */
+int csm_debug_force_splitk_serial(int mode);
 /* Measurement aid: same execution, each op bracketed by HIP events on `stream`; synchronises and returns ms per op. */
 int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
                             const float *weights, float *workspace, void *const *ext, int n_ext, void *stream,

@@ -132,6 +132,19 @@ def warp_frame(pts, rgbd, H, W, focal, baseline, shift, degrid_mode=1):
     return filled, existing, frame
 
 
+def warp_frame_mt(pts, rgbd, H, W, focal, baseline, shift):
+    """all-cores OpenMP variant of warp_frame (atomics, unspecified accumulation order): bench.py's timed CPU baseline only"""
+    pts, rgbd = _f(pts), _f(rgbd)
+    N = pts.shape[2]
+    s = np.asarray(shift, _F)
+    filled = np.empty((1, 4, H, W), _F); existing = np.empty((1, 1, H, W), _F)
+    frame = np.empty((H, W, 3), np.uint8)
+    lib().orc_warp_frame_mt(ctypes.c_int64(N), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_double(focal),
+                            ctypes.c_double(baseline), ctypes.c_float(s[0]), ctypes.c_float(s[1]), ctypes.c_float(s[2]),
+                            _p(pts), _p(rgbd), _p(filled), _p(existing), _p(frame))
+    return filled, existing, frame
+
+
 def shift_vector(settings, common):
     """host scalar part of process_shift (common.py:60-72), python floats like the reference"""
     cd = common['objDepthrange'][0] + (settings['fltDepthTo'] - settings['fltDepthFrom'])

@@ -94,6 +94,8 @@ void orc_pointrender_update_zee(int B, int64_t N, int H, int W, double focal,
  * mode 0: in-place, raster order (ONE legal interleaving of the racy reference)
  * mode 1: Jacobi -- all reads from a snapshot taken before the pass.  This is
  *         the deterministic semantics the HIP build adopts. */
+static int orc_mt = 0;     /* set only inside orc_warp_frame_mt (the timed all-cores baseline); 0 = the sequential checker */
+
 void orc_pointrender_degrid(int B, int H, int W, float *zee, int mode)
 {
     static const int ox[4] = {1, 0, 1, 1}, oy[4] = {0, 1, 1, -1};   /* :170-171 */
@@ -101,6 +103,7 @@ void orc_pointrender_degrid(int B, int H, int W, float *zee, int mode)
     float *src = zee;
     if (mode == 1) { src = (float *)malloc(n * sizeof(float)); memcpy(src, zee, n * sizeof(float)); }
     for (int b = 0; b < B; ++b)
+#pragma omp parallel for schedule(static) if (orc_mt && mode == 1)
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
                 const float *Z = src + (int64_t)b * H * W;
@@ -195,6 +198,7 @@ void orc_fill_disocclusion(int B, int C, int H, int W, const float *in, const fl
     int64_t P = (int64_t)H * W;
     for (int b = 0; b < B; ++b) {
         const float *D = depth + (int64_t)b * P;
+#pragma omp parallel for schedule(dynamic, 8) if (orc_mt)
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
                 if ((double)D[(int64_t)y * W + x] > 0.0) continue;                       /* :160 */
@@ -368,4 +372,90 @@ void orc_warp_frame(int64_t N, int H, int W, double focal, double baseline, floa
     orc_fill_disocclusion(1, 4, H, W, rnd, dm, render_filled);
     orc_frame_to_u8(4, H, W, render_filled, frame);
     free(sp); free(rnd); free(dm);
+}
+
+
+/* ---- all-cores variant of orc_warp_frame: TIMING ONLY (bench.py cpu_baseline), never used as a checker ------------------------
+ * The reference's kernels are one-thread-per-point with atomics (models/utils.py:63-313); this is the same formulation with OpenMP
+ * threads instead of GPU lanes: float atomicMin as a compare-exchange loop on the bit pattern, atomicAdd as `omp atomic`.  Like the
+ * reference on a GPU, the accumulation ORDER is then unspecified, so results equal the sequential checker's only up to fp32
+ * summation order (tests/test_oracle_warp.py compares them with a tolerance). */
+static void atomic_min_float(float *addr, float v)
+{
+    int *ia = (int *)addr;
+    int old = __atomic_load_n(ia, __ATOMIC_RELAXED);
+    for (;;) {
+        float cur; memcpy(&cur, &old, 4);
+        if (!(cur > v)) return;
+        int nv; memcpy(&nv, &v, 4);
+        if (__atomic_compare_exchange_n(ia, &old, nv, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return;
+    }
+}
+
+void orc_warp_frame_mt(int64_t N, int H, int W, double focal, double baseline, float sx, float sy, float sz,
+                       const float *pts, const float *rgbd, float *render_filled, float *existing, uint8_t *frame)
+{
+    const int C = 4, C1 = 5;
+    int64_t P = (int64_t)H * W;
+    float *sp = (float *)malloc((size_t)3 * N * sizeof(float));
+    float *zee = (float *)malloc((size_t)P * sizeof(float));
+    float *acc = (float *)calloc((size_t)C1 * P, sizeof(float));
+    float *rnd = (float *)malloc((size_t)C * P * sizeof(float));
+    float *dm = (float *)malloc((size_t)P * sizeof(float));
+    orc_mt = 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < N; ++p) {                                  /* process_shift, common.py:74-81 */
+        float z = pts[2 * N + p];
+        float r = z / (z + 0.0000001f);
+        sp[p] = pts[p] * r + sx; sp[N + p] = pts[N + p] * r + sy; sp[2 * N + p] = z + sz;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < P; ++i) zee[i] = 1000000.0f;
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < N; ++p) {                                  /* updateZee */
+        float fx, fy, err, w[4];
+        if (!orc_project(sp[p], sp[N + p], sp[2 * N + p], focal, baseline, W, H, &fx, &fy, &err)) continue;
+        int x0, y0;
+        orc_corners(fx, fy, &x0, &y0, w);
+        float nw = w[0], ne = w[1], sw = w[2], se = w[3];
+        int cx, cy;
+        if (nw >= ne && nw >= sw && nw >= se) { cx = x0; cy = y0; }
+        else if (ne >= nw && ne >= sw && ne >= se) { cx = x0 + 1; cy = y0; }
+        else if (sw >= nw && sw >= ne && sw >= se) { cx = x0; cy = y0 + 1; }
+        else if (se >= nw && se >= ne && se >= sw) { cx = x0 + 1; cy = y0 + 1; }
+        else continue;
+        if (cx >= 0 && cx < W && cy >= 0 && cy < H) atomic_min_float(zee + (int64_t)cy * W + cx, err);
+    }
+    orc_pointrender_degrid(1, H, W, zee, 1);
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < N; ++p) {                                  /* updateOutput */
+        float fx, fy, err, w[4];
+        if (!orc_project(sp[p], sp[N + p], sp[2 * N + p], focal, baseline, W, H, &fx, &fy, &err)) continue;
+        int x0, y0;
+        orc_corners(fx, fy, &x0, &y0, w);
+        const int dx[4] = {0, 1, 0, 1}, dy[4] = {0, 0, 1, 1};
+        for (int k = 0; k < 4; ++k) {
+            int cx = x0 + dx[k], cy = y0 + dy[k];
+            if (cx < 0 || cx >= W || cy < 0 || cy >= H) continue;
+            float zc = zee[(int64_t)cy * W + cx];
+            if (!((double)err <= (double)zc + 1.0)) continue;
+            for (int c = 0; c < C1; ++c) {
+                float v = (c < C ? rgbd[(int64_t)c * N + p] : 1.0f) * w[k];
+#pragma omp atomic
+                acc[((int64_t)c * H + cy) * W + cx] += v;
+            }
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < P; ++i) {
+        float e = acc[(int64_t)C * P + i], den = e + 0.0000001f;
+        for (int c = 0; c < C; ++c) rnd[(int64_t)c * P + i] = acc[(int64_t)c * P + i] / den;
+        existing[i] = e;
+        dm[i] = rnd[3 * P + i] * (e > 0.0f ? 1.0f : 0.0f);
+    }
+    memcpy(render_filled, rnd, (size_t)C * P * sizeof(float));
+    orc_fill_disocclusion(1, C, H, W, rnd, dm, render_filled);
+    orc_frame_to_u8(C, H, W, render_filled, frame);
+    orc_mt = 0;
+    free(sp); free(zee); free(acc); free(rnd); free(dm);
 }

@@ -141,3 +141,27 @@ def test_zoedepth_head_vs_reference_text():
     onets.run_program(prog, _zoe_inputs(g) + [out])
     assert rel_err(out, g['metric_depth']) < 1e-4, rel_err(out, g['metric_depth'])
     assert out.min() > 0
+
+
+def test_torch_cpu_interpreter_agrees_with_the_c_oracle():
+    """oracle/nets_torch.py (the torch-CPU / oneDNN execution that bench.py times as `cpu_baseline`) runs the same lowered
+    programs as the fmaf-chain C interpreter: outputs agree at fp32 round-off, so the timed baseline computes the real thing"""
+    from cartoonsegmentation_amd.nets import build_isnet, build_leres, build_rtmdet
+    from oracle import nets_torch
+    rng = np.random.default_rng(3)
+    p = build_isnet(SynthWeights('isnet.'), 2, 64, 64)
+    x = rng.normal(0, 1, (2, 4, 64, 64)).astype(np.float32)
+    ya, yb = np.zeros((2, 1, 64, 64), np.float32), np.zeros((2, 1, 64, 64), np.float32)
+    onets.run_program(p, [x, ya]); nets_torch.run_program(p, [x, yb])
+    assert rel_err(yb, ya) < 2e-4
+    p = build_leres(SynthWeights('leres.'), 1, 64, 96)
+    x = rng.normal(0, 1, (1, 3, 64, 96)).astype(np.float32)
+    ya, yb = np.zeros((1, 1, 64, 96), np.float32), np.zeros((1, 1, 64, 96), np.float32)
+    onets.run_program(p, [x, ya]); nets_torch.run_program(p, [x, yb])
+    assert rel_err(yb, ya) < 1e-4
+    rp, cfg = build_rtmdet(SynthWeights('rtmdet.'), 1, 64, 64)
+    x = rng.normal(0, 1, (1, 3, 64, 64)).astype(np.float32)
+    want = rp.cls + rp.reg + rp.kern + [rp.mask_feat]
+    va, vb = onets.run_program(rp.prog, [x], want_views=want), nets_torch.run_program(rp.prog, [x], want_views=want)
+    for t in want:
+        assert rel_err(vb[t], va[t]) < 1e-4

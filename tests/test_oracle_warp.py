@@ -122,3 +122,20 @@ def test_fma_contraction_bracket(path):
         assert np.array_equal(g['fill_depth'] > 0, f['fill_depth'] > 0)
         d = np.abs(g['frame'].astype(np.int32) - f['frame'].astype(np.int32))
         assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+def test_all_cores_warp_variant_matches_the_sequential_checker():
+    """orc_warp_frame_mt (OpenMP threads + atomics: bench.py's timed CPU baseline) against the sequential checker: same coverage,
+    render equal up to the fp32 accumulation order (which the atomics leave unspecified, exactly like the reference on a GPU)"""
+    from cartoonsegmentation_amd import synth
+    from oracle import warp as ow
+    H, W = 96, 128
+    sc = synth.warp_scene(H, W, 5)
+    _, dep, _, pts, _ = ow.disparity_to_points(sc['disp'], sc['focal'], sc['baseline'])
+    rgbd = np.concatenate([sc['rgb'], dep.reshape(1, 1, -1)], 1)
+    sh = np.array([3.0, -2.0, -10.0], np.float32)
+    a = ow.warp_frame(pts.reshape(1, 3, -1), rgbd, H, W, sc['focal'], sc['baseline'], sh, 1)
+    b = ow.warp_frame_mt(pts.reshape(1, 3, -1), rgbd, H, W, sc['focal'], sc['baseline'], sh)
+    assert np.array_equal(a[1] > 0, b[1] > 0)
+    assert np.abs(a[0] - b[0]).max() <= 1e-3 * max(1.0, np.abs(a[0]).max())
+    assert (np.abs(a[2].astype(np.int32) - b[2].astype(np.int32)) <= 1).all()
