@@ -58,28 +58,40 @@ def event_time_ms(fn, iters, warm=3):
 class Workload:
     frames_per_step = 1
     dtype = "f32"
+    MAX_INST = 0                 # instance masks shipped per frame (bit-packed); 0 = frames only
+
+    def make_records(self, device, nmax):
+        """per-frame output records (cartoonsegmentation_amd/shard.py: uint8 frame | MAX_INST bit-packed masks | count): the frame
+        loop writes its uint8 output straight into the record, so shipping a step is ONE gather of one flat tensor per rank"""
+        from cartoonsegmentation_amd import shard
+        self.fb, self.mb, self.rb = shard.record_layout(self.H, self.W, self.MAX_INST)
+        self.records = torch.zeros((nmax, self.rb), dtype=torch.uint8, device=device)
+        # device-resident count words 0 .. MAX_INST + 1 (a frame's count is copied device-to-device: no pageable H2D in the loop)
+        self.count_words = torch.arange(0, 4096, dtype=torch.int64).view(-1, 1).view(torch.uint8).to(device)
+
+    def frame_slot(self, k):
+        return self.records[k, :self.fb].view(self.H, self.W, 3)
 
     def attach(self, world, dist, device):
         self.world, self.dist = world, dist
         self.gather_list = None
         if dist is not None and dist.get_rank() == 0:
-            self.gather_list = [torch.empty((self.frames_per_step, self.H, self.W, 3), dtype=torch.uint8, device=device)
-                                for _ in range(world)]
+            self.gather_list = [torch.empty((self.frames_per_step, self.rb), dtype=torch.uint8, device=device) for _ in range(world)]
 
     def step_and_gather(self):
-        """one step on this rank, then the per-rank gather of the uint8 output to rank 0.  The gather runs
-        asynchronously on the communicator's stream from one of two staging copies of the frames, so step s + 1 computes while
-        the frames of step s travel; finish_gathers() (inside the timed region) waits for whatever is still in flight."""
+        """one step on this rank, then the per-rank gather of the output records (uint8 frames + bit-packed instance masks, SURVEY.md
+        8e) to rank 0.  The gather runs asynchronously on the communicator's stream from one of two staging copies, so step s + 1
+        computes while the records of step s travel; finish_gathers() (inside the timed region) waits for whatever is still in flight."""
         frame = self.step()
         if self.dist is not None:
             if not hasattr(self, '_stage'):
-                self._stage = [torch.empty((self.frames_per_step, self.H, self.W, 3), dtype=torch.uint8, device=frame.device) for _ in range(2)]
+                self._stage = [torch.empty((self.frames_per_step, self.rb), dtype=torch.uint8, device=frame.device) for _ in range(2)]
                 self._work, self._parity = [None, None], 0
             p = self._parity
             self._parity ^= 1
             if self._work[p] is not None:
                 self._work[p].wait()                           # the previous gather from this staging buffer (two steps ago)
-            self._stage[p].copy_(frame.view(self.frames_per_step, self.H, self.W, 3))
+            self._stage[p].copy_(self.records[:self.frames_per_step])
             self._work[p] = self.dist.gather(self._stage[p], self.gather_list, dst=0, async_op=True)
         return frame
 
@@ -88,6 +100,20 @@ class Workload:
             if w is not None:
                 w.wait()
                 self._work[p] = None
+
+    def check_gathered(self):
+        """rank 0, after the timed region: the last step's records of every rank unpack into a frame and the shipped masks"""
+        from cartoonsegmentation_amd import shard
+        if self.gather_list is None:
+            return None
+        ok, n_masks = True, 0
+        for r, g in enumerate(self.gather_list):
+            frame, masks, n = shard.read_record(g[0], self.H, self.W, self.MAX_INST)
+            ok = ok and frame.shape == (self.H, self.W, 3) and 0 <= n <= 4095 and masks.shape[0] == min(n, self.MAX_INST)
+            ok = ok and (masks.shape[0] == 0 or bool(masks.flatten(1).any(1).all()))
+            n_masks += int(masks.shape[0])
+        return {"records_ok": bool(ok), "masks_in_first_frames": n_masks, "record_bytes": self.rb,
+                "gathered_bytes_per_rank_step": self.rb * self.frames_per_step}
 
     def extra(self):
         return {}
@@ -115,9 +141,12 @@ class WarpWorkload(Workload):
         self.wf = ops.WarpFrame(size, size, device)
         self.P = size * size
         self.N = self.pts.shape[2]
+        self.make_records(device, 1)
 
     def step(self):
         frame, _ = self.wf(self.pts, self.rgb, self.dep, self.scene['focal'], self.scene['baseline'], self.shift)
+        if self.dist is not None:
+            self.frame_slot(0).copy_(frame)
         return frame
 
     def config(self, world):
@@ -145,7 +174,8 @@ class WarpWorkload(Workload):
         return {"bound": "hbm", "kernel": "csm_warp_frame_tiled: k_tile_bin + k_tile_render + k_tile_holes" if tiled
                 else "csm_warp_frame: k_fill + k_update_zee + k_degrid + k_update_output + k_finalize_frame + k_fill_holes",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": load_traffic("warp_chain_tiled" if tiled else "k_update_output"), "algorithmic_bytes_per_launch": alg,
+                "traffic": load_traffic("warp_chain_tiled" if tiled else "k_update_output"), "traffic_source": TRAFFIC_SOURCE,
+                "algorithmic_bytes_per_launch": alg,
                 "launch_us": round(ms * 1e3, 2)}
 
     def cpu_baseline(self, seconds):
@@ -170,6 +200,7 @@ class FrameWorkload(Workload):
     + LeReS depth @640 + depth adjustment + disparity->points + ONE Ken Burns warp (+ crop/resize to uint8)."""
     name = "seg+depth+warp"
     INSTANCES = 2
+    MAX_INST = 2                  # masks shipped per frame = the instance cap of the synthetic detector
 
     def __init__(self, size, rank, device, batch=8):
         self.frames_per_step = batch
@@ -188,11 +219,11 @@ class FrameWorkload(Workload):
         self.all_imgs = [torch.from_numpy(synth.image_u8(size, size, 1234 + 64 * rank + k)).to(device) for k in range(max(batch, 16))]
         self.imgs = self.all_imgs[:batch]
         self.wf = ops.WarpFrame(size, size, device)
-        self.out = torch.empty((max(batch, 16), size, size, 3), dtype=torch.uint8, device=device)
+        self.make_records(device, max(batch, 16))
         self.n_inst = None
 
     def step(self):
-        from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, f32, check
+        from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, i64, f32, check
         pipe = self.pipe
         if self.frames_per_step == 1:
             kcs = [pipe.generate_kenburns_config(self.imgs[0])]     # seg (main stream) || LeReS (side stream)
@@ -205,9 +236,17 @@ class FrameWorkload(Workload):
             shift = self.ops.shift_vector({'fltShiftU': 30.0, 'fltShiftV': -20.0, 'fltDepthFrom': d_from, 'fltDepthTo': d_from / 1.25}, kc)
             frame, _ = self.wf(kc['tenInpaPoints'], kc.inpainted_img, kc['tenInpaDepth'], kc['fltFocal'], kc['fltBaseline'], shift)
             pw, ph = int(0.97 * W), int(0.97 * H)
-            check(load().csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0), ptr(self.out[k]),
+            check(load().csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0), ptr(self.frame_slot(k)),
                                             stream_ptr()))
-        return self.out[:self.frames_per_step]
+            # the frame's instance masks join its output record bit-packed (frame + packed masks travel to rank 0)
+            rec, masks = self.records[k], kc.instances.masks
+            n = 0 if kc.instances.is_empty else int(masks.shape[0])
+            for j in range(min(n, self.MAX_INST)):
+                check(load().csm_pack_mask_bits(ptr(masks[j].view(torch.uint8)), i64(H * W), ptr(rec[self.fb + j * self.mb:]), stream_ptr()))
+            if n < self.MAX_INST:
+                rec[self.fb + n * self.mb: self.fb + self.MAX_INST * self.mb].zero_()
+            rec[self.fb + self.MAX_INST * self.mb:].copy_(self.count_words[min(n, 4095)])
+        return self.records[:self.frames_per_step, :self.fb]
 
     # ---- extra single-GPU measurements (batch 1 = BASELINE configs[1..2], n instances in {1, 8}, det 1024, the video) ----
     def _fps(self, batch=None, instances=None, det=None, steps=3, conv_roofline=False):
@@ -339,7 +378,9 @@ class FrameWorkload(Workload):
     def config(self, world):
         return {"workload": "seg(RTMDet-Ins-L det640 + maskhead + ISNet refine@720, %d instances) + LeReS depth@640 + 1 warp, "
                             "frame %dx%d" % (self.n_inst or self.INSTANCES, self.W, self.H),
-                "frames_per_gpu_step": self.frames_per_step, "global_batch": self.frames_per_step * world, "parallelism": "frames sharded x%d (no data-path collective; uint8 frame gather)" % world,
+                "frames_per_gpu_step": self.frames_per_step, "global_batch": self.frames_per_step * world,
+                "is_baseline_configs3": bool(world == 8 and self.frames_per_step * world == 64 and self.W == 1024),
+                "parallelism": "frames sharded x%d (no data-path collective; per-rank gather of uint8 frames + bit-packed instance masks)" % world,
                 "weights": "closed-form synthetic (no checkpoints offline)", "precision": "fp32 exact (v_mfma_f32_32x32x2_f32)"}
 
     def roofline(self):
@@ -373,7 +414,8 @@ class FrameWorkload(Workload):
         tot_fl /= self.frames_per_step
         return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_mfma (fp32 implicit GEMM, all conv launches of one step = %d frames)" % self.frames_per_step,
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
-                "traffic": load_traffic("k_conv"), "algorithmic_bytes_per_launch": int(alg_bytes / max(n_launch, 1)),
+                "traffic": load_traffic("k_conv"), "traffic_source": TRAFFIC_SOURCE,
+                "algorithmic_bytes_per_launch": int(alg_bytes / max(n_launch, 1)),
                 "algorithmic_flops_per_frame": tot_fl,
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_step": n_launch, "per_net": per_net}
 
@@ -394,6 +436,10 @@ def make_workload(kind, size, rank, device, world, dist, batch=8):
         raise SystemExit("unknown workload %r" % kind)
     wl.attach(world, dist, device)
     return wl
+
+
+TRAFFIC_SOURCE = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed by the builder; "
+                  "NOT re-measured inside this run (PMC collection needs its own rocprofv3 passes)")
 
 
 def load_traffic(kernel_key):
@@ -493,7 +539,13 @@ def main():
         out.update(wl.extra())
         if world == 1 and not a.no_variants and hasattr(wl, "variants"):
             out["variants"] = wl.variants()
+            b1 = out["variants"].get("batch1")
+            if b1:             # the literal BASELINE configs[1..2] (one frame per step) next to the headline (configs[3]'s 8 frames per rank)
+                out["batch1"] = {"frames_per_s": b1["frames_per_s"], "ms_per_frame": b1["ms_per_frame"],
+                                 "conv_frac_of_mfma_peak": b1.get("conv_frac_of_mfma_peak"),
+                                 "what": "BASELINE configs[1..2] literally: ONE 1024x1024 frame per step (seg + depth + warp)"}
         if world > 1:
+            out["gather"] = wl.check_gathered()
             out["weights_broadcast_bytes"] = bcast_bytes
             out["weights_equal_after_broadcast"] = weights_equal
             out["tile_table"] = os.environ.get("CSM_TUNE_CACHE")

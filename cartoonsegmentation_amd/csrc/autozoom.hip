@@ -379,16 +379,22 @@ __global__ __launch_bounds__(kBandThreads) void k_band_cover(ProjConst pc, const
             const float cz = Zc[0];
             const bool up = y > 0, dn = y < H - 1, lf = x > 0, rt = x < W - 1;
             int cnt2 = 0; float sum = 0.0f;
-            // `(double)cz >= (double)a + 1.0`  <=>  a <= the largest float below (double)cz - 1.0 ... NOT the same rounding: the
-            // reference adds 1.0 to a in double, so the test is (double)a <= (double)cz - 1.0 exactly (both sides exact doubles:
-            // a float +- 1.0 is representable in double) -> one threshold per pixel, fp32 compares per neighbour
+            // The reference tests `(double)cz >= (double)a + 1.0` per neighbour.  For |a| >= 2^-28 (or a == 0) the sum a + 1.0 is
+            // exact in double, and so is cz - 1.0 for |cz| >= 2^-28 (or 0), hence the test equals (double)a <= (double)cz - 1.0
+            // = a <= thr with thr the largest float <= cz - 1.0: one threshold per pixel, fp32 compares per neighbour.  Tiny
+            // non-zero neighbours (a + 1.0 rounds in double; unreachable for real depth ranges, where z-buffer entries are ~1e6)
+            // take the reference's own expression.
             const float thr = round_down_f32((double)cz - 1.0);
+            const bool cz_exact = fabsf(cz) >= 3.7252903e-9f || cz == 0.0f;     // 2^-28: cz - 1.0 is an exact double
+            auto below = [&](float a) {
+                return (cz_exact && (fabsf(a) >= 3.7252903e-9f || a == 0.0f)) ? a <= thr : (double)cz >= (double)a + 1.0;
+            };
             // loop order of the reference: (1,0) (0,1) (1,1) (1,-1), the +offset end first; a line counts only if both ends are inside
-            if (lf && rt) { const float a = Zc[1], d = Zc[-1]; if (a <= thr && d <= thr) { cnt2 += 2; sum += a; sum += d; } }
-            if (up && dn) { const float a = Zc[W], d = Zc[-W]; if (a <= thr && d <= thr) { cnt2 += 2; sum += a; sum += d; } }
+            if (lf && rt) { const float a = Zc[1], d = Zc[-1]; if (below(a) && below(d)) { cnt2 += 2; sum += a; sum += d; } }
+            if (up && dn) { const float a = Zc[W], d = Zc[-W]; if (below(a) && below(d)) { cnt2 += 2; sum += a; sum += d; } }
             if (lf && rt && up && dn) {
-                { const float a = Zc[W + 1], d = Zc[-W - 1]; if (a <= thr && d <= thr) { cnt2 += 2; sum += a; sum += d; } }
-                { const float a = Zc[-W + 1], d = Zc[W - 1]; if (a <= thr && d <= thr) { cnt2 += 2; sum += a; sum += d; } }
+                { const float a = Zc[W + 1], d = Zc[-W - 1]; if (below(a) && below(d)) { cnt2 += 2; sum += a; sum += d; } }
+                { const float a = Zc[-W + 1], d = Zc[W - 1]; if (below(a) && below(d)) { cnt2 += 2; sum += a; sum += d; } }
             }
             const float r = cnt2 > 0 ? fminf(cz, sum / (float)cnt2) : cz;
             // zd holds the z-test THRESHOLD of the pixel, not the degridded value: err passes  <=>  (double)err <= (double)r + 1.0

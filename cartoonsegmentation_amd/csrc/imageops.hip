@@ -317,6 +317,33 @@ extern "C" int csm_resize_u8_linear(const uint8_t *src_hwc, int H, int W, int C,
     return csm::check_launch("k_resize_u8_linear");
 }
 
+// cv2.resize(float32 HWC, (w,h), INTER_LINEAR): scaledown_maxsize / resize_pad on float masks (utils/io_utils.py:254-292 as called by
+// prepare_refine_batch, animeinsseg/__init__.py:47).  [EXT: OpenCV resize.cpp, float path restated: the same source index / fraction
+// as the uint8 path, HResizeLinear (row: s0 * (1 - fx) + s1 * fx) then VResizeLinear (r0 * (1 - fy) + r1 * fy), all in fp32.]
+__global__ __launch_bounds__(256) void k_resize_f32_linear(const float *__restrict__ src, int H, int W, int C, int h, int w,
+                                                            float *__restrict__ dst) {
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    int y0, y1, x0, x1; float fy, fx;
+    cv_src(y, H, (double)H / h, y0, y1, fy); cv_src(x, W, (double)W / w, x0, x1, fx);
+    const float a0 = 1.0f - fx, a1 = fx, b0 = 1.0f - fy, b1 = fy;
+    for (int c = 0; c < C; ++c) {
+        const float r0 = src[((int64_t)y0 * W + x0) * C + c] * a0 + src[((int64_t)y0 * W + x1) * C + c] * a1;
+        const float r1 = src[((int64_t)y1 * W + x0) * C + c] * a0 + src[((int64_t)y1 * W + x1) * C + c] * a1;
+        dst[((int64_t)y * w + x) * C + c] = r0 * b0 + r1 * b1;
+    }
+}
+
+extern "C" int csm_resize_f32_linear(const float *src_hwc, int H, int W, int C, int h, int w, float *dst_hwc, void *stream) {
+    CSM_REQUIRE(src_hwc && dst_hwc && H > 0 && W > 0 && h > 0 && w > 0 && C > 0 && C <= 4);
+    if (h == H && w == W) {
+        CSM_HIP(hipMemcpyAsync(dst_hwc, src_hwc, (size_t)H * W * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return CSM_OK;
+    }
+    k_resize_f32_linear<<<dim3(csm::cdiv(w, 256), h), 256, 0, (hipStream_t)stream>>>(src_hwc, H, W, C, h, w, dst_hwc);
+    return csm::check_launch("k_resize_f32_linear");
+}
+
 // cv2.resize(u8 [h,w], (W,H), INTER_LANCZOS4) -> float32 (kenburns_effect.py:572-575 when the 32-aligned LeReS map is LARGER than the
 // frame, k > 1).  [EXT: OpenCV 4.10 resize.cpp restated: source coordinate (d + 0.5) scale - 0.5, 8 taps sx-3..sx+4 with replicate
 // clamping per tap, interpolateLanczos4 coefficients in float -> short Q11 (cvRound), horizontal pass to int, vertical pass, result
@@ -688,6 +715,50 @@ extern "C" int csm_bokeh_depth(const uint8_t *depth_u8, float *out, int64_t n, f
     CSM_REQUIRE(depth_u8 && out && n > 0);
     k_bokeh_depth<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(depth_u8, out, n, dmax, focal_plane, mn, mx2);
     return csm::check_launch("k_bokeh_depth");
+}
+// General form of the depth map of bokeh_blur (utils/effects.py:146-153, :162-163) for the reference's own defaults -- float or uint8
+// depth, focal_plane optional, any depth_factor:  d' = has_focal ? max(d) - |d - focal| : d;  d'' = depth_factor != 1 ? d' ^ factor : d';
+// out = (1 - (d'' - min d'') / max(d'' - min d'')) * 0.0005.  np.power(float32, 2) is a square (numpy's fast path), other exponents
+// go through powf.  Every step is one fp32 operation per element as numpy performs it; x -> x - mn is monotone under rounding, so
+// max(d'' - mn) = fl(mx - mn) exactly and two min/max reductions (of d and of d'') are all the statistics needed.
+__global__ __launch_bounds__(256) void k_bokeh_depth_pre(const void *__restrict__ depth, int is_u8, int64_t n, const float *__restrict__ dmm,
+                                                          int has_focal, float focal, float factor, float *__restrict__ tmp) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = is_u8 ? (float)reinterpret_cast<const uint8_t *>(depth)[i] : reinterpret_cast<const float *>(depth)[i];
+    if (has_focal) v = dmm[1] - fabsf(v - focal);
+    if (factor == 2.0f) v = v * v;
+    else if (factor != 1.0f) v = powf(v, factor);
+    tmp[i] = v;
+}
+__global__ __launch_bounds__(256) void k_bokeh_depth_post(const float *__restrict__ tmp, int64_t n, const float *__restrict__ tmm,
+                                                           float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float mn = tmm[0], mx2 = tmm[1] - tmm[0];
+    float v = tmp[i] - mn;
+    v = v / mx2;
+    v = 1.0f - v;
+    out[i] = v * 0.0005f;
+}
+extern "C" int csm_bokeh_depth_general(const void *depth, int is_u8, int64_t n, int has_focal, float focal_plane, float depth_factor,
+                                       float *tmp, float *mm4, float *scratch512, float *out, void *stream) {
+    CSM_REQUIRE(depth && tmp && mm4 && scratch512 && out && n > 0 && !(((uintptr_t)tmp) & 15));
+    hipStream_t st = (hipStream_t)stream;
+    if (has_focal) {
+        // max(depth): through the float reduction (a uint8 plane is widened first -- into `out`, which is rewritten at the end)
+        const float *src = reinterpret_cast<const float *>(depth);
+        if (is_u8) {
+            k_bokeh_depth_pre<<<csm::cdiv(n, 256), 256, 0, st>>>(depth, 1, n, mm4, 0, 0.0f, 1.0f, out);
+            src = out;
+        }
+        CSM_REQUIRE(!(((uintptr_t)src) & 15));
+        int rc = csm_minmax(src, n, mm4, scratch512, stream); if (rc) return rc;
+    }
+    k_bokeh_depth_pre<<<csm::cdiv(n, 256), 256, 0, st>>>(depth, is_u8, n, mm4, has_focal, focal_plane, depth_factor, tmp);
+    int rc = csm_minmax(tmp, n, mm4 + 2, scratch512, stream); if (rc) return rc;
+    k_bokeh_depth_post<<<csm::cdiv(n, 256), 256, 0, st>>>(tmp, n, mm4 + 2, out);
+    return csm::check_launch("k_bokeh_depth_general");
 }
 extern "C" int csm_colorize_gray_r(const float *value, uint8_t *out, int64_t n, float vmin, float vmax, void *stream) {
     CSM_REQUIRE(value && out && n > 0);

@@ -272,6 +272,30 @@ __global__ __launch_bounds__(256) void k_det_preprocess(const uint8_t *__restric
 
 }  // namespace
 
+// np.packbits(mask != 0, bitorder='little') of a byte plane: the form instance masks travel in when a rank ships its outputs to
+// rank 0 (3 MB frame + bit-packed masks per frame).  One thread per output byte, 8-byte loads when aligned.
+namespace {
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t *__restrict__ m, int64_t n, uint8_t *__restrict__ out, int aligned) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= ((n + 7) >> 3)) return;
+    const int64_t base = o << 3;
+    unsigned v = 0u;
+    if (aligned && base + 8 <= n) {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long *>(m + base);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v |= (((w >> (8 * b)) & 0xffull) ? 1u : 0u) << b;
+    } else {
+        for (int b = 0; b < 8 && base + b < n; ++b) v |= (m[base + b] ? 1u : 0u) << b;
+    }
+    out[o] = (uint8_t)v;
+}
+}  // namespace
+extern "C" int csm_pack_mask_bits(const uint8_t *mask, int64_t n, uint8_t *out, void *stream) {
+    CSM_REQUIRE(mask && out && n > 0);
+    k_pack_bits<<<csm::cdiv((n + 7) >> 3, 256), 256, 0, (hipStream_t)stream>>>(mask, n, out, (((uintptr_t)mask) & 7) == 0 ? 1 : 0);
+    return csm::check_launch("k_pack_bits");
+}
+
 extern "C" size_t csm_nms_scratch_bytes(int n) { return (size_t)n * ((n + 63) / 64) * 8 + 64; }
 
 extern "C" int csm_nms(const float *boxes, const float *class_offsets, int n, float iou_thr, int max_keep, int *keep,

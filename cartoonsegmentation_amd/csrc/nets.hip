@@ -471,21 +471,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     int l_kh = l_tap / a.kw, l_kw = l_tap - l_kh * a.kw;
     unsigned l_w = (unsigned)(((int64_t)g * Tall + c_begin) * a.npad * 128);     // byte offset of the chunk's weight tile
     auto issue = [&](int stage) {
-#ifdef CSM_X_HOTDMA            // experiment: every chunk re-loads the first chunk's bytes (same instruction stream, all cache hits)
-        const unsigned coff = 0u;
-        l_w = (unsigned)(((int64_t)g * Tall + c_begin) * a.npad * 128);
-#else
         const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
-#endif
         const unsigned sb = (unsigned)stage * (unsigned)(kStageF * 4);
-#ifndef CSM_X_NODMA
 #pragma unroll
         for (int p = 0; p < GA; ++p)
             dma16(((vmA[p] >> l_tap) & 1u) ? offA[p] + coff : kOob, ra, ldsA + sb + (unsigned)p * 1024u);
 #pragma unroll
         for (int p = 0; p < GB; ++p)
             dma16(offB[p] == kOob ? kOob : offB[p] + l_w, rb, ldsB + sb + (unsigned)p * 1024u);
-#endif
         l_w += (unsigned)a.npad * 128u;
         ++l_tap;
         if (++l_kw == a.kw) { l_kw = 0; if (++l_kh == a.kh) { l_kh = 0; l_tap = 0; ++l_cb; } }
@@ -524,24 +517,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             float4 af[TM], bf[TN];
-#ifdef CSM_X_NOLDSREAD
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = float4{1.f + kb, 2.f, 3.f, 4.f + i};
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = float4{1.f, 2.f + j, 3.f + kb, 4.f};
-            (void)S;
-#else
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(S + rowA + i * 1024 + sw[kb]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(S + rowB + j * 1024 + sw[kb]);
-#endif
-#ifdef CSM_X_NOMFMA
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af[i].x), "v"(af[i].y), "v"(af[i].z), "v"(af[i].w));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bf[j].x), "v"(bf[j].y), "v"(bf[j].z), "v"(bf[j].w));
-#else
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -552,7 +531,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
                         const float bv = t == 0 ? bf[j].x : (t == 1 ? bf[j].y : (t == 2 ? bf[j].z : bf[j].w));
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                     }
-#endif
         }
     };
 
@@ -560,9 +538,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         issue(0);
         for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of `chunk` have landed ...
-#ifndef CSM_X_NOBARRIER
             __builtin_amdgcn_s_barrier();                          // ... everybody's have, and everybody is done reading stage st^1
-#endif
             if (chunk + 1 < T) issue(st ^ 1);
             compute(st, chunk);
         }
@@ -592,9 +568,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-#ifdef CSM_X_NOEPI
-                if (m >= 0) continue;
-#endif
                 if (m >= a.M) continue;
                 float v = acc[i][j][r];
                 if constexpr (SER) v = tot[i][j][r] + v;

@@ -1,30 +1,27 @@
 // warptile.hip -- one Ken Burns output frame (kenburns_effect.py:1027-1040) with the splat done per DESTINATION TILE in LDS.
 //
-// Why: the r01 chain (warp.hip: fill, updateZee, degrid, updateOutput, finalize, fill-holes) spends half of its 142 us in
-// updateOutput, whose 20 fp32 atomics per point go to the L2 atomic units; those retire about one lane-atomic per channel and
-// clock (~0.25 T lane-atomics/s measured on the z pass and on the accumulate pass alike), 50x below what the LDS of 256 CUs
-// sustains.  A wave of consecutive source pixels also lands in one or two 32 x 32 destination tiles.  So:
+// Why: the round-1 chain (warp.hip: fill, updateZee, degrid, updateOutput, finalize, fill-holes) spends half of its 141 us in
+// updateOutput, whose 20 fp32 atomics per point go to the L2 atomic units (~0.25 T lane-atomics/s on gfx950), 50x below what the
+// LDS of 256 CUs sustains, and a wave of consecutive source pixels lands in one or two destination tiles anyway.  Three kernels:
 //
-//   k_tile_count    per point: process_shift + projection (warp_device.h, the reference's statements), the <= 4 tiles whose
-//                   1-px-expanded area its 2 x 2 footprint touches; block-local LDS histogram, then ONE global atomic per
-//                   (block, touched tile) whose return value is the block's base inside that tile's segment.
-//   k_tile_scatter  every block scans the tile totals itself (LDS), recomputes the enumeration and writes 16-B entries
-//                   {fx, fy, fltError, point index} at offs[tile] + base[block][tile] + LDS cursor.  No scan kernel in between.
-//   k_tile_render   one 256-thread block per 32 x 16 tile, everything else in LDS: z-buffer of the tile + 1-px ring (ds_min_i32 /
-//                   ds_max_u32: float min through the sign-split integer trick), Jacobi degrid, z-test + bilinear splat of
-//                   rgb / depth / weight into 64-bit FIXED-POINT accumulators (ds_add_u64: ~2x the rate of ds_add_f32 on
-//                   gfx950 and order free, so a frame is bit-reproducible), normalise, depth mask, uint8 frame, masked-depth
-//                   plane, row / column valid BITMAPS (ballot), per-tile hole list; re-arms the tile's counters.
-//   k_tile_holes    flat, balanced list of all holes (prefix scan of the per-tile counts + binary search), 32 lanes per hole =
-//                   16 directions x {from, to} of fill_disocclusion (common.py:145-248); the four axis rays are word scans of
-//                   the row / column bitmaps, the oblique rays probe the bitmap four steps per round trip.
+//   k_tile_bin      ONE pass over the points: process_shift + projection (warp_device.h, the reference's statements), the <= 4
+//                   32 x 16 tiles whose 1-px-expanded area the 2 x 2 footprint touches; block-local LDS histogram whose atomic return
+//                   value is the entry's rank inside (block, tile); the rank-0 lane of every touched tile reserves the block's run
+//                   in the tile's FIXED-CAPACITY segment with one global atomic; 16-B entries {fx, fy, fltError, point index} go
+//                   to segment + run + rank.  Overflow goes to a spill list (exact for any cloud).
+//   k_tile_render   one 256-thread block per tile, everything else in LDS: z-buffer of the tile + 1-px ring (ds_min_i32 / ds_max_u32:
+//                   float min through the sign-split integer trick), Jacobi degrid, z-test + bilinear splat of rgb / depth / weight
+//                   into 64-bit FIXED-POINT accumulators (ds_add_u64: ~2x the rate of ds_add_f32 and order free, so a frame is
+//                   bit-reproducible), normalise, depth mask, uint8 frame, masked-depth plane, row / column valid BITMAPS (ballot);
+//                   the tile's holes are appended to the frame's flat hole list with one atomic; re-arms the tile's counter.
+//   k_tile_holes    32 lanes per hole = 16 directions x {from, to} of fill_disocclusion (common.py:145-248); the four axis rays are
+//                   word scans of the row / column bitmaps, the oblique rays probe the bitmap four steps per round trip and stop
+//                   once they have walked further than the best complete direction found so far.
 //
-// No float atomic reaches L2, the accumulator planes never exist in HBM, and the z-buffer decisions are the ones of the r01
+// No float atomic reaches L2, the accumulator planes never exist in HBM, and the z-buffer decisions are the ones of the round-1
 // chain bit for bit (min is order free; the degrid is the same Jacobi form; every comparison is the reference's expression).
-// Measured at 1024^2, N = P: 96-98 us per frame against 141 us; PMC traffic 120.6 MB per frame against SURVEY's 155 B per pixel
-// = 162.5 MB of algorithmic bytes for the reference's structure (profiles/r02_*).
+// Measured numbers per round: DESIGN.md section 4.1 and profiles/.
 #include "warp_device.h"
-#include <cstdlib>
 
 namespace {
 using namespace csmwarp;
@@ -115,15 +112,6 @@ __device__ __forceinline__ int64_t point_of(const PointMap &m, int64_t block, in
 
 constexpr int kTotalStride = 32;       // ints between two tiles' global counters: one 128-B line each (same-line atomics serialise)
 
-// Binning in ONE pass over the points: every tile owns a fixed-capacity segment entries[t * cap .. t * cap + cap).  A block
-// histograms its kPPB points in LDS (the LDS atomic's return value is the entry's rank inside (block, tile)), the rank-0 lane of
-// every touched tile
-// reserves the block's run in the tile's segment with ONE global atomic, then every lane writes its entries at
-// segment + run start + rank.  No counting pre-pass, no scan, no per-block offset table.  (Round-2 history: a separate count
-// kernel + per-block scan of the totals in the scatter kernel cost 8.7 + 10 us at 1024^2; the first design with one global
-// atomic per distinct tile per wave cost 49 us -- same-line device-scope atomics serialise at the memory side.)
-// Capacity is ~2.5x the expected load (tile_cap below).  Entries beyond it go to a global spill list that every render block
-// filters by tile id: exact for any input, slow only for pathological clouds (thousands of points in one 32 x 16 tile).
 template <bool SHIFT>
 __global__ __launch_bounds__(kBlock) void k_tile_bin(const float *__restrict__ pts, int64_t N, ProjConst pc, Shift s, TileGeom g, int cap,
                                                       PointMap pm, int *__restrict__ tile_total, Entry *__restrict__ entries,
@@ -213,7 +201,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q, double inv_sca
 
 __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict__ entries, int cap,
                                                          const float *__restrict__ rgb, const float *__restrict__ depth, int64_t N,
-                                                         int H, int W, TileGeom g, FrameOut out, int dbg) {
+                                                         int H, int W, TileGeom g, FrameOut out) {
     __shared__ float zee[ZH * ZW];
     __shared__ float zd[TPIX];
     __shared__ unsigned long long acc[5 * TPIX];
@@ -310,12 +298,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
             atomicAdd(&acc[4 * TPIX + li[k]], to_fixed(1.0f * wk, kScaleC));
         }
     };
-    if (!(dbg & 2)) {
 #pragma unroll
-        for (int k = 0; k < kReg; ++k) if (has[k]) splat(en[k], false, c0[k], c1[k], c2[k], c3[k]);
-        for (int e = e0 + tid + kReg * kBlock; e < e1; e += kBlock) splat(entries[e], true, 0.0f, 0.0f, 0.0f, 0.0f);
-        for (int e = tid; e < nspill; e += kBlock) if (out.spill_tile[e] == t) splat(out.spill[e], true, 0.0f, 0.0f, 0.0f, 0.0f);
-    }
+    for (int k = 0; k < kReg; ++k) if (has[k]) splat(en[k], false, c0[k], c1[k], c2[k], c3[k]);
+    for (int e = e0 + tid + kReg * kBlock; e < e1; e += kBlock) splat(entries[e], true, 0.0f, 0.0f, 0.0f, 0.0f);
+    for (int e = tid; e < nspill; e += kBlock) if (out.spill_tile[e] == t) splat(out.spill[e], true, 0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     // ---- models/utils.py:315 normalise; kenburns_effect.py:1039-1040 depth mask + uint8; hole list for fill_disocclusion --------
     const int64_t plane = (int64_t)H * W;
@@ -334,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
             rowbits[ly] = (unsigned)(bits >> (tid & 32));
             if (y < H) out.vbits[(int64_t)y * g.ntx + (t % g.ntx)] = (unsigned)(bits >> (tid & 32));
         }
-        if (!inside || (dbg & 16)) continue;
+        if (!inside) continue;
         const int64_t o = (int64_t)y * W + x;
         out.mdepth[o] = m;
         if (out.render) { out.render[o] = r0; out.render[plane + o] = r1; out.render[2 * plane + o] = r2; out.render[3 * plane + o] = r3; }
@@ -371,7 +357,7 @@ __constant__ float kDirY[16] = {1, 1, 1, 0, 2, 2, 1, -1, 3, 3, 3, 3, 2, 1, -1, -
 // directions, whose rays run the length of a disoccluded border strip, scan the row / column bitmap a word (32 px) at a time --
 // their steps are exact integers in fp32, so the visited pixels are the same.  A 16-lane lexicographic (distance, direction)
 // minimum then picks the direction exactly like the reference's sequential loop (shortest distance, first direction wins ties).
-__global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g, FrameOut out, int dbg) {
+__global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g, FrameOut out) {
     const int tid = threadIdx.x;
     const int total = *out.hole_count;                                          // the frame's flat hole list (k_tile_render)
     if (blockIdx.x == 0 && tid == 0) *out.spill_count = 0;                      // every reader (k_tile_render) has finished
@@ -389,9 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_holes(int H, int W, TileGeom g,
         float fx = (float)x, fy = (float)y;
         int ix = 0, iy = 0;
         bool ok = false, oblique = false;
-        if ((dbg & 256) && (k == 1 || k == 3)) { ok = false; }
-        else if ((dbg & 128) && k != 1 && k != 3) { ok = false; }
-        else if (k != 1 && k != 3) { oblique = true; }
+        if (k != 1 && k != 3) { oblique = true; }
         else if (k == 3) {
             // direction (1, 0): the ray visits (x +- j, y) exactly (integer steps are exact in fp32) -> scan the row bitmap by words
             const unsigned *R = out.vbits + (int64_t)y * g.ntx;
@@ -550,8 +534,6 @@ extern "C" size_t csm_warp_tile_header_bytes(int H, int W) { return (H <= 0 || W
 // largest tile count the block-local histograms / prefix tables support (LDS: 4 B per tile); larger frames use csm_warp_frame
 extern "C" int csm_warp_tile_supported(int H, int W) { return H > 0 && W > 0 && tile_geom(H, W).nt <= 8192; }
 
-static int g_tile_dbg = -1;
-
 extern "C" int csm_warp_frame_tiled(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal,
                                     double baseline, float sx, float sy, float sz, void *scratch, float *render_filled,
                                     uint8_t *frame_u8, void *stream) {
@@ -559,7 +541,6 @@ extern "C" int csm_warp_frame_tiled(const float *pts, const float *rgb, const fl
     CSM_REQUIRE(N == 0 || (pts && rgb && depth));
     CSM_REQUIRE((((uintptr_t)scratch) & 15) == 0);
     if (!csm_warp_tile_supported(H, W)) return csm::fail_arg("frame too large for the tiled path (more than 8192 tiles): use csm_warp_frame");
-    if (g_tile_dbg < 0) { const char *e = getenv("CSM_TILE_DBG"); g_tile_dbg = e ? atoi(e) : 0; }   // measurement aid (phase ablation)
     hipStream_t st = (hipStream_t)stream;
     const TileGeom g = tile_geom(H, W);
     const TileScratch ts = carve(scratch, H, W, g.nt, N);
@@ -576,15 +557,8 @@ extern "C" int csm_warp_frame_tiled(const float *pts, const float *rgb, const fl
     }
     FrameOut out{frame_u8, ts.vbits, ts.cbits, ts.mdepth, render_filled, ts.holes, ts.hole_count, ts.totals, ts.cpitch,
                  ts.spill, ts.spill_tile, ts.spill_count};
-    if (!(g_tile_dbg & 64)) {
-        k_tile_render<<<g.nt, kBlock, 0, st>>>(ts.entries, ts.cap, rgb, depth, N, H, W, g, out, g_tile_dbg);
-        rc = csm::check_launch("k_tile_render"); if (rc) return rc;
-    }
-    if (!(g_tile_dbg & 32)) {
-        static int hb = 0;
-        if (!hb) { const char *e = getenv("CSM_TILE_HOLE_BLOCKS"); hb = e ? atoi(e) : 1024; if (hb < 1) hb = 1024; }
-        k_tile_holes<<<hb, kBlock, 0, st>>>(H, W, g, out, g_tile_dbg);
-        rc = csm::check_launch("k_tile_holes"); if (rc) return rc;
-    }
-    return CSM_OK;
+    k_tile_render<<<g.nt, kBlock, 0, st>>>(ts.entries, ts.cap, rgb, depth, N, H, W, g, out);
+    rc = csm::check_launch("k_tile_render"); if (rc) return rc;
+    k_tile_holes<<<1024, kBlock, 0, st>>>(H, W, g, out);
+    return csm::check_launch("k_tile_holes");
 }

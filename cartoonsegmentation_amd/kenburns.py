@@ -10,8 +10,9 @@ MI355X-first differences (results unchanged):
     coverage needs (z-buffer, degrid, z-test: autozoom.hip); the counts are read back once;
   * the 75-frame loop (kenburns_effect.py:1015-1072) is the fused csm_warp_frame + csm_crop_resize_u8; frames are
     copied to the host once at the end (the reference does a 12 MB D2H per frame).
-Point-cloud inpainting (Inpaint GridNet, :441-512) is built; bokeh depth-of-field (depth_field=True, :1042-1067) is built;
-out of scope this round: ldm/patchmatch inpainting, zoe/marigold depth, Refine/CRF depth refinement inside infer_disparity.
+Point-cloud inpainting (Inpaint GridNet, :441-512), bokeh depth-of-field (depth_field=True, :1042-1067), the `Refine` depth
+refinement (:619-622) and the sniklaus `default` estimator are built; out of scope: ldm/patchmatch inpainting, CRF refinement, the
+un-vendored BEiT core of ZoeDepth and Marigold.
 """
 import math
 import os
@@ -535,8 +536,15 @@ class KenBurnsPipeline:
             frames_d = [self._scaled_frame(t) for t in imgs_d]
             seg = lambda: self.animeinsseg.infer(list(imgs_d), self.cfg.pred_score_thr, self.cfg.mask_refine_kwargs or None,
                                                  output_type='tensor', max_instances=self.max_instances)
+            # the batched estimator exists for LeReS only; any other selected estimator runs frame by frame (same results as
+            # generate_kenburns_config), still on the side stream when overlap is on
+            batched_leres = self._depth_est == self._depth_est_leres
+            def depth_of(group, slot):
+                if batched_leres:
+                    return self._depth_est_leres_batch(group, slot=slot)
+                return [self._depth_est(None, f) for f in group]
             if self.overlap_depth:
-                # LeReS only needs the images: it runs on a second HIP stream while the detector / ISNet batches (and the
+                # the depth CNN only needs the images: it runs on a second HIP stream while the detector / ISNet batches (and the
                 # detector's one host sync) occupy the main stream, so kernel tails of one net are filled by the other.
                 main = torch.cuda.current_stream(self.device)
                 k = max(1, min(self.depth_streams, len(imgs_d)))
@@ -551,7 +559,7 @@ class KenBurnsPipeline:
                     side = self._side_streams[si]
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        coarse += self._depth_est_leres_batch(grp, slot=si)
+                        coarse += depth_of(grp, si)
                 insts = seg()
                 for side in self._side_streams[:k]:
                     main.wait_stream(side)
@@ -559,7 +567,7 @@ class KenBurnsPipeline:
                     c.record_stream(main)
             else:
                 insts = seg()
-                coarse = self._depth_est_leres_batch(frames_d)
+                coarse = depth_of(frames_d, 0)
             return [self._config_from(im, inst, c, verbose, frame_dev=f) for im, inst, c, f in zip(imgs, insts, coarse, frames_d)]
 
     def _config_from(self, img, instances, coarse, verbose=False, frame_dev=None):

@@ -164,6 +164,19 @@ def resize_u8_linear(img, h, w):
     return out
 
 
+def resize_f32_linear(img, h, w):
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR) of a float32 HxWxC (or HxW) device tensor (float masks through
+    utils/io_utils.py:254-292, animeinsseg/__init__.py:47)"""
+    if not img.is_cuda or img.dtype != torch.float32:
+        raise _lib.CsmError("resize_f32_linear: float32 device tensor expected")
+    img = img.contiguous()
+    C = 1 if img.dim() == 2 else int(img.shape[2])
+    out = torch.empty((h, w) if img.dim() == 2 else (h, w, C), dtype=torch.float32, device=img.device)
+    check(_lib.load().csm_resize_f32_linear(ptr(img), i32(img.shape[0]), i32(img.shape[1]), i32(C), i32(h), i32(w), ptr(out),
+                                            stream_ptr()), "resize_f32_linear")
+    return out
+
+
 def autozoom_coverage(tenPoints, shifts, intWidth, intHeight, fltFocal, fltBaseline, chunk=None, host=True):
     """coverage counts `(tenExisting > 0.0).float().sum()` of render_pointcloud(process_shift(tenPoints, shift_k)) for every
     candidate shift_k = (sx, sy, sz) -- common.py:110-126 -- in batched launches (csm_autozoom_coverage), no colour rendered,
@@ -253,6 +266,8 @@ class WarpFrame:
         self.H, self.W, self.device = H, W, device
         self.path = path or os.environ.get('CSM_WARP_PATH', 'tiled')
         assert self.path in ('tiled', 'atomics')
+        if self.path == 'tiled' and not _lib.load().csm_warp_tile_supported(i32(H), i32(W)):
+            self.path = 'atomics'                          # more than 8192 tiles (e.g. 3840 x 2160): the global-atomic chain has no limit
         self.frame = torch.empty((H, W, 3), dtype=torch.uint8, device=device)
         self.render = torch.empty((1, 4, H, W), dtype=torch.float32, device=device) if keep_render else None
         self.scratch, self._cap = None, -1
@@ -308,14 +323,22 @@ def _percentile_linear(sorted_vals, q):
 _TAIL_SCRATCH = {}
 
 
+def ctypes_ptr(t, offset_elems):
+    """device pointer `offset_elems` elements into tensor t"""
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + offset_elems * t.element_size())
+
+
 def _tail_scratch(dev):
-    """per-device scratch of the sync-free frame tail (percentile select state + partial histograms, bokeh stats)"""
-    if dev not in _TAIL_SCRATCH:
+    """scratch of the sync-free frame tail (percentile select state + partial histograms, bokeh stats), one set per (device,
+    stream): calls on one stream are ordered, calls on different streams / threads of a device get their own state"""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _TAIL_SCRATCH:
         L = _lib.load()
-        _TAIL_SCRATCH[dev] = (torch.empty(L.csm_percentile_scratch_bytes(), dtype=torch.uint8, device=dev),
+        _TAIL_SCRATCH[key] = (torch.empty(L.csm_percentile_scratch_bytes(), dtype=torch.uint8, device=dev),
                               torch.zeros(L.csm_bokeh_depth_scratch_bytes(), dtype=torch.uint8, device=dev),   # completion counter starts at 0
                               torch.empty(2, dtype=torch.float32, device=dev))
-    return _TAIL_SCRATCH[dev]
+    return _TAIL_SCRATCH[key]
 
 
 def colorize_gray_r(tenValue):
@@ -346,16 +369,21 @@ def bokeh_blur(img, depth, num_samples=32, lightness_factor=10, depth_factor=2, 
     H, W = int(img_d.shape[0]), int(img_d.shape[1])
     n = H * W
     d8 = (depth if isinstance(depth, torch.Tensor) else torch.from_numpy(_np.ascontiguousarray(depth))).to(dev)
-    if depth_factor != 1 or d8.dtype != torch.uint8:
-        raise NotImplementedError("bokeh_blur: the hot path calls it with the uint8 colorized depth and depth_factor=1 "
-                                  "(configs/3dkenburns.yaml:47)")
+    if d8.dtype not in (torch.uint8, torch.float32):
+        d8 = d8.float()                                    # `depth.astype(np.float32)`, utils/effects.py:147
     d8 = d8.contiguous()
-    if focal_plane is None:
-        raise NotImplementedError("bokeh_blur without focal_plane is not used by the pipeline")
-    fp = float(_np.float32(focal_plane))
     dm = torch.empty((H, W), dtype=torch.float32, device=dev)
-    # depth.max(), min / max of depth.max() - |depth - focal| (utils/effects.py:146-153) from the uint8 histogram, on the device
-    check(L.csm_bokeh_depth_auto(ptr(d8), ptr(dm), i64(n), f32(fp), ptr(_tail_scratch(dev)[1]), stream_ptr()), "bokeh_depth")
+    if d8.dtype == torch.uint8 and depth_factor == 1 and focal_plane is not None:
+        # the pipeline's call (uint8 colorized depth, configs/3dkenburns.yaml:47): depth.max(), min / max of depth.max() - |depth - focal|
+        # (utils/effects.py:146-153) in closed form from the uint8 histogram, on the device
+        fp = float(_np.float32(focal_plane))
+        check(L.csm_bokeh_depth_auto(ptr(d8), ptr(dm), i64(n), f32(fp), ptr(_tail_scratch(dev)[1]), stream_ptr()), "bokeh_depth")
+    else:
+        # the reference's general form, incl. its own defaults (float depth, depth_factor = 2, focal_plane = None)
+        tmp = torch.empty(n + 4 + 512, dtype=torch.float32, device=dev)
+        check(L.csm_bokeh_depth_general(ptr(d8), i32(1 if d8.dtype == torch.uint8 else 0), i64(n), i32(0 if focal_plane is None else 1),
+                                        f32(0.0 if focal_plane is None else float(_np.float32(focal_plane))), f32(float(depth_factor)),
+                                        ptr(tmp), ctypes_ptr(tmp, n), ctypes_ptr(tmp, n + 4), ptr(dm), stream_ptr()), "bokeh_depth_general")
     hi = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     check(L.csm_bokeh_highlight(ptr(img_d), ptr(hi), i64(n * 3), f32(lightness_factor), stream_ptr()), "bokeh_highlight")
     a, b = torch.empty_like(hi), torch.empty_like(hi)

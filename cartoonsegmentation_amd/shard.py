@@ -44,3 +44,48 @@ def gather_outputs(local, n_frames, dist=None, dst=0):
                 if i < n_frames:
                     out[i] = bucket[r]
     return out if rank == dst else None
+
+
+# ---- per-frame output record: what a rank ships to rank 0 for every frame --------------------------------------
+# [ uint8 frame H*W*3 | max_inst bit-packed masks, ceil(H*W/8) bytes each (np.packbits little-endian; unused slots zero) | 8 bytes:
+#   instance count (little-endian int64) ]  -- one flat uint8 tensor per frame, equal size on every rank, so ONE gather moves it.
+def record_layout(H, W, max_inst):
+    """(frame_bytes, mask_bytes_per_instance, record_bytes)"""
+    fb, mb = H * W * 3, (H * W + 7) // 8
+    return fb, mb, fb + max_inst * mb + 8
+
+
+def write_record(rec, frame_u8, masks_bool, H, W, max_inst, pack_fn=None):
+    """fill the flat uint8 record `rec` (device or host) from a frame [H,W,3] and boolean masks [n,H,W] (n may be 0 or exceed
+    max_inst: the first max_inst are shipped, the count says how many there were).  pack_fn(mask_plane_u8, out_bytes) packs on the
+    device (csm_pack_mask_bits); None = torch reference packing (CPU tests)."""
+    fb, mb, _ = record_layout(H, W, max_inst)
+    rec[:fb].copy_(frame_u8.reshape(-1))
+    n = 0 if masks_bool is None else int(masks_bool.shape[0])
+    rec[fb:fb + max_inst * mb].zero_()
+    for k in range(min(n, max_inst)):
+        plane = masks_bool[k].reshape(-1).to(torch.uint8)
+        dst = rec[fb + k * mb: fb + (k + 1) * mb]
+        if pack_fn is not None:
+            pack_fn(plane, dst)
+        else:
+            pad = (-plane.numel()) % 8
+            p8 = torch.cat([plane, plane.new_zeros(pad)]).view(-1, 8).to(torch.int32)
+            dst.copy_((p8 << torch.arange(8, dtype=torch.int32, device=p8.device)).sum(1).to(torch.uint8))
+    cnt = torch.tensor([n], dtype=torch.int64).view(torch.uint8)
+    rec[fb + max_inst * mb:].copy_(cnt.to(rec.device))
+    return rec
+
+
+def read_record(rec, H, W, max_inst):
+    """-> (frame uint8 [H,W,3], masks bool [min(n, max_inst), H, W], n) from a flat record (host side, rank 0)"""
+    fb, mb, _ = record_layout(H, W, max_inst)
+    rec = rec.cpu()
+    n = int(rec[fb + max_inst * mb:].clone().view(torch.int64)[0])
+    frame = rec[:fb].view(H, W, 3)
+    masks = []
+    for k in range(min(n, max_inst)):
+        b = rec[fb + k * mb: fb + (k + 1) * mb].to(torch.int32)
+        bits = ((b[:, None] >> torch.arange(8, dtype=torch.int32)) & 1).reshape(-1)[:H * W]
+        masks.append(bits.bool().view(H, W))
+    return frame, (torch.stack(masks) if masks else torch.zeros((0, H, W), dtype=torch.bool)), n

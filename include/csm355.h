@@ -99,14 +99,17 @@ int csm_warp_frame(const float *pts, const float *rgb, const float *depth, int64
                    float *render_filled, uint8_t *frame_u8, void *stream);
 
 /* The same frame as csm_warp_frame with the splat done per destination tile in LDS (warptile.hip): points are binned by the
- * 32 x 32 tile(s) their footprint touches (integer atomics only), then one block per tile builds the z-buffer window, degrids,
- * z-tests, accumulates (LDS float atomics), normalises and writes the uint8 frame; holes are filled per tile from an LDS copy of
- * the valid map.  Same decisions (z-buffer, coverage, fill sources) as csm_warp_frame; colours equal up to fp32 summation order,
- * which is unordered in the reference as well.
+ * 32 x 16 tile(s) their footprint touches (integer atomics only), then one block per tile builds the z-buffer window, degrids,
+ * z-tests, accumulates into 64-bit fixed-point LDS accumulators (integer atomics: order free, a frame is bit-reproducible),
+ * normalises and writes the uint8 frame; holes are filled from row / column validity bitmaps.  Same decisions (z-buffer, coverage,
+ * fill sources) as csm_warp_frame; colours within 2^-20 absolute of the exact sum that every fp32 summation order approximates
+ * (the reference's own order is unspecified).
+ * csm_warp_tile_supported(H, W): 1 when the frame has at most 8192 tiles (up to ~2048 x 2048); larger frames use csm_warp_frame.
  * scratch: csm_warp_tile_scratch_bytes(H, W, N) bytes, 16-B aligned; its first csm_warp_tile_header_bytes(H, W) bytes must be
  * ZERO before the first call (hipMemset once after allocation) -- every call leaves them re-armed for the next frame. */
 size_t csm_warp_tile_scratch_bytes(int H, int W, int64_t N);
 size_t csm_warp_tile_header_bytes(int H, int W);
+int csm_warp_tile_supported(int H, int W);
 int csm_warp_frame_tiled(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal,
                          double baseline, float sx, float sy, float sz, void *scratch, float *render_filled, uint8_t *frame_u8,
                          void *stream);
@@ -238,6 +241,10 @@ int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_tensor_desc 
  * Instance-segmentation post-processing
  * ---------------------------------------------------------------------------------- */
 
+/* np.packbits(mask != 0, bitorder='little'): boolean instance masks (1 B per pixel, as AnimeInstances holds them) -> 1 bit per pixel,
+ * the wire format of the per-rank output gather.  out: ceil(n / 8) bytes. */
+int csm_pack_mask_bits(const uint8_t *mask, int64_t n, uint8_t *out, void *stream);
+
 /* Greedy NMS, replaces mmcv.ops.batched_nms -> nms (C++/CUDA ext; call site: mmdet head, imported at
  * animeinsseg/models/rtmdet_inshead_custom.py:10).  boxes [n,4] xyxy sorted by descending score;
  * class_offsets [n] (label * (max_coord+1)) or NULL for class-agnostic / single class;
@@ -285,6 +292,9 @@ int csm_det_preprocess(const uint8_t *img_hwc, int H, int W, int rh, int rw, int
 /* utils/io_utils.py:254-274 scaledown_maxsize (the frame itself: kenburns_effect.py:917): cv2.resize(INTER_LINEAR) of a uint8
  * HWC image [H,W,C] (C <= 4) to [h,w,C]; the host applies the size rule. */
 int csm_resize_u8_linear(const uint8_t *src_hwc, int H, int W, int C, int h, int w, uint8_t *dst_hwc, void *stream);
+/* the same for float32 images / masks (resize_pad(seg, ...) of prepare_refine_batch, animeinsseg/__init__.py:47): cv2's float
+ * INTER_LINEAR -- horizontal then vertical linear pass in fp32 */
+int csm_resize_f32_linear(const float *src_hwc, int H, int W, int C, int h, int w, float *dst_hwc, void *stream);
 /* kenburns_effect.py:563-571 + depth_modules/leres/leres/depthmap.py:16-38: BGR u8 HWC [H,W,3] -> cv2 INTER_LINEAR to
  * (h,w) -> /255 -> RGB -> (x-mean)/std (ImageNet) -> fp32 NCHW [1,3,h,w] */
 int csm_leres_input(const uint8_t *img_hwc, int H, int W, int h, int w, float *out, void *stream);
@@ -336,6 +346,12 @@ int csm_bokeh_finish(const float *diag_hwc, const float *rhom_hwc, uint8_t *out_
 /* depth map of bokeh_blur  utils/effects.py:146-153,162-163: out = (1 - ((dmax - |d - focal|) - mn) / mx2) * 0.0005 ;
  * dmax = max(d), mn = min(dmax - |d-focal|), mx2 = max(that - mn) are scalar reductions supplied by the caller. */
 int csm_bokeh_depth(const uint8_t *depth_u8, float *out, int64_t n, float dmax, float focal_plane, float mn, float mx2, void *stream);
+/* The same map for the reference's own call forms (utils/effects.py:143-153 defaults: float depth, depth_factor = 2, focal_plane =
+ * None): depth is float32 (is_u8 = 0, 16-B aligned) or uint8 (is_u8 = 1); has_focal selects `max(d) - |d - focal_plane|`;
+ * depth_factor != 1 applies np.power (2 -> square, else powf).  tmp [n] floats, mm4 [4] floats and scratch512 [512] floats are
+ * device scratch; all reductions stay on the device (no host sync). */
+int csm_bokeh_depth_general(const void *depth, int is_u8, int64_t n, int has_focal, float focal_plane, float depth_factor,
+                            float *tmp, float *mm4, float *scratch512, float *out, void *stream);
 /* colorize(value, cmap='gray_r')[...,0]  depth_modules/zoedepth/utils/misc.py:97-135 (vmin/vmax = 2nd/85th percentile) */
 int csm_colorize_gray_r(const float *value, uint8_t *out, int64_t n, float vmin, float vmax, void *stream);
 

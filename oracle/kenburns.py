@@ -194,12 +194,15 @@ def colorize_gray_r(value):
     return gray_r_lut()[np.clip(k, 0, 255)]
 
 
-def bokeh_blur(img, depth_u8, num_samples, lightness_factor, focal_plane):
-    """utils/effects.py:143-181 (use_cuda branch, depth_factor == 1)"""
+def bokeh_blur(img, depth_u8, num_samples, lightness_factor, focal_plane, depth_factor=1):
+    """utils/effects.py:143-181 (use_cuda branch); depth may be uint8 or float, focal_plane may be None"""
     L = oseg.lib()
     H, W = img.shape[:2]
     d = depth_u8.astype(np.float32)
-    d = d.max() - np.abs(d - np.float32(focal_plane))
+    if focal_plane is not None:
+        d = d.max() - np.abs(d - np.float32(focal_plane))
+    if depth_factor != 1:
+        d = np.power(d, depth_factor)
     d = d - d.min()
     d = d.astype(np.float32) / d.max()
     d = ((np.float32(1) - d) * np.float32(0.0005)).astype(np.float32)

@@ -252,6 +252,24 @@ void orc_resize_u8_linear(const uint8_t *src, int H, int W, int C, int h, int w,
         }
 }
 
+/* cv2.resize(float32 HWC, INTER_LINEAR) -- utils/io_utils.py:254-292 on float masks (animeinsseg/__init__.py:47) [EXT: OpenCV
+ * resize.cpp float path restated: HResizeLinear then VResizeLinear in fp32] */
+void orc_resize_f32_linear(const float *src, int H, int W, int C, int h, int w, float *dst)
+{
+    double sy = (double)H / h, sx = (double)W / w;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int y0, y1, x0, x1; float fy, fx;
+            cv_src(y, H, sy, &y0, &y1, &fy); cv_src(x, W, sx, &x0, &x1, &fx);
+            float a0 = 1.0f - fx, a1 = fx, b0 = 1.0f - fy, b1 = fy;
+            for (int c = 0; c < C; ++c) {
+                float r0 = src[((int64_t)y0 * W + x0) * C + c] * a0 + src[((int64_t)y0 * W + x1) * C + c] * a1;
+                float r1 = src[((int64_t)y1 * W + x0) * C + c] * a0 + src[((int64_t)y1 * W + x1) * C + c] * a1;
+                dst[((int64_t)y * w + x) * C + c] = r0 * b0 + r1 * b1;
+            }
+        }
+}
+
 /* cv2.resize(u8, INTER_LANCZOS4) -> float32 [EXT: OpenCV 4.10 resize.cpp restated, see imageops.hip] */
 static void orc_lanczos4_q11(float x, int c[8])
 {

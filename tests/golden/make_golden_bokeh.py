@@ -44,3 +44,16 @@ one = fx.ftensor2img(fx.bokeh_filter_cupy(t_img, t_d, np.cos(-np.pi / 6), np.sin
 np.savez_compressed(os.path.join(HERE, 'bokeh_240x320.npz'), img=img, depth_f=depth_f, depth_u8=depth_u8, dn=dn,
                     one_pass=one, **out)
 print('ok', depth_u8.min(), depth_u8.max(), out['blur_fp100'].shape, out['blur_fp100'].dtype, np.abs(out['blur_fp100'].astype(int) - img).mean())
+
+# ---- bokeh_blur with the reference's OWN defaults (utils/effects.py:143: depth_factor=2, lightness_factor=10, focal_plane=None) on a
+# float depth map, and float depth + focal plane + depth_factor 2 / 3.  use_cuda=True: the kernel_bokeh text (the use_cuda=False twin
+# is a numba-compiled loop whose typing cannot be reproduced without numba; both implement the same sampling rule)
+H2, W2 = 96, 128
+img2 = synth.image_u8(H2, W2, 10)
+yy, xx = np.mgrid[0:H2, 0:W2].astype(np.float32)
+depth2 = (2.0 + 0.02 * yy + 1.5 / (1.0 + np.exp((np.hypot(xx - 60, yy - 40) - 25) / 1.5))).astype(np.float32)
+out2 = {'blur_defaults': fx.bokeh_blur(img2, depth2, use_cuda=True),
+        'blur_focal_f2': fx.bokeh_blur(img2, depth2, 32, 10, 2, True, focal_plane=3.0),
+        'blur_u8_f3': fx.bokeh_blur(img2, (depth2 * 60).astype(np.uint8), 16, 8, 3, True, focal_plane=None)}
+np.savez_compressed(os.path.join(HERE, 'bokeh_defaults_96x128.npz'), img=img2, depth=depth2, **out2)
+print('ok defaults', {k: float(np.abs(v.astype(int) - img2).mean()) for k, v in out2.items()})

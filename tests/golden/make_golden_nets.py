@@ -96,6 +96,20 @@ def inpaint_case():
     print('inpaint', float(out['tenExisting'].mean()), float(out['tenImage'].mean()), float(out['tenDisparity'].mean()))
 
 
+def refine_case():
+    """Refine.forward of anime_3dkenburns/models/disparity_refinement.py:97-126 (the depth refinement of kenburns_effect.py:619-622):
+    image at the frame size, disparity at a quarter of it (the reference's own usage: the estimator output is smaller than the frame)"""
+    m = ref_loader.load_by_path("anime_3dkenburns.models.disparity_refinement", "anime_3dkenburns/models/disparity_refinement.py")
+    net = fill_synthetic(m.Refine(), 'refine.')
+    g = np.random.default_rng(5)
+    img = g.uniform(0, 1, (1, 3, 48, 64)).astype(np.float32)
+    dsp = g.uniform(1, 40, (1, 1, 12, 16)).astype(np.float32)
+    with torch.no_grad():
+        y = net(torch.from_numpy(img), torch.from_numpy(dsp))
+    np.savez_compressed(os.path.join(HERE, 'net_refine_48x64.npz'), img=img, dsp=dsp, y=y.numpy())
+    print('refine', float(y.mean()), float(y.std()))
+
+
 def disparity_case():
     """Semantics (VGG19-BN slices) + Disparity GridNet of anime_3dkenburns/models/disparity_estimation.py.  torchvision is absent:
     `torchvision.models.vgg19_bn` is supplied with torchvision's published cfg 'E' + batch norm ([EXT]); which of its entries are
@@ -197,4 +211,6 @@ if __name__ == '__main__':
         leres_cases()
     if 'inpaint' in which:
         inpaint_case()
+    if 'refine' in which:
+        refine_case()
 

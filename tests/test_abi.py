@@ -69,6 +69,22 @@ local = [torch.full((2, 3), float(i) * w[1].item()) for i in mine]
 out = shard.gather_outputs(local, n, dist)
 if rank == 0:
     assert len(out) == n and all(float(out[i][0, 0]) == float(i) for i in range(n)), out
+# per-frame output records: uint8 frame + bit-packed instance masks + count, one flat tensor per frame (SURVEY 8e item 2)
+H, W, MI = 10, 13, 3
+g = torch.Generator().manual_seed(7)
+frames = [torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, generator=g) for _ in range(n)]
+masks = [torch.rand((i % 5, H, W), generator=g) > 0.5 for i in range(n)]            # 0..4 instances: empty and over-full cases
+_, _, rb = shard.record_layout(H, W, MI)
+recs = [shard.write_record(torch.empty(rb, dtype=torch.uint8), frames[i], masks[i], H, W, MI) for i in mine]
+got = shard.gather_outputs(recs, n, dist)
+if rank == 0:
+    for i in range(n):
+        f, m, cnt = shard.read_record(got[i], H, W, MI)
+        assert torch.equal(f, frames[i]) and cnt == masks[i].shape[0] and torch.equal(m, masks[i][:MI]), i
+    import numpy as np
+    r0 = shard.write_record(torch.empty(rb, dtype=torch.uint8), frames[4], masks[4], H, W, MI)
+    fb, mb, _ = shard.record_layout(H, W, MI)
+    assert np.array_equal(r0[fb:fb + mb].numpy(), np.packbits(masks[4][0].numpy().reshape(-1), bitorder='little'))
     print("GATHER_OK")
 dist.barrier(); dist.destroy_process_group()
 '''

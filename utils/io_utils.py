@@ -51,10 +51,16 @@ def scaledown_maxsize(img, max_size: int, divisior: int = None):
     if (h, w) == (h0, w0):
         return img
     if isinstance(img, torch.Tensor):
-        return ops.resize_u8_linear(img, h, w)
-    if img.dtype != np.uint8:
-        raise NotImplementedError("scaledown_maxsize: uint8 images (float masks are resized inside csm_refine_prepare_batch)")
-    return ops.resize_u8_linear(torch.from_numpy(np.ascontiguousarray(img)).cuda(), h, w).cpu().numpy()
+        if img.dtype == torch.uint8:
+            return ops.resize_u8_linear(img, h, w)
+        return ops.resize_f32_linear(img.float(), h, w).to(img.dtype if img.is_floating_point() else torch.float32)
+    if img.dtype == np.uint8:
+        return ops.resize_u8_linear(torch.from_numpy(np.ascontiguousarray(img)).cuda(), h, w).cpu().numpy()
+    if img.dtype == np.bool_:
+        raise TypeError("scaledown_maxsize: cv2.resize does not take bool arrays either -- pass uint8 or float32 masks")
+    # float masks / images (prepare_refine_batch calls resize_pad(seg, ...), animeinsseg/__init__.py:47): cv2's float INTER_LINEAR
+    out = ops.resize_f32_linear(torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).cuda(), h, w).cpu().numpy()
+    return out.astype(img.dtype) if img.dtype in (np.float64, np.float16) else out
 
 
 def resize_pad(img, tgt_size: int, pad_value=(0, 0, 0)):
