@@ -208,14 +208,8 @@ class FrameWorkload(Workload):
         # every rank builds the same closed-form weights (a rank with placeholder zeros finds no instance, builds no ISNet and
         # would take part in fewer broadcasts); the RCCL broadcast from rank 0 then overwrites them, as it would real checkpoints
         from cartoonsegmentation_amd import ops, synth
-        from cartoonsegmentation_amd.kenburns import KenBurnsConfig, KenBurnsPipeline
         self.ops, self.H, self.W, self.device = ops, size, size, device
-        cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=640, max_size=size,
-                             refine_crf=False, depth_field=False, focal=size / 2.0,
-                             mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 720})
-        self.pipe = KenBurnsPipeline(cfg, device=str(device))
-        self.pipe.max_instances = self.INSTANCES          # synthetic weights score every prior ~0.49: cap like infer(max_instances=)
-        self.pipe.overlap_depth = os.environ.get("CSM_OVERLAP_DEPTH", "1") == "1"
+        self.pipe = self.make_pipe()
         self.all_imgs = [torch.from_numpy(synth.image_u8(size, size, 1234 + 64 * rank + k)).to(device) for k in range(max(batch, 16))]
         self.imgs = self.all_imgs[:batch]
         self.wf = ops.WarpFrame(size, size, device)
@@ -223,30 +217,72 @@ class FrameWorkload(Workload):
         self.n_inst = None
 
     def step(self):
+        self.n_inst = self.run_frames(self.pipe, self.wf, self.imgs, self.records)
+        return self.records[:self.frames_per_step, :self.fb]
+
+    def run_frames(self, pipe, wf, imgs, records):
+        """the hot path over `imgs` (one step): seg + depth -> point cloud -> one warp + crop/resize per frame, outputs (uint8 frame,
+        bit-packed instance masks, count) written into `records`; returns the instance count of the first frame"""
         from cartoonsegmentation_amd._lib import load, ptr, stream_ptr, i32, i64, f32, check
-        pipe = self.pipe
-        if self.frames_per_step == 1:
-            kcs = [pipe.generate_kenburns_config(self.imgs[0])]     # seg (main stream) || LeReS (side stream)
+        if len(imgs) == 1:
+            kcs = [pipe.generate_kenburns_config(imgs[0])]     # seg (main stream) || LeReS (side stream)
         else:
-            kcs = pipe.generate_kenburns_configs(self.imgs)         # batched detector / refine / LeReS, per-frame glue
-        self.n_inst = len(kcs[0].instances)
+            kcs = pipe.generate_kenburns_configs(imgs)         # batched detector / refine / LeReS, per-frame glue
         for k, kc in enumerate(kcs):
             W, H = kc['intWidth'], kc['intHeight']
             d_from = kc['objDepthrange'][0]
             shift = self.ops.shift_vector({'fltShiftU': 30.0, 'fltShiftV': -20.0, 'fltDepthFrom': d_from, 'fltDepthTo': d_from / 1.25}, kc)
-            frame, _ = self.wf(kc['tenInpaPoints'], kc.inpainted_img, kc['tenInpaDepth'], kc['fltFocal'], kc['fltBaseline'], shift)
+            frame, _ = wf(kc['tenInpaPoints'], kc.inpainted_img, kc['tenInpaDepth'], kc['fltFocal'], kc['fltBaseline'], shift)
             pw, ph = int(0.97 * W), int(0.97 * H)
-            check(load().csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0), ptr(self.frame_slot(k)),
-                                            stream_ptr()))
+            rec = records[k]
+            check(load().csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0), ptr(rec), stream_ptr()))
             # the frame's instance masks join its output record bit-packed (SURVEY 8e: frame + packed masks travel to rank 0)
-            rec, masks = self.records[k], kc.instances.masks
+            masks = kc.instances.masks
             n = 0 if kc.instances.is_empty else int(masks.shape[0])
             for j in range(min(n, self.MAX_INST)):
                 check(load().csm_pack_mask_bits(ptr(masks[j].view(torch.uint8)), i64(H * W), ptr(rec[self.fb + j * self.mb:]), stream_ptr()))
             if n < self.MAX_INST:
                 rec[self.fb + n * self.mb: self.fb + self.MAX_INST * self.mb].zero_()
             rec[self.fb + self.MAX_INST * self.mb:].copy_(self.count_words[min(n, 4095)])
-        return self.records[:self.frames_per_step, :self.fb]
+        return len(kcs[0].instances)
+
+    def make_pipe(self):
+        from cartoonsegmentation_amd.kenburns import KenBurnsConfig, KenBurnsPipeline
+        size = self.H
+        cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=640, max_size=size,
+                             refine_crf=False, depth_field=False, focal=size / 2.0,
+                             mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 720})
+        pipe = KenBurnsPipeline(cfg, device=str(self.device))
+        pipe.max_instances = self.INSTANCES          # synthetic weights score every prior ~0.49: cap like infer(max_instances=)
+        pipe.overlap_depth = os.environ.get("CSM_OVERLAP_DEPTH", "1") == "1"
+        return pipe
+
+    def _fps_lanes(self, batch, lanes, steps=4):
+        """frames/s with `lanes` steps in flight (cartoonsegmentation_amd/lanes.py): every lane is a thread with its own pipeline
+        object, streams, warp scratch and output records; a step's frames are computed exactly as in step()"""
+        from cartoonsegmentation_amd.lanes import FrameLanes
+        imgs_all = self.all_imgs
+
+        def make_worker(i):
+            pipe, wf = self.make_pipe(), self.ops.WarpFrame(self.H, self.W, self.device)
+            records = torch.zeros((batch, self.rb), dtype=torch.uint8, device=self.device)
+            self.run_frames(pipe, wf, imgs_all[:batch], records)          # builds this lane's programs (tiles come from the shared table)
+            torch.cuda.current_stream().synchronize()
+            return lambda imgs: self.run_frames(pipe, wf, imgs, records)
+        self._fps(batch=batch, steps=1)                                   # the main pipeline has tuned every layer of this batch size
+        fl = FrameLanes(make_worker, lanes, self.device)
+        try:
+            jobs = [[imgs_all[(j * batch + q) % len(imgs_all)] for q in range(batch)] for j in range(lanes * steps)]
+            fl.map(jobs[:lanes]); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fl.map(jobs)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            fl.close()
+        return {"frames_per_s": round(len(jobs) * batch / dt, 2), "ms_per_frame": round(dt / (len(jobs) * batch) * 1e3, 3), "batch": batch,
+                "lanes": lanes, "what": "%d steps of %d frame(s) in flight on %d host threads / stream sets (FrameLanes); each frame "
+                                        "computed as in the serial loop" % (lanes, batch, lanes)}
 
     # ---- extra single-GPU measurements (SURVEY 8d: batch 1 = BASELINE configs[1..2], n instances in {1, 8}, det 1024, the video) ----
     def _fps(self, batch=None, instances=None, det=None, steps=3, conv_roofline=False):
@@ -328,10 +364,33 @@ class FrameWorkload(Workload):
                 alg = 155.0 * size * size                       # B_warp = 155 P bytes per frame for N = P, C = 4
                 out["%s_%d" % (path, size)] = {"us_per_frame": round(ms * 1e3, 2), "algorithmic_bytes": alg,
                                                "GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            # the same chain with consecutive frames on 3 HIP streams (own scratch each), as KenBurnsPipeline.process_kenburns issues
+            # them: frame k + 1's binning runs under frame k's render / hole fill.  Same kernels, same frames; throughput, not latency.
+            main = torch.cuda.current_stream(self.device)
+            lanes = [(torch.cuda.Stream(self.device), self.ops.WarpFrame(size, size, self.device, path="tiled")) for _ in range(3)]
+            def rr(n):
+                for st, _ in lanes:
+                    st.wait_stream(main)
+                for k in range(n):
+                    st, wf = lanes[k % 3]
+                    with torch.cuda.stream(st):
+                        wf(pts, rgb, dep, sc['focal'], sc['baseline'], shift)
+                for st, _ in lanes:
+                    main.wait_stream(st)
+            rr(9); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); rr(60); e1.record(); e1.synchronize()
+            ms = e0.elapsed_time(e1) / 60
+            alg = 155.0 * size * size
+            out["tiled_%d_3streams" % size] = {"us_per_frame": round(ms * 1e3, 2), "GBps": round(alg / (ms * 1e-3) / 1e9, 1),
+                                               "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                               "what": "60 frames round-robin over 3 streams with their own scratch (the video loop's issue order)"}
         return out
 
     def variants(self):
-        v = {"batch1": self._fps(batch=1, conv_roofline=True), "batch16": self._fps(batch=16, conv_roofline=True), "instances1": self._fps(instances=1),
+        v = {"batch1": self._fps(batch=1, conv_roofline=True), "batch1_lanes2": self._fps_lanes(1, 2, steps=8), "batch1_lanes3": self._fps_lanes(1, 3, steps=8),
+             "batch8_lanes2": self._fps_lanes(8, 2, steps=3),
+             "batch16": self._fps(batch=16, conv_roofline=True), "instances1": self._fps(instances=1),
              "instances8": self._fps(instances=8), "instances100_batch1": self._fps(batch=1, instances=100, steps=2),
              "det1024_batch4": self._fps(batch=4, det=1024), "video": self._video(),
              "warp_chain": self._warp_points()}

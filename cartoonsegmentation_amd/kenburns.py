@@ -197,6 +197,9 @@ class KenBurnsPipeline:
         self._side_stream = None
         self._side_streams = []
         self.depth_streams = int(os.environ.get('CSM_DEPTH_STREAMS', '1'))   # batched path: LeReS sub-batches on this many side streams
+        self.frame_streams = int(os.environ.get('CSM_FRAME_STREAMS', '3'))   # process_kenburns: output frames in flight (1 = the serial loop)
+        self._frame_streams = []
+        self._lane_wf = {}
         self.set_detector(cfg.detector)
         self.set_depth_estimation(cfg.depth_est)
         if self.cfg.default_depth_refine:
@@ -631,6 +634,21 @@ class KenBurnsPipeline:
                                                'objTo': objTo, 'boolInpaint': True}, cfg, inpaint, verbose)
             return frames
 
+    def _focal_end(self, depth_u8, ins):
+        """kenburns_effect.py:1045-1056: the largest per-instance MEDIAN of the colourised depth (np.median: mean of the two middle
+        order statistics for even counts), the plane the depth of field settles on"""
+        focal_end = -1
+        for m in ins.masks:
+            vals = depth_u8[m.to(self.device)]
+            if vals.numel() == 0:
+                continue
+            sv_, _ = torch.sort(vals)
+            nn_ = sv_.numel()
+            dm = float(sv_[nn_ // 2].item()) if nn_ % 2 else (float(sv_[nn_ // 2 - 1].item()) + float(sv_[nn_ // 2].item())) / 2.0
+            if dm > focal_end:
+                focal_end = dm
+        return focal_end
+
     # ---- frame loop (kenburns_effect.py:979-1081) -----------------------------------------------------------------
     def process_kenburns(self, objSettings, objCommon: KenBurnsConfig, inpaint: bool = True, verbose: bool = False,
                          to_numpy: bool = True):
@@ -661,6 +679,21 @@ class KenBurnsPipeline:
                     self.inpaint(1.1 * tenShift, None, objCommon, verbose)
                 objCommon._inpaint_shared = None                   # the features shared by the two passes (285 MB at 1024^2) are dead now
             pts, rgb, dep = objCommon['tenInpaPoints'].contiguous(), objCommon.inpainted_img.contiguous(), objCommon['tenInpaDepth'].contiguous()
+            # MI355X: the frames of a video are independent (same cloud, different shift) and a frame is a chain of ~20 short,
+            # latency-bound kernels (bin -> render -> holes -> percentiles -> bokeh passes -> crop), so consecutive frames go to
+            # `frame_streams` HIP streams round-robin, each with its own warp scratch: frame k + 1's binning runs under frame k's hole
+            # fill / bokeh tail.  Every frame's kernels and results are those of the one-stream loop (kenburns_effect.py:1015-1072).
+            main = torch.cuda.current_stream(self.device)
+            ns = max(1, min(self.frame_streams, len(steps)))
+            while len(self._frame_streams) < ns:
+                self._frame_streams.append(torch.cuda.Stream(self.device))
+            def lane_wf(i):                                                      # warp scratch per lane, kept across videos of one size
+                key = (H, W, bool(objCommon.depth_field), i)
+                if key not in self._lane_wf:
+                    self._lane_wf = {kk: v for kk, v in self._lane_wf.items() if kk[:3] == key[:3]}    # another size: drop the old sets
+                    self._lane_wf[key] = ops.WarpFrame(H, W, self.device, keep_render=bool(objCommon.depth_field))
+                return self._lane_wf[key]
+            lanes = [(main if ns == 1 else self._frame_streams[i], wf if i == 0 else lane_wf(i)) for i in range(ns)]
             for k, fltStep in enumerate(steps):
                 fltFrom = 1.0 - fltStep
                 fltTo = 1.0 - fltFrom
@@ -670,29 +703,28 @@ class KenBurnsPipeline:
                 d_from = objCommon['objDepthrange'][0]
                 d_to = d_from * (cwid / max(oF['intCropWidth'], oT['intCropWidth']))
                 shift = ops.shift_vector({'fltShiftU': su, 'fltShiftV': sv, 'fltDepthFrom': d_from, 'fltDepthTo': d_to}, objCommon)
-                frame, render = wf(pts, rgb, dep, objCommon['fltFocal'], objCommon['fltBaseline'], shift)
-                if objCommon.depth_field:                                         # kenburns_effect.py:1042-1067
-                    depth_u8 = ops.colorize_gray_r(render[0, 3])
-                    if k == 0:
-                        ins = objCommon.instances
-                        if ins is not None and not ins.is_empty:
-                            focal_end = -1
-                            for m in ins.masks:
-                                vals = depth_u8[m.to(self.device)]
-                                if vals.numel() == 0:
-                                    continue
-                                sv_, _ = torch.sort(vals)
-                                nn_ = sv_.numel()
-                                dm = float(sv_[nn_ // 2].item()) if nn_ % 2 else (float(sv_[nn_ // 2 - 1].item()) + float(sv_[nn_ // 2].item())) / 2.0
-                                if dm > focal_end:
-                                    focal_end = dm
-                            focal_start = 255 if abs(255 - focal_end) > abs(0 - focal_end) else 0
-                    focal_int = 1 / (1 + np.exp((0.5 - fltStep) * objCommon.dof_speed))
-                    focal_plane = focal_int * focal_end + (1 - focal_int) * focal_start
-                    frame = ops.bokeh_blur(frame, depth_u8, 32, objCommon.lightness_factor, focal_plane=focal_plane, use_cuda=True,
-                                           depth_factor=objCommon.depth_factor)
-                check(L.csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0),
-                                           ptr(out[k]), stream_ptr()), "crop_resize")
+                if k == 1 and ns > 1:
+                    for st_, _ in lanes:                                         # frame 0 (focal-plane statistics) ran on the caller's stream
+                        st_.wait_stream(main)
+                st_k, wf_k = (main, lanes[0][1]) if (k == 0 or ns == 1) else lanes[k % ns]
+                with torch.cuda.stream(st_k):
+                    frame, render = wf_k(pts, rgb, dep, objCommon['fltFocal'], objCommon['fltBaseline'], shift)
+                    if objCommon.depth_field:                                         # kenburns_effect.py:1042-1067
+                        depth_u8 = ops.colorize_gray_r(render[0, 3])
+                        if k == 0:
+                            ins = objCommon.instances
+                            if ins is not None and not ins.is_empty:
+                                focal_end = self._focal_end(depth_u8, ins)
+                                focal_start = 255 if abs(255 - focal_end) > abs(0 - focal_end) else 0
+                        focal_int = 1 / (1 + np.exp((0.5 - fltStep) * objCommon.dof_speed))
+                        focal_plane = focal_int * focal_end + (1 - focal_int) * focal_start
+                        frame = ops.bokeh_blur(frame, depth_u8, 32, objCommon.lightness_factor, focal_plane=focal_plane, use_cuda=True,
+                                               depth_factor=objCommon.depth_factor)
+                    check(L.csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0),
+                                               ptr(out[k]), stream_ptr()), "crop_resize")
+            if ns > 1:
+                for st_, _ in lanes:
+                    main.wait_stream(st_)
             frames = [f for f in out.cpu().numpy()] if to_numpy else out
             return [frames, objCommon]
 

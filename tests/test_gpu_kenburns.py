@@ -473,3 +473,49 @@ def test_io_utils_float_masks_and_large_frame_fallback():
     frame, _ = wf(pts.view(1, 3, -1), torch.from_numpy(sc['rgb']).cuda(), depth.view(1, 1, -1), sc['focal'], sc['baseline'], [3.0, -2.0, -5.0])
     torch.cuda.synchronize()
     assert frame.shape == (H, W, 3) and float(frame.float().mean()) > 1.0
+
+
+def test_frame_streams_and_lanes_give_the_serial_results():
+    """MI355X scheduling additions are invisible in the results: (i) process_kenburns with consecutive frames on 3 HIP streams ==
+    the one-stream loop, byte for byte, with and without the bokeh tail; (ii) FrameLanes (frames in flight on several host threads,
+    each with its own pipeline object) == the serial per-frame loop"""
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd import synth
+    from cartoonsegmentation_amd.lanes import FrameLanes
+
+    def make():
+        cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='leres', depth_est_size=96, max_size=512, refine_crf=False, focal=160.0,
+                             num_frame=7, mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 64})
+        p = KenBurnsPipeline(cfg)
+        p.max_instances = 2
+        p.animeinsseg.set_detect_size(96)
+        return p
+    pipe = make()
+    img = synth.image_u8(320, 352, 61)
+    res = {}
+    for dof in (False, True):
+        for ns in (1, 3):
+            pipe.frame_streams = ns
+            kc = pipe.generate_kenburns_config(img)
+            kc.depth_field = dof
+            res[(dof, ns)] = np.stack(pipe.autozoom(kc, inpaint=False))
+        assert np.array_equal(res[(dof, 1)], res[(dof, 3)]), dof
+    assert not np.array_equal(res[(False, 1)], res[(True, 1)])
+    imgs = [synth.image_u8(320, 352, 70 + k) for k in range(5)]
+
+    def one(p, im):
+        kc = p.generate_kenburns_config(im)
+        return (kc['tenRawPoints'].clone(), kc.instances.masks.clone(), kc['objDepthrange'])
+    serial = [one(pipe, im) for im in imgs]
+
+    def make_worker(i):
+        p = make()
+        return lambda im: one(p, im)
+    fl = FrameLanes(make_worker, lanes=2)
+    try:
+        par = fl.map(imgs)
+    finally:
+        fl.close()
+    for a, b in zip(serial, par):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
