@@ -114,6 +114,8 @@ struct ConvArgs {
     int ksplit;                        // >1: blockIdx.z = g*ksplit + s, raw partial sums go to `partial`
     float *partial;                    // [M][ksplit*cout] (groups == 1 only)
     int serial;                        // ksplit > 1 only: 1 = one block walks all runs and combines them in registers (SER kernels)
+    int m_begin;                       // k_conv_dma: first output row of this launch (rows [m_begin, M)); 0 unless the launch is split
+    int split;                         // launcher hint: cover the last partial round of the grid with small tiles (see launch_conv_dma_t)
     int dbg;                           // tuning aid: 1 = no global loads, 2 = no MFMA, 4 = no LDS stores, 8 = no epilogue stores
 };
 
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 
     int mt, ntile, zz;
     block_to_tile(mt, ntile, zz);
-    const int m0 = mt * BM, n0 = ntile * BN;
+    const int m0 = a.m_begin + mt * BM, n0 = ntile * BN;
     const int g = SER ? zz : zz / a.ksplit, ks = SER ? 0 : zz - g * a.ksplit;
     const int ho = a.out.h, wo = a.out.w;
     const int cin_off = g * a.cin_g, cout_off = g * a.cout_g;
@@ -484,6 +486,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         if (++l_kw == a.kw) { l_kw = 0; if (++l_kh == a.kh) { l_kh = 0; l_tap = 0; ++l_cb; } }
     };
 
+#ifdef CSM_CONV_PREFETCH
+    // L2 warm-up: one byte per 16-B slot of the chunk at the loader position (= the chunk AFTER the one whose DMA was just issued).
+    // The DMA for those lines goes out one chunk time later and then hits L2 instead of waiting for HBM inside the two-stage window.
+    // Always GA + GB instructions (dead lanes are out of range), so the loop's counted wait stays exact.
+    auto prefetch = [&](bool live) {
+        const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
+        unsigned dummy;
+#pragma unroll
+        for (int p = 0; p < GA; ++p)
+            asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=v"(dummy)
+                         : "v"((live && ((vmA[p] >> l_tap) & 1u)) ? offA[p] + coff : kOob), "s"(ra) : "memory");
+#pragma unroll
+        for (int p = 0; p < GB; ++p)
+            asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=v"(dummy)
+                         : "v"((live && offB[p] != kOob) ? offB[p] + l_w : kOob), "s"(rb) : "memory");
+    };
+#endif
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -536,10 +556,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 
     if constexpr (NS == 2) {
         issue(0);
+#ifdef CSM_CONV_PREFETCH
+        prefetch(c_begin + 1 < T);
+#endif
         for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
+#ifdef CSM_CONV_PREFETCH
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GA + GB) : "memory");   // loads retire in order: only the newest warm-up may be out
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of `chunk` have landed ...
+#endif
             __builtin_amdgcn_s_barrier();                          // ... everybody's have, and everybody is done reading stage st^1
             if (chunk + 1 < T) issue(st ^ 1);
+#ifdef CSM_CONV_PREFETCH
+            prefetch(chunk + 2 < T);
+#endif
             compute(st, chunk);
         }
     } else {
@@ -1377,16 +1407,49 @@ int launch_conv(const ConvArgs &a, hipStream_t st) {
     return full ? launch_conv_k<MT, WM, WN, TN, true, false>(a, st) : launch_conv_k<MT, WM, WN, TN, false, false>(a, st);
 }
 
+// Grid quantisation: a launch of `total` equal tiles on S = 256 x (blocks per CU) slots takes ceil(total / S) rounds; with 3.1 rounds
+// (the 40 x 40 x 1024 layers of ResNeXt at batch 8: 800 tiles of 128 x 128) a quarter of the machine time is an almost empty fourth
+// round.  Every tile configuration produces the same bits, so a launch may MIX them: when `split` is set the big tiles cover whole
+// rounds only and the remaining rows (less than ~0.6 of a round) are covered by a second launch of 64 x 64 tiles, which spreads
+// them over all CUs.  Speed only; chosen per layer by the autotuner (csm_op.tile bit 7).
+static int conv_split_rows(const ConvArgs &a, int BM, int BN, int blocks_per_cu) {
+    const int64_t n_n = (int64_t)((a.cout_g + BN - 1) / BN) * a.groups * ((a.ksplit > 1 && !a.serial) ? a.ksplit : 1);
+    const int64_t m_tiles = (a.M + BM - 1) / BM, slots = 256ll * (blocks_per_cu > 0 ? blocks_per_cu : 1);
+    const double rounds = (double)(m_tiles * n_n) / (double)slots;
+    const int64_t full = (int64_t)rounds;
+    const double frac = rounds - (double)full;
+    if (full < 1 || frac < 0.02 || frac > 0.6) return 0;
+    const int64_t mt_main = full * slots / n_n;
+    if (mt_main <= 0 || mt_main >= m_tiles) return 0;
+    return (int)(mt_main * BM);
+}
+
 template <int WM, int WN, int TM, int TN, int NS, bool SER>
 int launch_conv_dma_t(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgs a = a0;
-    a.m_tiles = (a.M + BM - 1) / BM;
     size_t lds = (size_t)NS * (BM + BN) * 128;
     static unsigned prepared = 0;
-    if (first_use_on_device(prepared))
+    static int blocks_per_cu = 0;
+    if (first_use_on_device(prepared)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma<WM, WN, TM, TN, NS, SER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_dma<WM, WN, TM, TN, NS, SER>),
+                                                         64 * WM * WN, lds) == hipSuccess && nb > 0) blocks_per_cu = nb;
+    }
+    if (a.split && (BM > 64 || BN > 64) && (a.ksplit <= 1 || SER)) {
+        const int rows = conv_split_rows(a, BM, BN, blocks_per_cu);
+        if (rows > 0) {
+            ConvArgs tail = a;
+            tail.m_begin = a.m_begin + rows; tail.split = 0;
+            a.M = a.m_begin + rows; a.split = 0;
+            int rc = launch_conv_dma_t<WM, WN, TM, TN, NS, SER>(a, st);
+            if (rc) return rc;
+            return launch_conv_dma_t<2, 2, 1, 1, 2, SER>(tail, st);
+        }
+    }
+    a.m_tiles = (a.M - a.m_begin + BM - 1) / BM;
     dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * (SER ? 1 : a.ksplit));
     k_conv_dma<WM, WN, TM, TN, NS, SER><<<grid, 64 * WM * WN, lds, st>>>(a);
     int rc = csm::check_launch("k_conv_dma");
@@ -1460,8 +1523,10 @@ enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CF
        CFG_COUNT = 38 };
 static int g_force_cfg = -1;
 static int g_force_serial = -1;    // tests: -1 = rule / tuned, 0 = parallel split-K, 1 = serial split-K
+static int g_tune_split = 1;       // tuner: consider mixed-tile launches (csm_debug_conv_tuner_options)
 static int g_dbg = 0;
 constexpr int kTileSerial = 64;
+constexpr int kTileSplit = 128;    // csm_op.tile bit 7: mixed-tile launch (big tiles for whole rounds + 64 x 64 tiles for the rest)
 
 static void read_force_env() {
     static bool env_read = false;
@@ -1582,6 +1647,7 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 // csm_op.tile = 1 + configuration (+ kTileSerial: split-K runs walked by one block).  Untuned ops: serial once the
                 // batch supplies enough output tiles by itself (speed only: both executions give the same bits)
                 const int tcfg = op.tile & (kTileSerial - 1);
+                a.split = (op.tile & kTileSplit) != 0 && g_force_cfg < 0;
                 const bool tuned = tcfg > 0 && tcfg <= CFG_COUNT && g_force_cfg < 0;
                 a.serial = a.ksplit > 1 && (g_force_serial >= 0 ? g_force_serial != 0 : tuned ? (op.tile & kTileSerial) != 0
                                             : (int64_t)((a.M + 63) / 64) * ((op.cout_g + 63) / 64) >= 512);
@@ -1779,11 +1845,14 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
             if (cand_bn[c] == 32 && op.cout_g > 64 && (op.cout_g % 64) != 32) continue;   // (96, 160 ... outputs: 32-wide tiles waste no MFMA columns)
             for (int ser = 0; ser <= (op.ksplit > 1 ? 1 : 0) && rc == CSM_OK; ++ser) {     // split-K layers: both executions
-                op.tile = cand_all[c] + 1 + (ser ? kTileSerial : 0);
-                float tmin;
-                rc = time_tile(reps, tmin);
-                if (rc) break;
-                timed.emplace_back(tmin, op.tile - 1);
+                const bool dfam = cand_all[c] >= CFG_D64x64 && cand_all[c] <= CFG_D192x128 && cand_all[c] != CFG_NARROW && cand_all[c] != CFG_D64x64;
+                for (int sp = 0; sp <= ((dfam && g_tune_split && (op.ksplit <= 1 || ser)) ? 1 : 0) && rc == CSM_OK; ++sp) {   // mixed-tile launch
+                    op.tile = cand_all[c] + 1 + (ser ? kTileSerial : 0) + (sp ? kTileSplit : 0);
+                    float tmin;
+                    rc = time_tile(reps, tmin);
+                    if (rc) break;
+                    timed.emplace_back(tmin, op.tile - 1);
+                }
             }
             if (rc) break;
         }
@@ -1833,7 +1902,7 @@ extern "C" int csm_conv_tile_cache_load(const char *path) {
         std::array<int, 16> key; int tile = 0; bool ok = true;
         for (int &v : key) ok = ok && fscanf(f, "%d", &v) == 1;
         if (!ok || fscanf(f, "%d", &tile) != 1) break;
-        if (tile >= 0 && (tile & (kTileSerial - 1)) <= CFG_COUNT && tile < 2 * kTileSerial) { std::lock_guard<std::mutex> lk(g_tile_mutex); g_tile_cache[key] = tile; ++n; }
+        if (tile >= 0 && (tile & (kTileSerial - 1)) <= CFG_COUNT && tile < 2 * kTileSplit) { std::lock_guard<std::mutex> lk(g_tile_mutex); g_tile_cache[key] = tile; ++n; }
     }
     fclose(f);
     return n;
@@ -1843,6 +1912,12 @@ extern "C" int csm_conv_tile_cache_load(const char *path) {
 // (ConvArgs::dbg).  Not part of the stable ABI.
 extern "C" int csm_debug_force_conv_cfg(int cfg) {
     if (cfg >= 0) { g_force_cfg = cfg & 0xff; g_dbg = cfg >> 8; } else { g_force_cfg = -1; g_dbg = 0; }
+    return CSM_OK;
+}
+
+// measurement aid: which launch forms the autotuner may choose from (bit 0: mixed-tile launches); default all
+extern "C" int csm_debug_conv_tuner_options(int options) {
+    g_tune_split = options & 1;
     return CSM_OK;
 }
 

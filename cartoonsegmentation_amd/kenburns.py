@@ -224,9 +224,12 @@ class KenBurnsPipeline:
         if depth_est == 'default':                       # kenburns_effect.py:547-548: the original 3D-Ken-Burns estimator
             self._set_default_estimator()
             return
+        if depth_est == 'zoe':                           # kenburns_effect.py:541-544
+            self._set_zoe_estimator()
+            return
         if depth_est != 'leres':
-            raise NotImplementedError("depth_est %r: 'leres' (the shipped yaml) and 'default' (sniklaus Disparity + VGG19-BN) are built; "
-                                      "zoe / marigold need un-vendored sources (SURVEY F3/F4)" % depth_est)
+            raise NotImplementedError("depth_est %r: 'leres' (the shipped yaml), 'default' (sniklaus Disparity + VGG19-BN) and 'zoe' (with "
+                                      "a MiDaS core plugged in) are built; marigold needs the un-vendored diffusers pipeline (SURVEY F4)" % depth_est)
         if self._leres_ws is None:
             p = os.environ.get('CSM_LERES_CKPT', 'models/leres/res101.pth')
             if not os.path.exists(p) and not _synthetic_ok():
@@ -237,6 +240,37 @@ class KenBurnsPipeline:
             else:
                 self._leres_ws = SynthWeights('leres.')
         self._depth_est = self._depth_est_leres
+
+    def _set_zoe_estimator(self):
+        """depth_modules/__init__.py:40-47 load_zoe(DEPTH_ZOE_CKPT, img_size=[672, 672]): the metric-bins head's weights come from the
+        checkpoint (or closed-form); the MiDaS DPT-BEiT-L core is a plug (self.set_zoe_core) -- the reference downloads it with
+        torch.hub and does not vendor it, so without a core the estimator raises at its first call"""
+        from .zoedepth import ZoeDepth
+        if getattr(self, 'depth_zoe', None) is None:
+            p = 'models/AnimeInstanceSegmentation/ZoeD_M12_N.pt'                     # utils/constants.py:82
+            if os.path.exists(p):
+                sd = torch.load(p, map_location='cpu', weights_only=False)
+                ws = StateDictWeights(sd.get('model', sd))
+            elif _synthetic_ok() or str(self.cfg.det_ckpt).startswith('synthetic'):
+                ws = SynthWeights('zoe.')
+            else:
+                raise FileNotFoundError("%s (set CSM_SYNTHETIC_WEIGHTS=1 for closed-form head weights)" % p)
+            self.depth_zoe = ZoeDepth(ws, core=getattr(self, '_zoe_core', None), img_size=(672, 672), keep_aspect_ratio=True, device=self.device)
+        self._depth_est = self._depth_est_zoe
+
+    def set_zoe_core(self, core):
+        """plug the MiDaS core: core(x_prepared [B,3,h,w]) -> (rel_depth [B,h,w], [out_conv, bottleneck, r4, r3, r2, r1])"""
+        self._zoe_core = core
+        if getattr(self, 'depth_zoe', None) is not None:
+            self.depth_zoe.set_core(core)
+
+    def _depth_est_zoe(self, img_tensor, img_d):
+        """kenburns_effect.py:812-818"""
+        from .zoedepth import depth_to_disparity
+        if img_tensor is None:
+            img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+        depth = self.depth_zoe.infer(img_tensor, with_flip_aug=True, pad_input=True)
+        return depth_to_disparity(depth, self.cfg.focal, self.cfg.baseline)
 
     def _set_default_estimator(self):
         """anime_3dkenburns/models/__init__.py:33-52: Semantics (torchvision vgg19_bn) + Disparity (network-disparity.pytorch)"""

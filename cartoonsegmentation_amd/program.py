@@ -41,6 +41,11 @@ def fold_bn(w, b, gamma, beta, mean, var, eps):
                                                              + np.asarray(beta, np.float64)).astype(np.float32)
 
 
+# channels of a grouped convolution's super-group (narrow groups are run block-diagonally inside one MFMA tile; exact: fmaf(x, 0, acc) ==
+# acc).  32 = one 32x32x2 tile (4x / 2x zero work for 8- / 16-channel groups), 16 = one 16x16x4 tile (2x / none)
+GROUP_PACK = int(os.environ.get('CSM_GROUP_PACK', '32'))
+
+
 def pack_conv_weights(w, groups):
     """w [cout, cin_g, kh, kw] (fp32, folded) -> (packed fp32 1-D, super_groups, cin_sg, cout_sg)
     packed layout: [sg][cb][tap][npad][32]  (cb = 32-channel block, OUTER = the chain order; npad = cout_sg rounded to 32; zero padded)"""
@@ -50,7 +55,7 @@ def pack_conv_weights(w, groups):
         wsg = w.reshape(1, cout, cin_g, kh, kw)
     else:
         cout_g = cout // groups
-        s = max(1, 32 // cin_g)
+        s = max(1, GROUP_PACK // cin_g)
         while groups % s:
             s -= 1
         sg, cin_sg, cout_sg = groups // s, s * cin_g, s * cout_g

@@ -209,8 +209,9 @@ typedef struct csm_op {
                                 the others at 0) and the runs are added in order ((p0+p1)+p2)...  1 = single chain */
     int32_t scratch;         /* tensor id of the [n,h,w,ksplit*cout] partial-sum buffer when ksplit > 1, else -1 */
     int32_t tile;            /* CONV: 0 = built-in tile rule; low 6 bits k > 0 = tile configuration k-1, bit 6 (64) = split-K runs
-                                walked serially by one block instead of ksplit blocks + reduce (speed only: every configuration
-                                and both split-K executions produce the same bits); filled in by csm_conv_autotune */
+                                walked serially by one block instead of ksplit blocks + reduce, bit 7 (128) = mixed-tile launch (the
+                                configuration's tiles cover whole rounds of the grid, 64 x 64 tiles the remaining rows).  Speed only:
+                                every configuration and every launch form produces the same bits; filled in by csm_conv_autotune */
 } csm_op;
 
 /* Measure every eligible tile configuration of every CONV op on the device (HIP events on `stream`, `reps` timed launches
@@ -232,10 +233,29 @@ int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
 int csm_debug_force_conv_cfg(int cfg);
 /* Test aid (not stable ABI): how ksplit > 1 layers are executed: -1 = tuned / built-in rule, 0 = parallel, 1 = serial. */
 int csm_debug_force_splitk_serial(int mode);
+/* Measurement aid (not stable ABI): launch forms the autotuner may choose from; bit 0 = mixed-tile launches (default on). */
+int csm_debug_conv_tuner_options(int options);
 /* Measurement aid: same execution, each op bracketed by HIP events on `stream`; synchronises and returns ms per op. */
 int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
                             const float *weights, float *workspace, void *const *ext, int n_ext, void *stream,
                             float *op_ms);
+
+/* ------------------------------------------------------------------------------------
+ * ZoeDepth plumbing around the metric-bins head (CSM_OP_ATTRACTOR / CSM_OP_LOGBINOM) and the pluggable MiDaS core
+ * replaces DepthModel.infer / _infer_with_pad_aug / infer_with_flip_aug (depth_modules/zoedepth/models/depth_model.py:57-129),
+ * PrepForMidas + Resize (models/base_models/midas.py:49-187) and the tail of _depth_est_zoe (kenburns_effect.py:812-818)
+ * ---------------------------------------------------------------------------------- */
+
+/* img [B,3,H,W] (0..1) -> out [B,3,nh,nw] = Normalize(0.5, 0.5)(bilinear_align_corners(reflect_pad(flip ? hflip(img) : img, pad_w,
+ * pad_h) -> (nh, nw))) in ONE pass (the padded image never exists); pad < size. */
+int csm_zoe_pad_prep(const float *img, int B, int H, int W, int pad_h, int pad_w, int flip, int nh, int nw, float *out, void *stream);
+/* d [B,1,h,w] (prediction at the core's resolution for the padded input) -> out [B,1,H,W]: bicubic (aten, A = -0.75,
+ * align_corners = false) to the padded size (H + 2 pad_h, W + 2 pad_w), cropped to the original view, mirrored back when unflip;
+ * mode 0: out = v; mode 1: out = (out + v) / 2 (second pass of infer_with_flip_aug). */
+int csm_zoe_resize_crop(const float *d, int B, int h, int w, int pad_h, int pad_w, int H, int W, int unflip, int mode, float *out,
+                        void *stream);
+/* disparity = reciprocal(depth + 1e-5) * (focal * baseline); nan / +-inf -> 0   (kenburns_effect.py:816-817) */
+int csm_zoe_depth_to_disparity(const float *depth, int64_t n, float focal_times_baseline, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Instance-segmentation post-processing

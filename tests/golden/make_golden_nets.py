@@ -199,6 +199,98 @@ def zoe_head_case():
     print('zoe head', md.shape, float(md.mean()), float(md.std()), float(bc.min()), float(bc.max()))
 
 
+def zoe_infer_case():
+    """The whole `depth_est: 'zoe'` call chain with the reference's OWN classes -- KenBurnsPipeline._depth_est_zoe
+    (kenburns_effect.py:812-818, its text executed) -> DepthModel.infer (depth_model.py: reflect padding, flip TTA, bicubic resize
+    back, crop) -> ZoeDepth.forward (zoedepth_v1.py) -> MidasCore.forward (midas.py: PrepForMidas resize + normalise, feature hooks)
+    -- around a deterministic stand-in for the un-vendored MiDaS network (zoe_stub_core.py).  Stored: the image, what the core
+    received in both TTA passes (= padding + flip + PrepForMidas), the metric depth and the disparity."""
+    import itertools
+    import json
+    import types
+    import zoe_stub_core as stub
+    nn = torch.nn
+    tvt = sys.modules['torchvision.transforms']
+
+    class Normalize:                                # [EXT] torchvision.transforms.Normalize on a batched tensor: (x - mean) / std per channel
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(1, -1, 1, 1), torch.tensor(std).view(1, -1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+    tvt.Normalize = Normalize
+    for n in ("depth_modules", "depth_modules.zoedepth", "depth_modules.zoedepth.models", "depth_modules.zoedepth.models.layers",
+              "depth_modules.zoedepth.models.base_models"):
+        ref_loader._bare(n)
+    Lp = "depth_modules/zoedepth/models/"
+    att = ref_loader.load_by_path("depth_modules.zoedepth.models.layers.attractor", Lp + "layers/attractor.py")
+    dist = ref_loader.load_by_path("depth_modules.zoedepth.models.layers.dist_layers", Lp + "layers/dist_layers.py")
+    lb = ref_loader.load_by_path("depth_modules.zoedepth.models.layers.localbins_layers", Lp + "layers/localbins_layers.py")
+    dm = ref_loader.load_by_path("depth_modules.zoedepth.models.depth_model", Lp + "depth_model.py")
+    mid = ref_loader.load_by_path("depth_modules.zoedepth.models.base_models.midas", Lp + "base_models/midas.py")
+    ns = dict(torch=torch, nn=nn, itertools=itertools, DepthModel=dm.DepthModel, MidasCore=mid.MidasCore, load_state_from_resource=None,
+              AttractorLayer=att.AttractorLayer, AttractorLayerUnnormed=att.AttractorLayerUnnormed,
+              ConditionalLogBinomial=dist.ConditionalLogBinomial, Projector=lb.Projector, SeedBinRegressor=lb.SeedBinRegressor,
+              SeedBinRegressorUnnormed=lb.SeedBinRegressorUnnormed)
+    ZoeDepth = ref_loader.extract_def(Lp + "zoedepth/zoedepth_v1.py", "ZoeDepth", ns)
+    conf = json.load(open(os.path.join(ref_loader.REF, Lp + "zoedepth/config_zoedepth.json")))["model"]
+
+    class Fn(nn.Module):
+        def __init__(self, f):
+            super().__init__()
+            self.f = f
+
+        def forward(self, x):
+            return self.f(x)
+
+    class StubMidas(nn.Module):                     # the attribute layout MidasCore.attach_hooks walks (midas.py:302-325)
+        def __init__(self):
+            super().__init__()
+            self.scratch = nn.Module()
+            # output_conv's child [3] is the activation MidasCore calls "out_conv"
+            self.scratch.output_conv = nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity(), Fn(stub.out_conv), Fn(stub.rel_depth))
+            self.scratch.layer4_rn = Fn(stub.layer4_rn)
+            for lv in (4, 3, 2, 1):
+                setattr(self.scratch, 'refinenet%d' % lv, Fn(lambda x, lv=lv: stub.refinenet(x, lv)))
+            self.seen = []
+
+        def forward(self, x):
+            self.seen.append(x.clone())
+            self.scratch.layer4_rn(x)
+            for lv in (4, 3, 2, 1):
+                getattr(self.scratch, 'refinenet%d' % lv)(x)
+            return self.scratch.output_conv(x)
+    midas = StubMidas()
+    NET = (96, 128)
+    core = mid.MidasCore(midas, trainable=False, fetch_features=True, freeze_bn=True, keep_aspect_ratio=True, img_size=list(NET))
+    core.output_channels = (256, 256, 256, 256, 256)
+    model = ZoeDepth(core, **{k: v for k, v in conf.items() if k not in ("name", "version_name", "img_size")}).eval()
+    kinds = {}
+    for mname, m in model.named_modules():
+        if isinstance(m, nn.Conv2d):
+            kinds[mname + '.weight'] = 'conv_w'; kinds[mname + '.bias'] = 'conv_b'
+    sd = model.state_dict()
+    for name, t in sd.items():
+        if name in kinds:
+            t.copy_(torch.from_numpy(synth_tensor('zoe.' + name, tuple(t.shape), kinds[name])))
+    model.load_state_dict(sd)
+    g = np.random.default_rng(410)
+    H, W = 70, 110
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = (0.5 + 0.35 * np.sin(xx[None] / 9.0 + np.arange(3).reshape(3, 1, 1)) * np.cos(yy[None] / 7.0)
+           + g.uniform(-0.1, 0.1, (3, H, W))).clip(0, 1).astype(np.float32)[None]
+    est = ref_loader.extract_def("anime_3dkenburns/kenburns_effect.py", "KenBurnsPipeline._depth_est_zoe", dict(torch=torch))
+    fake_self = types.SimpleNamespace(depth_zoe=model, cfg=types.SimpleNamespace(focal=55.0, baseline=40.0), device='cpu')
+    with torch.no_grad():
+        depth = model.infer(torch.from_numpy(img), with_flip_aug=True, pad_input=True)
+        n_seen = len(midas.seen)
+        disparity = est(fake_self, torch.from_numpy(img))
+    assert n_seen == 2
+    np.savez_compressed(os.path.join(HERE, 'zoe_infer_70x110.npz'), img=img, net=np.array(NET), prep0=midas.seen[0].numpy(),
+                        prep1=midas.seen[1].numpy(), depth=depth.numpy(), disparity=disparity.numpy(), focal=55.0, baseline=40.0)
+    print('zoe infer', tuple(midas.seen[0].shape), tuple(depth.shape), float(depth.mean()), float(depth.std()), float(disparity.mean()))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['isnet', 'leres']
     if 'zoe' in which:
@@ -213,4 +305,6 @@ if __name__ == '__main__':
         inpaint_case()
     if 'refine' in which:
         refine_case()
+    if 'zoe_infer' in which:
+        zoe_infer_case()
 

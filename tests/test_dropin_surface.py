@@ -53,3 +53,17 @@ def test_io_utils_host_logic(tmp_path):
     assert scaledown_size(600, 400, 640, 32) == (608, 416) and scaledown_size(100, 50, 720) == (100, 50)
     img, pads = resize_pad(a, 32, pad_value=(0, 0, 0))                             # no scaling needed: pure host padding
     assert img.shape == (32, 32, 3) and pads == (0, 12, 0, 2) and np.array_equal(img[:20, :30], a) and img[20:].max() == 0
+
+
+def test_midas_resize_rule_matches_the_reference_fixture():
+    """Resize.get_size ('minimal', multiple of 32, aspect ratio kept; midas.py:108-160) as the host computes it: the fixture's core
+    input was produced by the reference's own Resize for a 104 x 154 padded image and a 96 x 128 network size"""
+    import os
+    import numpy as np
+    from cartoonsegmentation_amd.zoedepth import midas_size
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "zoe_infer_70x110.npz"))
+    H, W = g['img'].shape[2:]
+    ph, pw = int(np.sqrt(H / 2) * 3), int(np.sqrt(W / 2) * 3)
+    nw, nh = midas_size(W + 2 * pw, H + 2 * ph, int(g['net'][1]), int(g['net'][0]))
+    assert (nh, nw) == g['prep0'].shape[2:]
+    assert midas_size(1024, 1024, 672, 672) == (672, 672) and midas_size(1920, 1080, 672, 672) == (1184, 672)

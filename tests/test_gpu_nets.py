@@ -281,3 +281,67 @@ def test_zoedepth_head_vs_reference_text():
     CompiledProgram(build_zoe_head(SynthWeights('zoe.'), 1, H, W, [(H >> s, W >> s) for s in (5, 4, 3, 2, 1)]), dev).run(*ext, out)
     y = out.cpu().numpy()
     assert np.abs(y - g['metric_depth']).max() <= 1e-4 * np.abs(g['metric_depth']).max()
+
+
+def test_zoedepth_infer_chain_vs_reference_classes():
+    """`depth_est: 'zoe'` around a plugged core (tests/golden/zoe_stub_core.py, the stand-in the fixture was made with): padding +
+    flip + PrepForMidas (what the core receives in both TTA passes), the metric depth of DepthModel.infer and the disparity of
+    KenBurnsPipeline._depth_est_zoe, against the reference's own classes / text (tests/golden/make_golden_nets.py zoe_infer).
+    north_star tolerance for fp32 depth: 1e-3 relative; measured ~1e-5"""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import zoe_stub_core as stub
+    from cartoonsegmentation_amd import _lib
+    from cartoonsegmentation_amd.zoedepth import ZoeDepth, depth_to_disparity, midas_size
+    g = dict(np.load(os.path.join(GOLDEN, "zoe_infer_70x110.npz")))
+    dev = torch.device('cuda')
+    seen = []
+
+    def core(xp):
+        seen.append(xp.clone())
+        return stub.core(xp)
+    z = ZoeDepth(SynthWeights('zoe.'), core=core, img_size=tuple(int(v) for v in g['net']), keep_aspect_ratio=True, device=dev)
+    x = torch.from_numpy(g['img']).to(dev)
+    depth = z.infer(x, pad_input=True, with_flip_aug=True)
+    assert len(seen) == 2
+    assert tuple(seen[0].shape) == g['prep0'].shape == (1, 3, 96, 128) and midas_size(154, 104, 128, 96) == (128, 96)
+    assert np.abs(seen[0].cpu().numpy() - g['prep0']).max() <= 2e-5 and np.abs(seen[1].cpu().numpy() - g['prep1']).max() <= 2e-5
+    d = depth.cpu().numpy()
+    assert d.shape == g['depth'].shape and np.abs(d - g['depth']).max() <= 1e-4 * np.abs(g['depth']).max()
+    disp = depth_to_disparity(depth, float(g['focal']), float(g['baseline'])).cpu().numpy()
+    assert np.abs(disp - g['disparity']).max() <= 1e-3 * np.abs(g['disparity']).max()
+    # single pass / no padding variants run and differ from the TTA result; zeros, nan and inf follow the reference's rules
+    d1 = z.infer(x, pad_input=False, with_flip_aug=False)
+    assert d1.shape == depth.shape and torch.isfinite(d1).all() and not torch.equal(d1, depth)
+    t = torch.tensor([[0.0, 2.0, float('nan'), float('inf'), -1e-5]], device=dev).view(1, 1, 1, 5)
+    o = depth_to_disparity(t.clone(), 55.0, 40.0).view(-1).cpu().numpy()
+    assert o[0] == o[1] and o[2] == 0.0 and o[3] == 0.0 and o[4] == 0.0 and abs(o[1] - 2200.0 / 2.00001) < 0.01
+    # without a core the estimator refuses loudly (the BEiT network is not vendored)
+    z.set_core(None)
+    with pytest.raises(_lib.CsmError):
+        z.infer(x)
+
+
+def test_zoe_depth_estimation_is_wired_into_the_pipeline():
+    """set_depth_estimation('zoe') (kenburns_effect.py:541-544): needs a plugged core, then generate_kenburns_config runs end to end"""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import zoe_stub_core as stub
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd import _lib, synth
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='zoe', max_size=512, refine_crf=False, focal=176.0, num_frame=2,
+                         mask_refine_kwargs={'refine_method': 'none'})
+    pipe = KenBurnsPipeline(cfg)
+    pipe.max_instances = 2
+    pipe.animeinsseg.set_detect_size(96)
+    img = synth.image_u8(320, 352, 91)
+    with pytest.raises(_lib.CsmError):
+        pipe.generate_kenburns_config(img)
+    pipe.set_zoe_core(stub.core)
+    kc = pipe.generate_kenburns_config(img)
+    assert kc['tenRawDisparity'].shape == (1, 1, 320, 352) and torch.isfinite(kc['tenRawPoints']).all()
+    frames = pipe.autozoom(kc, inpaint=False)
+    assert len(frames) == 2 and frames[0].shape == (320, 352, 3)
+    kcs = pipe.generate_kenburns_configs([img, synth.image_u8(320, 352, 92)])        # batched API dispatches on the selected estimator
+    assert torch.equal(kcs[0]['tenRawPoints'], kc['tenRawPoints'])

@@ -3,7 +3,11 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from cartoonsegmentation_amd import nets
+from cartoonsegmentation_amd import nets, _lib
+if os.environ.get('LP_LIB'):                    # A/B of two builds of the library (e.g. make PREFETCH=1 OUT=...)
+    _lib.LIB_PATH = os.path.abspath(os.environ['LP_LIB'])
+if os.environ.get('LP_TUNER_OPTIONS'):
+    _lib.load().csm_debug_conv_tuner_options(int(os.environ['LP_TUNER_OPTIONS']))
 from cartoonsegmentation_amd.runtime import CompiledProgram
 from cartoonsegmentation_amd.weights import SynthWeights
 
@@ -46,7 +50,7 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['isnet', 'leres', 'rtmdet']
     dev = 'cuda'
     if 'isnet' in which:
-        nb = min(2 * B, 8)
+        nb = min(2 * B, 16)
         p = nets.build_isnet(SynthWeights('isnet.'), nb, 720, 720)
         prof('isnet n=%d 720' % nb, p, [torch.rand(nb, 4, 720, 720, device=dev), torch.empty(nb, 1, 720, 720, device=dev)])
     if 'leres' in which:
