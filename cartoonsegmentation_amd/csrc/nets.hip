@@ -489,17 +489,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 #ifdef CSM_CONV_PREFETCH
     // L2 warm-up: one byte per 16-B slot of the chunk at the loader position (= the chunk AFTER the one whose DMA was just issued).
     // The DMA for those lines goes out one chunk time later and then hits L2 instead of waiting for HBM inside the two-stage window.
-    // Always GA + GB instructions (dead lanes are out of range), so the loop's counted wait stays exact.
+    // Always GA + GB instructions (dead lanes are out of range), so the loop's counted wait stays exact.  The loads return
+    // asynchronously into `pf_sink`, a register that stays allocated to the end of the kernel ("+v" here, consumed after the final
+    // wait) -- a scratch output register would be recycled by the compiler while loads are still in flight.
+    unsigned pf_sink = 0u;
     auto prefetch = [&](bool live) {
         const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
-        unsigned dummy;
 #pragma unroll
         for (int p = 0; p < GA; ++p)
-            asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=v"(dummy)
+            asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "+v"(pf_sink)
                          : "v"((live && ((vmA[p] >> l_tap) & 1u)) ? offA[p] + coff : kOob), "s"(ra) : "memory");
 #pragma unroll
         for (int p = 0; p < GB; ++p)
-            asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=v"(dummy)
+            asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "+v"(pf_sink)
                          : "v"((live && offB[p] != kOob) ? offB[p] + l_w : kOob), "s"(rb) : "memory");
     };
 #endif
@@ -572,6 +574,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 #endif
             compute(st, chunk);
         }
+#ifdef CSM_CONV_PREFETCH
+        asm volatile("s_waitcnt vmcnt(0)\n\t; keep %0" :: "v"(pf_sink) : "memory");
+#endif
     } else {
         // NS stages: the loads of chunk + NS - 1 are issued while chunk is consumed, so a load may take NS - 1 chunk times
         // (L2 misses of the short-K-chunk 1x1 layers) before it stalls the pipe.  vmcnt retires in order: "at most

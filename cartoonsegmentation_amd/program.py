@@ -41,9 +41,10 @@ def fold_bn(w, b, gamma, beta, mean, var, eps):
                                                              + np.asarray(beta, np.float64)).astype(np.float32)
 
 
-# channels of a grouped convolution's super-group (narrow groups are run block-diagonally inside one MFMA tile; exact: fmaf(x, 0, acc) ==
-# acc).  32 = one 32x32x2 tile (4x / 2x zero work for 8- / 16-channel groups), 16 = one 16x16x4 tile (2x / none)
-GROUP_PACK = int(os.environ.get('CSM_GROUP_PACK', '32'))
+# channels of a grouped convolution's super-group: narrow groups run block-diagonally inside one 32x32x2 MFMA tile (exact: fmaf(x, 0,
+# acc) == acc; 4x / 2x zero work for 8- / 16-channel groups).  Measured round 3: 16-wide super-groups on the 16x16x4 tile (2x / none)
+# are SLOWER (ResNeXt g8 layer 22.0 -> 16.0 TF/s, g16 42.8 -> 31.9: the register-staged kernel's per-block overhead dominates).
+GROUP_PACK = 32
 
 
 def pack_conv_weights(w, groups):

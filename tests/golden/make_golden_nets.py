@@ -247,8 +247,10 @@ def zoe_infer_case():
         def __init__(self):
             super().__init__()
             self.scratch = nn.Module()
-            # output_conv's child [3] is the activation MidasCore calls "out_conv"
-            self.scratch.output_conv = nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity(), Fn(stub.out_conv), Fn(stub.rel_depth))
+            # output_conv's child [3] is the activation MidasCore calls "out_conv"; the last child stands for the final 1-channel conv
+            # (it sees the prepared input through `self.x`: the stand-in's relative depth is a function of the input, like its features)
+            self.scratch.output_conv = nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity(), Fn(stub.out_conv),
+                                                     Fn(lambda _act: stub.rel_depth(self.x)))
             self.scratch.layer4_rn = Fn(stub.layer4_rn)
             for lv in (4, 3, 2, 1):
                 setattr(self.scratch, 'refinenet%d' % lv, Fn(lambda x, lv=lv: stub.refinenet(x, lv)))
@@ -256,6 +258,7 @@ def zoe_infer_case():
 
         def forward(self, x):
             self.seen.append(x.clone())
+            self.x = x
             self.scratch.layer4_rn(x)
             for lv in (4, 3, 2, 1):
                 getattr(self.scratch, 'refinenet%d' % lv)(x)

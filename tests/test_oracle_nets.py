@@ -165,3 +165,38 @@ def test_torch_cpu_interpreter_agrees_with_the_c_oracle():
     va, vb = onets.run_program(rp.prog, [x], want_views=want), nets_torch.run_program(rp.prog, [x], want_views=want)
     for t in want:
         assert rel_err(vb[t], va[t]) < 1e-4
+
+
+def test_zoe_infer_chain_on_the_oracle_matches_the_reference_fixture():
+    """CPU statement of `depth_est: 'zoe'` around the stand-in core (tests/golden/zoe_stub_core.py): reflect padding + flip +
+    PrepForMidas in torch, the metric-bins head through the oracle interpreter, bicubic resize back + crop + flip average -- against
+    the fixture made by the reference's own DepthModel / ZoeDepth / MidasCore classes.  Pins the host-side rules the HIP path mirrors
+    (pad sizes, Resize.get_size, feature order, TTA) without a GPU."""
+    import sys
+    import torch
+    import torch.nn.functional as F
+    sys.path.insert(0, GOLDEN)
+    import zoe_stub_core as stub
+    from cartoonsegmentation_amd.nets import build_zoe_head
+    from cartoonsegmentation_amd.zoedepth import midas_size
+    g = np.load(os.path.join(GOLDEN, "zoe_infer_70x110.npz"))
+    x = torch.from_numpy(g['img'])
+    H, W = x.shape[2:]
+    ph, pw = int(np.sqrt(H / 2) * 3), int(np.sqrt(W / 2) * 3)
+    outs = []
+    for flip in (0, 1):
+        xi = torch.flip(x, dims=[3]) if flip else x
+        xpd = F.pad(xi, [pw, pw, ph, ph], mode='reflect')
+        nw, nh = midas_size(xpd.shape[3], xpd.shape[2], int(g['net'][1]), int(g['net'][0]))
+        xp = (F.interpolate(xpd, (nh, nw), mode='bilinear', align_corners=True) - 0.5) / 0.5
+        assert float((xp - torch.from_numpy(g['prep%d' % flip])).abs().max()) <= 1e-6
+        rel, feats = stub.core(xp)
+        oc, btl, blocks = feats[0], feats[1], feats[2:]
+        prog = build_zoe_head(SynthWeights('zoe.'), 1, nh, nw, [tuple(btl.shape[2:])] + [tuple(b.shape[2:]) for b in blocks])
+        out = np.zeros((1, 1, nh, nw), np.float32)
+        ext = [rel.reshape(1, 1, nh, nw).numpy(), oc.numpy(), btl.numpy()] + [b.numpy() for b in blocks]
+        onets.run_program(prog, [np.ascontiguousarray(a) for a in ext] + [out])
+        d = F.interpolate(torch.from_numpy(out), size=tuple(xpd.shape[2:]), mode='bicubic', align_corners=False)[:, :, ph:-ph, pw:-pw]
+        outs.append(torch.flip(d, dims=[3]) if flip else d)
+    depth = ((outs[0] + outs[1]) / 2).numpy()
+    assert rel_err(depth, g['depth']) < 1e-5
