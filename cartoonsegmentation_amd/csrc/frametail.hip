@@ -289,3 +289,61 @@ extern "C" int csm_bokeh_depth_auto(const uint8_t *depth_u8, float *out, int64_t
     k_bokeh_depth_dev<<<csm::cdiv(n, kBlock), kBlock, 0, st>>>(depth_u8, out, n, focal_plane, stats);
     return csm::check_launch("k_bokeh_depth_dev");
 }
+
+// ---- focal plane of the depth of field: the largest per-instance MEDIAN of the colourised depth (kenburns_effect.py:1045-1056) ----
+// The reference gathers depth_rendered[mask] on the host and calls np.median per instance.  Values are uint8, so a 256-bin histogram
+// per instance holds everything: the two middle order statistics come from its prefix sums, np.median's even-count rule (mean of
+// the two) is exact in float, empty masks are skipped like the reference's `nan > x == False`.  No gather, no sort, and one
+// scalar for the host to read instead of two reads per instance.
+namespace {
+__global__ __launch_bounds__(256) void k_masked_hist(const uint8_t *__restrict__ v, const uint8_t *__restrict__ masks, int64_t n,
+                                                      unsigned *__restrict__ hist /* [inst][256], zeroed */) {
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint8_t *m = masks + (int64_t)blockIdx.y * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        if (m[i]) atomicAdd(&h[v[i]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[(int64_t)blockIdx.y * 256 + threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_masked_median_max(const unsigned *__restrict__ hist, int n_inst, float *__restrict__ out /* [n_inst + 1] */) {
+    __shared__ unsigned cum[256];
+    __shared__ float best;
+    if (threadIdx.x == 0) best = -1.0f;                      // focalplane_end = -1
+    __syncthreads();
+    for (int k = 0; k < n_inst; ++k) {
+        cum[threadIdx.x] = hist[k * 256 + threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned run = 0;
+            for (int b = 0; b < 256; ++b) { run += cum[b]; cum[b] = run; }          // inclusive prefix (256 steps, once per instance)
+            const unsigned cnt = run;
+            float med = __uint_as_float(0x7FC00000u);        // np.median of an empty selection: nan
+            if (cnt > 0) {
+                const unsigned r1 = (cnt - 1) / 2, r2 = cnt / 2;                     // 0-based ranks of the two middle values
+                int v1 = 0, v2 = 0;
+                while (cum[v1] <= r1) ++v1;
+                while (cum[v2] <= r2) ++v2;
+                med = ((float)v1 + (float)v2) / 2.0f;
+                if (med > best) best = med;
+            }
+            out[k] = med;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n_inst] = best;
+}
+}  // namespace
+
+extern "C" int csm_masked_u8_median_max(const uint8_t *values, const uint8_t *masks, int n_inst, int64_t n, unsigned *hist, float *out,
+                                        void *stream) {
+    CSM_REQUIRE(values && masks && hist && out && n_inst > 0 && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    CSM_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned) * 256 * (size_t)n_inst, st));
+    const unsigned blocks = (unsigned)((n + 256 * 16 - 1) / (256 * 16) < 256 ? ((n + 256 * 16 - 1) / (256 * 16) > 0 ? (n + 256 * 16 - 1) / (256 * 16) : 1) : 256);
+    k_masked_hist<<<dim3(blocks, (unsigned)n_inst), 256, 0, st>>>(values, masks, n, hist);
+    int rc = csm::check_launch("k_masked_hist"); if (rc) return rc;
+    k_masked_median_max<<<1, 256, 0, st>>>(hist, n_inst, out);
+    return csm::check_launch("k_masked_median_max");
+}

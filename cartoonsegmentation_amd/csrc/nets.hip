@@ -486,26 +486,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         if (++l_kw == a.kw) { l_kw = 0; if (++l_kh == a.kh) { l_kh = 0; l_tap = 0; ++l_cb; } }
     };
 
-#ifdef CSM_CONV_PREFETCH
-    // L2 warm-up: one byte per 16-B slot of the chunk at the loader position (= the chunk AFTER the one whose DMA was just issued).
-    // The DMA for those lines goes out one chunk time later and then hits L2 instead of waiting for HBM inside the two-stage window.
-    // Always GA + GB instructions (dead lanes are out of range), so the loop's counted wait stays exact.  The loads return
-    // asynchronously into `pf_sink`, a register that stays allocated to the end of the kernel ("+v" here, consumed after the final
-    // wait) -- a scratch output register would be recycled by the compiler while loads are still in flight.
-    unsigned pf_sink = 0u;
-    auto prefetch = [&](bool live) {
-        const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
-#pragma unroll
-        for (int p = 0; p < GA; ++p)
-            asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "+v"(pf_sink)
-                         : "v"((live && ((vmA[p] >> l_tap) & 1u)) ? offA[p] + coff : kOob), "s"(ra) : "memory");
-#pragma unroll
-        for (int p = 0; p < GB; ++p)
-            asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "+v"(pf_sink)
-                         : "v"((live && offB[p] != kOob) ? offB[p] + l_w : kOob), "s"(rb) : "memory");
-    };
-#endif
-
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -558,25 +538,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 
     if constexpr (NS == 2) {
         issue(0);
-#ifdef CSM_CONV_PREFETCH
-        prefetch(c_begin + 1 < T);
-#endif
         for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
-#ifdef CSM_CONV_PREFETCH
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GA + GB) : "memory");   // loads retire in order: only the newest warm-up may be out
-#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of `chunk` have landed ...
-#endif
             __builtin_amdgcn_s_barrier();                          // ... everybody's have, and everybody is done reading stage st^1
             if (chunk + 1 < T) issue(st ^ 1);
-#ifdef CSM_CONV_PREFETCH
-            prefetch(chunk + 2 < T);
-#endif
             compute(st, chunk);
         }
-#ifdef CSM_CONV_PREFETCH
-        asm volatile("s_waitcnt vmcnt(0)\n\t; keep %0" :: "v"(pf_sink) : "memory");
-#endif
     } else {
         // NS stages: the loads of chunk + NS - 1 are issued while chunk is consumed, so a load may take NS - 1 chunk times
         // (L2 misses of the short-K-chunk 1x1 layers) before it stalls the pipe.  vmcnt retires in order: "at most

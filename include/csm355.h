@@ -372,6 +372,10 @@ int csm_bokeh_depth(const uint8_t *depth_u8, float *out, int64_t n, float dmax, 
  * device scratch; all reductions stay on the device (no host sync). */
 int csm_bokeh_depth_general(const void *depth, int is_u8, int64_t n, int has_focal, float focal_plane, float depth_factor,
                             float *tmp, float *mm4, float *scratch512, float *out, void *stream);
+/* Focal plane of the depth of field (kenburns_effect.py:1045-1056): out[k] = np.median(values[masks[k] != 0]) for each of the n_inst
+ * boolean masks [n_inst, n] (nan when the mask is empty), out[n_inst] = the largest of them, -1 if every mask is empty.  values
+ * uint8 [n]; hist: n_inst * 256 uint32 of device scratch (zeroed by the call). */
+int csm_masked_u8_median_max(const uint8_t *values, const uint8_t *masks, int n_inst, int64_t n, unsigned *hist, float *out, void *stream);
 /* colorize(value, cmap='gray_r')[...,0]  depth_modules/zoedepth/utils/misc.py:97-135 (vmin/vmax = 2nd/85th percentile) */
 int csm_colorize_gray_r(const float *value, uint8_t *out, int64_t n, float vmin, float vmax, void *stream);
 

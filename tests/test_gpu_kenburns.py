@@ -519,3 +519,32 @@ def test_frame_streams_and_lanes_give_the_serial_results():
         fl.close()
     for a, b in zip(serial, par):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_device_focal_plane_median_matches_numpy():
+    """csm_masked_u8_median_max == max_k np.median(depth_u8[mask_k]) (kenburns_effect.py:1045-1056) for odd / even counts, a single
+    pixel, an empty mask (skipped: np.median gives nan) and all-empty (-1, the reference's initial focalplane_end)"""
+    from cartoonsegmentation_amd import _lib
+    from cartoonsegmentation_amd._lib import check, i32, i64, ptr, stream_ptr
+    L = _lib.load()
+    rng = np.random.default_rng(4)
+    H, W = 123, 211
+    d8 = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    d8[:40] = (d8[:40] // 64) * 3                                   # heavy ties in one region
+    masks = np.zeros((5, H, W), bool)
+    masks[0, 10:60, 20:91] = True                                   # 50 x 71 = 3550 (even)
+    masks[1, 0:33, 0:33] = True                                     # 1089 (odd), inside the tie region
+    masks[2, 100, 200] = True                                       # one pixel
+    masks[4] = rng.uniform(size=(H, W)) > 0.7
+    def run(m):
+        md = torch.from_numpy(m).cuda().view(torch.uint8)
+        hist = torch.empty(m.shape[0] * 256, dtype=torch.int32, device='cuda')
+        out = torch.empty(m.shape[0] + 1, device='cuda')
+        check(L.csm_masked_u8_median_max(ptr(torch.from_numpy(d8).cuda()), ptr(md), i32(m.shape[0]), i64(H * W), ptr(hist), ptr(out), stream_ptr()))
+        return out.cpu().numpy()
+    got = run(masks)
+    want = [np.median(d8[m]) if m.any() else np.nan for m in masks]
+    for k in range(5):
+        assert (np.isnan(got[k]) and np.isnan(want[k])) or got[k] == np.float32(want[k]), (k, got[k], want[k])
+    assert got[5] == np.float32(np.nanmax(want))
+    assert run(np.zeros((2, H, W), bool))[2] == -1.0
