@@ -106,17 +106,25 @@ class AnimeInstances:
         bbox columns 0,2 by the HEIGHT ratio and 1,3 by the WIDTH ratio -- kept)"""
         if self.is_empty or not self.is_tensor:
             return
-        masks = self.masks.to(torch.float).unsqueeze(1)
-        oh, ow = masks.shape[2], masks.shape[3]
+        oh, ow = int(self.masks.shape[1]), int(self.masks.shape[2])
         hs, ws = h / oh, w / ow
         bboxes = self.bboxes.float()
         bboxes[:, ::2] *= hs
         bboxes[:, 1::2] *= ws
         self.bboxes = torch.round(bboxes).int()
         if (oh, ow) == (h, w):        # identity resize: interpolate(area) of a 0/1 mask then > 0.3 returns the mask itself
-            self.masks = masks.squeeze(1) > 0.3
+            self.masks = self.masks.to(torch.float) > 0.3
+        elif self.masks.is_cuda and mode == 'area' and self.masks.dtype == torch.bool:
+            # device instances (the pipeline's case): adaptive-average resize + threshold in one hand-written pass over the 1-B masks
+            from . import _lib
+            from ._lib import check, f32, i32, ptr, stream_ptr
+            src = self.masks.contiguous().view(torch.uint8)
+            out = torch.empty((src.shape[0], h, w), dtype=torch.uint8, device=src.device)
+            check(_lib.load().csm_mask_area_resize_threshold(ptr(src), i32(src.shape[0]), i32(oh), i32(ow), i32(h), i32(w), f32(0.3), ptr(out),
+                                                             stream_ptr(src.device)), "mask_area_resize")
+            self.masks = out.view(torch.bool)
         else:
-            self.masks = torch.nn.functional.interpolate(masks, (h, w), mode=mode).squeeze(1) > 0.3
+            self.masks = torch.nn.functional.interpolate(self.masks.to(torch.float).unsqueeze(1), (h, w), mode=mode).squeeze(1) > 0.3
 
     def compose_masks(self, output_type=None):
         if self.is_empty:

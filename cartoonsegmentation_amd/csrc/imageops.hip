@@ -765,3 +765,126 @@ extern "C" int csm_colorize_gray_r(const float *value, uint8_t *out, int64_t n, 
     k_colorize_gray_r<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(value, out, n, vmin, vmax);
     return csm::check_launch("k_colorize_gray_r");
 }
+
+// ---- whole-tensor mean / std and the normalise / de-normalise steps around the Inpaint and Refine nets ------------------------------
+// pointcloud_inpainting.py:116-131, :196-203 and disparity_refinement.py:97-107, :121-126: x.mean(), x.std(unbiased=False), (x - mean) /
+// (std + 1e-7), y * (std + 1e-7) + mean, then clip(0, 1) (image) or threshold(0) (disparity).  The reductions accumulate in double
+// (two passes: mean, then the centred second moment) -- at least as accurate as any fp32 summation order torch may use; results are
+// compared with the reference modules at fp32 tolerance.  Statistics stay on the device.
+namespace {
+__global__ __launch_bounds__(256) void k_sum_partial(const float *__restrict__ x, int64_t n, const float *__restrict__ centre, double *__restrict__ part) {
+    __shared__ double red[256];
+    const double c = centre ? (double)centre[0] : 0.0;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)x[i] - c;
+        s += centre ? v * v : v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) { if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void k_sum_final(const double *__restrict__ part, int nparts, int64_t n, int is_var, float *__restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) { if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = is_var ? (float)sqrt(red[0] / (double)n) : (float)(red[0] / (double)n);
+}
+__global__ __launch_bounds__(256) void k_normalise_ms(const float *__restrict__ x, int64_t n, const float *__restrict__ ms, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (x[i] - ms[0]) / (ms[1] + 0.0000001f);
+}
+__global__ __launch_bounds__(256) void k_denormalise_ms(const float *__restrict__ x, int64_t n, const float *__restrict__ ms, int mode, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i] * (ms[1] + 0.0000001f) + ms[0];
+    if (mode == 1) v = fminf(fmaxf(v, 0.0f), 1.0f);            // tensor.clip(0.0, 1.0)
+    else if (mode == 2) v = v > 0.0f ? v : 0.0f;              // torch.nn.functional.threshold(v, 0.0, 0.0)
+    out[i] = v;
+}
+
+// torch.nn.functional.interpolate(mode='bilinear') of `planes` independent [H, W] planes (aten upsample_bilinear2d: UpSample.h
+// area_pixel_compute_source_index; identity when the sizes match) -- the resize branches of depth_adjustment_animesseg
+// (kenburns_effect.py:49-52, :89-90) and of disparity_estimation (models/__init__.py:46-49)
+__device__ __forceinline__ void aten_src(int dst, int in_size, int out_size, float scale, bool align, int &i0, int &i1, float &l0, float &l1) {
+    if (in_size == out_size) { i0 = i1 = dst; l0 = 1.0f; l1 = 0.0f; return; }
+    float real;
+    if (align) real = scale * (float)dst;
+    else { real = scale * ((float)dst + 0.5f) - 0.5f; if (real < 0.0f) real = 0.0f; }
+    i0 = min((int)real, in_size - 1);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = fminf(fmaxf(real - (float)i0, 0.0f), 1.0f);
+    l0 = 1.0f - l1;
+}
+__global__ __launch_bounds__(256) void k_bilinear_planes(const float *__restrict__ in, int planes, int H, int W, int h, int w, int align,
+                                                          float sh, float sw, float *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)planes * h * w;
+    if (idx >= total) return;
+    const int x = (int)(idx % w); int64_t t = idx / w; const int y = (int)(t % h); const int64_t p = t / h;
+    int y0, y1, x0, x1; float hl0, hl1, wl0, wl1;
+    aten_src(y, H, h, sh, align != 0, y0, y1, hl0, hl1); aten_src(x, W, w, sw, align != 0, x0, x1, wl0, wl1);
+    const float *P = in + p * (int64_t)H * W;
+    out[idx] = hl0 * (wl0 * P[(int64_t)y0 * W + x0] + wl1 * P[(int64_t)y0 * W + x1]) + hl1 * (wl0 * P[(int64_t)y1 * W + x0] + wl1 * P[(int64_t)y1 * W + x1]);
+}
+
+// AnimeInstances.resize (animeinsseg/anime_instances.py:268-280): interpolate(masks.float(), (h, w), mode='area') > 0.3 = adaptive
+// average pooling of 0 / 1 values.  Window [floor(o I / O), ceil((o + 1) I / O)) per axis and `sum / kH / kW` as aten's device kernel
+// writes it (AdaptiveAveragePooling: START_IND / END_IND in float); the sum of a 0 / 1 window is an exact integer in any order.
+__global__ __launch_bounds__(256) void k_mask_area_threshold(const uint8_t *__restrict__ m, int n, int H, int W, int h, int w, float thr,
+                                                              uint8_t *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)n * h * w;
+    if (idx >= total) return;
+    const int x = (int)(idx % w); int64_t t = idx / w; const int y = (int)(t % h); const int64_t k = t / h;
+    const int ys = (int)floorf((float)(y * H) / (float)h), ye = (int)ceilf((float)((y + 1) * H) / (float)h);
+    const int xs = (int)floorf((float)(x * W) / (float)w), xe = (int)ceilf((float)((x + 1) * W) / (float)w);
+    const uint8_t *P = m + k * (int64_t)H * W;
+    float sum = 0.0f;
+    for (int yy = ys; yy < ye; ++yy)
+        for (int xx = xs; xx < xe; ++xx) sum += P[(int64_t)yy * W + xx] ? 1.0f : 0.0f;
+    out[idx] = (sum / (float)(ye - ys) / (float)(xe - xs)) > thr ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int csm_mean_std(const float *x, int64_t n, float *out2, void *scratch, void *stream) {
+    CSM_REQUIRE(x && out2 && scratch && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    double *part = (double *)scratch;
+    const int nb = (int)(n >= (1 << 18) ? 512 : (n + 1023) / 1024 > 0 ? (n + 1023) / 1024 : 1);
+    k_sum_partial<<<nb, 256, 0, st>>>(x, n, nullptr, part);
+    k_sum_final<<<1, 256, 0, st>>>(part, nb, n, 0, out2);
+    k_sum_partial<<<nb, 256, 0, st>>>(x, n, out2, part);
+    k_sum_final<<<1, 256, 0, st>>>(part, nb, n, 1, out2 + 1);
+    return csm::check_launch("k_mean_std");
+}
+extern "C" size_t csm_mean_std_scratch_bytes(void) { return 512 * sizeof(double); }
+
+extern "C" int csm_normalise_mean_std(const float *x, int64_t n, const float *mean_std_dev, float *out, void *stream) {
+    CSM_REQUIRE(x && mean_std_dev && out && n > 0);
+    k_normalise_ms<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(x, n, mean_std_dev, out);
+    return csm::check_launch("k_normalise_ms");
+}
+extern "C" int csm_denormalise_mean_std(const float *x, int64_t n, const float *mean_std_dev, int mode, float *out, void *stream) {
+    CSM_REQUIRE(x && mean_std_dev && out && n > 0 && mode >= 0 && mode <= 2);
+    k_denormalise_ms<<<csm::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(x, n, mean_std_dev, mode, out);
+    return csm::check_launch("k_denormalise_ms");
+}
+
+extern "C" int csm_resize_bilinear_planes(const float *in, int planes, int H, int W, int h, int w, int align_corners, float *out, void *stream) {
+    CSM_REQUIRE(in && out && planes > 0 && H > 0 && W > 0 && h > 0 && w > 0);
+    float sh, sw;
+    if (align_corners) { sh = h > 1 ? (float)(H - 1) / (float)(h - 1) : 0.0f; sw = w > 1 ? (float)(W - 1) / (float)(w - 1) : 0.0f; }
+    else { sh = (float)H / (float)h; sw = (float)W / (float)w; }
+    k_bilinear_planes<<<csm::cdiv((int64_t)planes * h * w, 256), 256, 0, (hipStream_t)stream>>>(in, planes, H, W, h, w, align_corners, sh, sw, out);
+    return csm::check_launch("k_bilinear_planes");
+}
+
+extern "C" int csm_mask_area_resize_threshold(const uint8_t *masks, int n, int H, int W, int h, int w, float thr, uint8_t *out, void *stream) {
+    CSM_REQUIRE(masks && out && n > 0 && H > 0 && W > 0 && h > 0 && w > 0 && (int64_t)H * h < (1 << 24) && (int64_t)W * w < (1 << 24));
+    k_mask_area_threshold<<<csm::cdiv((int64_t)n * h * w, 256), 256, 0, (hipStream_t)stream>>>(masks, n, H, W, h, w, thr, out);
+    return csm::check_launch("k_mask_area_threshold");
+}

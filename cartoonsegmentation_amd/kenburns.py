@@ -152,8 +152,7 @@ def depth_adjustment_animesseg(instances, tenDisparity, tenImage, use_medium=Fal
     assert tenDisparity.shape[0] == 1
     masks = [] if instances.is_empty else ([instances.masks[i].float() for i in range(instances.masks.shape[0])] if use_medium else [True])
     resized = tenDisparity.shape[2:] != tenImage.shape[2:]
-    adj = torch.nn.functional.interpolate(tenDisparity, size=tuple(tenImage.shape[2:]), mode='bilinear', align_corners=False) \
-        if resized else tenDisparity
+    adj = ops.resize_bilinear(tenDisparity, int(tenImage.shape[2]), int(tenImage.shape[3])) if resized else tenDisparity
     if use_medium:
         for m in masks:
             plane = adj * m
@@ -173,7 +172,7 @@ def depth_adjustment_animesseg(instances, tenDisparity, tenImage, use_medium=Fal
         for i in range(mk.shape[0]):
             check(_lib.load().csm_depth_adjust_instance(ptr(adj), ptr(mk[i]), i32(H), i32(W), ptr(scratch), stream_ptr()), "depth_adjust")
     if resized:
-        return torch.nn.functional.interpolate(adj, size=tuple(tenDisparity.shape[2:]), mode='bilinear', align_corners=False)
+        return ops.resize_bilinear(adj, int(tenDisparity.shape[2]), int(tenDisparity.shape[3]))
     return adj
 
 
@@ -305,7 +304,7 @@ class KenBurnsPipeline:
         H, W = int(img_tensor.shape[2]), int(img_tensor.shape[3])
         ratio = float(W) / float(H)
         w, h = min(int(512 * ratio), 512), min(int(512 / ratio), 512)
-        x = torch.nn.functional.interpolate(img_tensor, size=(h, w), mode='bilinear', align_corners=False).contiguous()
+        x = ops.resize_bilinear(img_tensor, h, w)
         if (h, w) not in self._disp_progs:
             self._disp_progs[(h, w)] = (CompiledProgram(build_semantics(self._sem_ws, h, w), self.device),
                                         CompiledProgram(build_disparity(self._disp_ws, h, w), self.device))
@@ -337,14 +336,11 @@ class KenBurnsPipeline:
         H, W, h, w = img.shape[2], img.shape[3], disparity.shape[2], disparity.shape[3]
         if (H, W, h, w) not in self._refine_progs:
             self._refine_progs[(H, W, h, w)] = CompiledProgram(build_refine(self._refine_ws, H, W, h, w), self.device)
-        tenMean = [img.mean([1, 2, 3], True), disparity.mean([1, 2, 3], True)]
-        tenStd = [img.std([1, 2, 3], False, True), disparity.std([1, 2, 3], False, True)]
-        ni = ((img - tenMean[0]) / (tenStd[0] + 0.0000001)).contiguous()
-        nd = ((disparity - tenMean[1]) / (tenStd[1] + 0.0000001)).contiguous()
+        ms_i, ms_d = ops.mean_std(img), ops.mean_std(disparity)              # statistics stay on the device
+        ni, nd = ops.normalise(img, ms_i), ops.normalise(disparity, ms_d)
         out = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
         self._refine_progs[(H, W, h, w)].run(ni, nd, out)
-        out = out * (tenStd[1] + 0.0000001) + tenMean[1]
-        return torch.nn.functional.threshold(out, threshold=0.0, value=0.0)
+        return ops.denormalise(out, ms_d, 2)                                  # * (std + 1e-7) + mean, threshold(0)
 
     def set_inpainting(self, inpainting: str):
         """kenburns_effect.py:425-440: 'default' = the Inpaint GridNet; 'ldm'/'patchmatch' call external services"""
@@ -383,20 +379,18 @@ class KenBurnsPipeline:
         if shared is None or shared[0] != key:
             _, _, pts, _ = ops.disparity_to_points(tenDisparity, f, b, eps=0.0000001)
             pts = pts.view(1, 3, -1)
-            tenMean = [tenImage.mean([1, 2, 3], True), tenDisparity.mean([1, 2, 3], True)]
-            tenStd = [tenImage.std([1, 2, 3], False, True), tenDisparity.std([1, 2, 3], False, True)]
-            ni = (tenImage - tenMean[0]) / (tenStd[0] + 0.0000001)
-            nd = (tenDisparity - tenMean[1]) / (tenStd[1] + 0.0000001)
+            ms_i, ms_d = ops.mean_std(tenImage), ops.mean_std(tenDisparity)
+            ni, nd = ops.normalise(tenImage, ms_i), ops.normalise(tenDisparity, ms_d)
             x = torch.cat([ni, nd], 1).contiguous()
             ctx = torch.empty((1, 64, H, W), dtype=torch.float32, device=self.device)
             ctx_p.run(x, ctx)
             feat = torch.cat([ni, nd, ctx], 1).view(1, 68, -1)
-            shared = (key, pts, tenMean, tenStd, nd, feat)
+            shared = (key, pts, ms_i, ms_d, nd, feat)
             try:
                 objCommon._inpaint_shared = shared
             except AttributeError:                                              # a plain dict config: no caching
                 pass
-        _, pts, tenMean, tenStd, nd, feat = shared
+        _, pts, ms_i, ms_d, nd, feat = shared
         ps = (pts + tenShift).contiguous()
         render, existing = ops.render_pointcloud(ps, feat, W, H, f, b)
         if segmasks is not None:
@@ -409,10 +403,8 @@ class KenBurnsPipeline:
         img = torch.empty((1, 3, H, W), dtype=torch.float32, device=self.device)
         dsp = torch.empty((1, 1, H, W), dtype=torch.float32, device=self.device)
         grid_p.run(gin, img, dsp)
-        img = img * (tenStd[0] + 0.0000001) + tenMean[0]
-        dsp = dsp * (tenStd[1] + 0.0000001) + tenMean[1]
-        return {'tenExisting': existing, 'tenImage': img.clip(0.0, 1.0),
-                'tenDisparity': torch.nn.functional.threshold(dsp, threshold=0.0, value=0.0), 'segmasks': segmasks}
+        return {'tenExisting': existing, 'tenImage': ops.denormalise(img, ms_i, 1),          # * (std + 1e-7) + mean, clip(0, 1)
+                'tenDisparity': ops.denormalise(dsp, ms_d, 2), 'segmasks': segmasks}       # ..., threshold(0)
 
     def inpaint(self, tenShift, tenPoints, objCommon: KenBurnsConfig, verbose: bool = False):
         """kenburns_effect.py:441-512 (inpaint_type 'default'): inpaint the view at `tenShift` and append the points that

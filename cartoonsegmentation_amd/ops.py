@@ -177,6 +177,42 @@ def resize_f32_linear(img, h, w):
     return out
 
 
+def resize_bilinear(x, h, w, align_corners=False):
+    """torch.nn.functional.interpolate(x, size=(h, w), mode='bilinear', align_corners=...) of a float32 NCHW device tensor (aten
+    upsample_bilinear2d restated: csm_resize_bilinear_planes)"""
+    x = _dev(x, "x")
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().csm_resize_bilinear_planes(ptr(x), i32(N * C), i32(H), i32(W), i32(h), i32(w), i32(1 if align_corners else 0), ptr(out),
+                                                 stream_ptr()), "resize_bilinear_planes")
+    return out
+
+
+def mean_std(x):
+    """device tensor {x.mean(), x.std(unbiased=False)} over all elements (the statistics of Inpaint.forward / Refine.forward)"""
+    x = _dev(x, "x")
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(_lib.load().csm_mean_std_scratch_bytes(), dtype=torch.uint8, device=x.device)
+    check(_lib.load().csm_mean_std(ptr(x), i64(x.numel()), ptr(out), ptr(scratch), stream_ptr()), "mean_std")
+    return out
+
+
+def normalise(x, ms):
+    """(x - mean) / (std + 1e-7) with ms = mean_std(...)"""
+    x = _dev(x, "x")
+    out = torch.empty_like(x)
+    check(_lib.load().csm_normalise_mean_std(ptr(x), i64(x.numel()), ptr(ms), ptr(out), stream_ptr()), "normalise_mean_std")
+    return out
+
+
+def denormalise(x, ms, mode=0):
+    """x * (std + 1e-7) + mean; mode 1: .clip(0, 1), mode 2: threshold(0, 0)"""
+    x = _dev(x, "x")
+    out = torch.empty_like(x)
+    check(_lib.load().csm_denormalise_mean_std(ptr(x), i64(x.numel()), ptr(ms), i32(mode), ptr(out), stream_ptr()), "denormalise_mean_std")
+    return out
+
+
 def autozoom_coverage(tenPoints, shifts, intWidth, intHeight, fltFocal, fltBaseline, chunk=None, host=True):
     """coverage counts `(tenExisting > 0.0).float().sum()` of render_pointcloud(process_shift(tenPoints, shift_k)) for every
     candidate shift_k = (sx, sy, sz) -- common.py:110-126 -- in batched launches (csm_autozoom_coverage), no colour rendered,

@@ -2,7 +2,7 @@
 
 Same constructor / infer() signature and result type (AnimeInstances), so run_segmentation.ipynb drops in.
 Flow per image (reference :464-504, :447-462, :638-665), everything on the MI355X, masks never leave HBM:
-  uint8 image --csm_det_preprocess--> RTMDet-Ins layer program --decode (tiny torch index ops)--> csm_nms -->
+  uint8 image --csm_det_preprocess--> RTMDet-Ins layer program --csm_det_decode--> csm_nms --csm_det_gather-->
   csm_maskhead_logits --> csm_mask_resize_threshold --> [ISNet refine: csm_refine_prepare_batch --> ISNet layer
   program --> csm_refine_threshold] --> AnimeInstances(masks bool [n,H,W], bboxes xywh int32, scores).
 The reference makes 5 host<->device crossings per image; here the only syncs are the data-dependent counts.
@@ -106,7 +106,7 @@ class AnimeInsSeg:
             blob = torch.load(ckpt, map_location='cpu', weights_only=False)
             self.cfg = config_from_ckpt_cfg(blob['meta']['cfg'])
             self._det_ws = StateDictWeights(blob['state_dict'])
-        self._det_programs, self._det_weights, self._prior_cache = {}, None, {}
+        self._det_programs, self._det_weights = {}, None
         self._refine_programs, self._refine_weights, self._refine_ws = {}, None, None
         self.refine_method = None
         self.refine_batch = int(os.environ.get('CSM_REFINE_BATCH', '16'))   # instances per ISNet run when frames are batched
@@ -149,14 +149,6 @@ class AnimeInsSeg:
             self._det_weights = cp.weights
             self._det_programs[(S, n)] = (rp, cp)
         return self._det_programs[(S, n)]
-
-    def _priors(self, S, lvl, hl, wl, stride):
-        key = (S, lvl)
-        if key not in self._prior_cache:
-            ys, xs = torch.meshgrid(torch.arange(hl, device=self.device), torch.arange(wl, device=self.device), indexing='ij')
-            st = torch.full_like(xs.reshape(-1), stride)
-            self._prior_cache[key] = torch.stack([xs.reshape(-1) * stride, ys.reshape(-1) * stride, st, st], 1).float()
-        return self._prior_cache[key]
 
     def _refiner(self, n, T):
         if (n, T) not in self._refine_programs:
@@ -254,63 +246,59 @@ class AnimeInsSeg:
         return self._decode_batch(rp, cp, nb, H, W, S, rh, rw, w_scale, h_scale)
 
     def _decode_batch(self, rp, cp, nb, H, W, S, rh, rw, w_scale, h_scale):
-        """mmdet RTMDetInsHead.predict_by_feat / _bbox_mask_post_process up to NMS, for all images of the batch with FIXED
-        shapes and one host sync: instead of filtering (`scores > score_thr`, data-dependent sizes) invalid candidates get
-        score -1, which the stable descending sorts push behind every valid one; they cannot suppress a valid box in the
-        greedy NMS (a box only suppresses lower-ranked ones) and are dropped at the end.  Same kept set and order as the
-        filter-then-topk of the reference."""
+        """mmdet RTMDetInsHead.predict_by_feat / _bbox_mask_post_process up to and including NMS, for all images of the batch, on the
+        device with FIXED shapes and one host sync (csm_det_decode -> csm_nms -> csm_det_gather, csrc/detdecode.hip): instead of
+        filtering (`scores > score_thr`, data-dependent sizes) invalid candidates carry score -1, which the stable descending sorts
+        push behind every valid one; they cannot suppress a valid box in the greedy NMS (a box only suppresses lower-ranked ones) and
+        are dropped at the end.  Same kept set and order as the filter-then-topk of the reference."""
         L, cfg, dev = _lib.load(), self.cfg, self.device
-        nc = cfg.num_classes
-        sc_l, lab_l, dist_l, pri_l, ker_l = [], [], [], [], []
-        for lvl, stride in enumerate(cfg.strides):
-            cls = cp.view(rp.cls[lvl]).reshape(nb, -1)                             # [nb, P_l*nc], sigmoid fused in the conv epilogue
-            k = min(cfg.nms_pre, cls.shape[1])
-            masked = torch.where(cls > cfg.score_thr, cls, cls.new_full((), -1.0))  # filter_scores_and_topk
-            sc, order = masked.sort(dim=1, descending=True, stable=True)
-            sc, order = sc[:, :k], order[:, :k]
-            keep, lab = order // nc, order % nc
-            reg = cp.view(rp.reg[lvl]).reshape(nb, -1, 4) * float(stride)           # F.relu(rtm_reg) * stride
-            ker = cp.view(rp.kern[lvl]).reshape(nb, -1, cfg.num_gen_params)
-            pri = self._priors(S, lvl, rp.cls[lvl].h, rp.cls[lvl].w, stride)        # MlvlPointGenerator(offset=0), cached
-            sc_l.append(sc); lab_l.append(lab)
-            dist_l.append(torch.gather(reg, 1, keep[..., None].expand(-1, -1, 4)))
-            ker_l.append(torch.gather(ker, 1, keep[..., None].expand(-1, -1, cfg.num_gen_params)))
-            pri_l.append(pri[keep])
-        scores, labels = torch.cat(sc_l, 1), torch.cat(lab_l, 1)
-        dist, priors, kernels = torch.cat(dist_l, 1), torch.cat(pri_l, 1), torch.cat(ker_l, 1)
-        x1 = (priors[..., 0] - dist[..., 0]).clamp(0, rw); y1 = (priors[..., 1] - dist[..., 1]).clamp(0, rh)   # distance2bbox
-        x2 = (priors[..., 0] + dist[..., 2]).clamp(0, rw); y2 = (priors[..., 1] + dist[..., 3]).clamp(0, rh)
-        sf = torch.tensor([1 / w_scale, 1 / h_scale] * 2, dtype=torch.float32, device=dev)                     # rescale=True
-        boxes = torch.stack([x1, y1, x2, y2], 2) * sf
-        valid = scores > cfg.score_thr
-        if cfg.min_bbox_size >= 0:
-            valid = valid & ((boxes[..., 2] - boxes[..., 0]) > cfg.min_bbox_size) & ((boxes[..., 3] - boxes[..., 1]) > cfg.min_bbox_size)
-        scores = torch.where(valid, scores, scores.new_full((), -1.0))
-        boxes = boxes * valid[..., None]
-        scores, order = scores.sort(dim=1, descending=True, stable=True)
-        K = min(scores.shape[1], 4096)
-        scores, order = scores[:, :K], order[:, :K]
-        g4 = order[..., None].expand(-1, -1, 4)
-        boxes, priors = torch.gather(boxes, 1, g4).contiguous(), torch.gather(priors, 1, g4)
-        kernels = torch.gather(kernels, 1, order[..., None].expand(-1, -1, cfg.num_gen_params))
-        labels = torch.gather(labels, 1, order)
-        offs = (labels.float() * (boxes.amax(dim=(1, 2), keepdim=False)[:, None] + 1)).contiguous() if nc > 1 else None
-        keep = torch.zeros((nb, cfg.max_per_img), dtype=torch.int32, device=dev)
+        nc, nl, G, M = cfg.num_classes, len(cfg.strides), cfg.num_gen_params, cfg.max_per_img
+        if cfg.score_thr < 0:
+            raise _lib.CsmError("score_thr must be >= 0 (scores are sigmoids; the device top-k orders their bit patterns)")
+
+        def base(v):                                       # device address of the first element of an NHWC view in the workspace
+            return cp.workspace.data_ptr() + 4 * (v.buf.offset + v.coff)
+        vp = ctypes.c_void_p * nl
+        cls_p, reg_p, ker_p = (vp(*[base(t[l]) for l in range(nl)]) for t in (rp.cls, rp.reg, rp.kern))
+        level_hw = (ctypes.c_int * (2 * nl))(*[v for l in range(nl) for v in (rp.cls[l].h, rp.cls[l].w)])
+        strides = (ctypes.c_int * nl)(*[int(s) for s in cfg.strides])
+        lds3 = (ctypes.c_int * (3 * nl))(*[v for l in range(nl) for v in (rp.cls[l].buf.c, rp.reg[l].buf.c, rp.kern[l].buf.c)])
+        slots = L.csm_det_decode_slots(level_hw, i32(nl), i32(nc), i32(cfg.nms_pre))
+        if slots < 0:
+            raise _lib.CsmError("detector decode: nms_pre <= 1024 and at most 4096 candidates per image are supported")
+        K = min(slots, 4096)
+        scores = torch.empty((nb, K), dtype=torch.float32, device=dev)
+        boxes = torch.empty((nb, K, 4), dtype=torch.float32, device=dev)
+        src = torch.empty((nb, K), dtype=torch.int32, device=dev)
+        labels = torch.empty((nb, K), dtype=torch.int32, device=dev)
+        offs = torch.empty((nb, K), dtype=torch.float32, device=dev) if nc > 1 else None
+        scratch = torch.empty(L.csm_det_decode_scratch_bytes(i32(nb), i32(slots)), dtype=torch.uint8, device=dev)
+        sfx, sfy = float(np.float32(1 / w_scale)), float(np.float32(1 / h_scale))                                      # rescale=True
+        check(L.csm_det_decode(cls_p, reg_p, level_hw, strides, lds3, i32(nl), i32(nb), i32(nc), f32(cfg.score_thr), i32(cfg.nms_pre),
+                               f32(rw), f32(rh), f32(sfx), f32(sfy), f32(cfg.min_bbox_size), i32(K), ptr(scores), ptr(boxes), ptr(src),
+                               ptr(labels), ptr(offs), ptr(scratch), stream_ptr()), "det_decode")
+        keep = torch.zeros((nb, M), dtype=torch.int32, device=dev)
         nk = torch.zeros(nb, dtype=torch.int32, device=dev)
-        scratch = torch.empty(L.csm_nms_scratch_bytes(i32(K)), dtype=torch.uint8, device=dev)
+        nscr = torch.empty(L.csm_nms_scratch_bytes(i32(K)), dtype=torch.uint8, device=dev)
         for bi in range(nb):
-            check(L.csm_nms(ptr(boxes[bi]), ptr(None if offs is None else offs[bi]), i32(K), f32(cfg.nms_iou), i32(cfg.max_per_img),
-                            ptr(keep[bi]), ptr(nk[bi:bi + 1]), ptr(scratch), stream_ptr()), "nms")
-        kept_scores = torch.gather(scores, 1, keep.long())
-        nk_h, ks_h = nk.tolist(), kept_scores.tolist()                             # the one host sync of the decode
+            check(L.csm_nms(ptr(boxes[bi]), ptr(None if offs is None else offs[bi]), i32(K), f32(cfg.nms_iou), i32(M),
+                            ptr(keep[bi]), ptr(nk[bi:bi + 1]), ptr(nscr), stream_ptr()), "nms")
+        k_scores = torch.empty((nb, M), dtype=torch.float32, device=dev)
+        k_boxes = torch.empty((nb, M, 4), dtype=torch.float32, device=dev)
+        k_labels = torch.empty((nb, M), dtype=torch.int32, device=dev)
+        k_priors = torch.empty((nb, M, 4), dtype=torch.float32, device=dev)
+        k_kernels = torch.empty((nb, M, G), dtype=torch.float32, device=dev)
+        check(L.csm_det_gather(ker_p, level_hw, strides, lds3, i32(nl), i32(nb), i32(K), i32(M), i32(G), ptr(keep), ptr(scores), ptr(boxes),
+                               ptr(src), ptr(labels), ptr(k_scores), ptr(k_boxes), ptr(k_labels), ptr(k_priors), ptr(k_kernels),
+                               stream_ptr()), "det_gather")
+        nk_h, ks_h = nk.tolist(), k_scores.tolist()                                # the one host sync of the decode
         outs = []
         for bi in range(nb):
             n = sum(1 for j in range(nk_h[bi]) if ks_h[bi][j] > cfg.score_thr)    # valid ones come first in keep[]
             out = dict(H=H, W=W, S=S, rh=rh, rw=rw, w_scale=w_scale, h_scale=h_scale, rp=rp, cp=cp, bi=bi, n=n)
             if n:
-                kidx = keep[bi, :n].long()
-                out.update(boxes=boxes[bi][kidx], scores=scores[bi][kidx], priors=priors[bi][kidx].contiguous(),
-                           kernels=kernels[bi][kidx].contiguous(), labels=labels[bi][kidx], scores_host=ks_h[bi][:n])
+                out.update(boxes=k_boxes[bi, :n], scores=k_scores[bi, :n], priors=k_priors[bi, :n], kernels=k_kernels[bi, :n],
+                           labels=k_labels[bi, :n], scores_host=ks_h[bi][:n])
             outs.append(out)
         return outs
 

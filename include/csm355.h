@@ -241,6 +241,25 @@ int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_tensor_desc 
                             float *op_ms);
 
 /* ------------------------------------------------------------------------------------
+ * Glue around the Inpaint / Refine nets, the depth-adjustment resize branch and AnimeInstances.resize (rounds 1-2 used torch ops here)
+ * ---------------------------------------------------------------------------------- */
+
+/* out2 = {x.mean(), x.std(unbiased=False)} over all n elements (pointcloud_inpainting.py:116-119, disparity_refinement.py:97-98);
+ * double accumulation, two passes; scratch: csm_mean_std_scratch_bytes() bytes. */
+size_t csm_mean_std_scratch_bytes(void);
+int csm_mean_std(const float *x, int64_t n, float *out2, void *scratch, void *stream);
+/* out = (x - mean) / (std + 1e-7) with {mean, std} read from device memory (:121-131 / :100-107) */
+int csm_normalise_mean_std(const float *x, int64_t n, const float *mean_std_dev, float *out, void *stream);
+/* out = x * (std + 1e-7) + mean, then mode 0: nothing, 1: clip(0, 1) (tenImage), 2: threshold(0.0, 0.0) (tenDisparity) */
+int csm_denormalise_mean_std(const float *x, int64_t n, const float *mean_std_dev, int mode, float *out, void *stream);
+/* torch.nn.functional.interpolate(mode='bilinear', align_corners=...) of `planes` [H,W] planes (NCHW with N*C = planes) to [h,w]:
+ * depth_adjustment_animesseg's resize round trip (kenburns_effect.py:49-52, :89-90), disparity_estimation's input resize */
+int csm_resize_bilinear_planes(const float *in, int planes, int H, int W, int h, int w, int align_corners, float *out, void *stream);
+/* AnimeInstances.resize (animeinsseg/anime_instances.py:268-280): interpolate(masks.float(), (h, w), mode='area') > thr on boolean
+ * masks [n,H,W] (1 B per pixel) -> [n,h,w] */
+int csm_mask_area_resize_threshold(const uint8_t *masks, int n, int H, int W, int h, int w, float thr, uint8_t *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * ZoeDepth plumbing around the metric-bins head (CSM_OP_ATTRACTOR / CSM_OP_LOGBINOM) and the pluggable MiDaS core
  * replaces DepthModel.infer / _infer_with_pad_aug / infer_with_flip_aug (depth_modules/zoedepth/models/depth_model.py:57-129),
  * PrepForMidas + Resize (models/base_models/midas.py:49-187) and the tail of _depth_est_zoe (kenburns_effect.py:812-818)
@@ -264,6 +283,31 @@ int csm_zoe_depth_to_disparity(const float *depth, int64_t n, float focal_times_
 /* np.packbits(mask != 0, bitorder='little'): boolean instance masks (1 B per pixel, as AnimeInstances holds them) -> 1 bit per pixel,
  * the wire format of the per-rank output gather.  out: ceil(n / 8) bytes. */
 int csm_pack_mask_bits(const uint8_t *mask, int64_t n, uint8_t *out, void *stream);
+
+/* RTMDet-Ins box decode between the head's raw maps and NMS -- mmdet RTMDetInsHead.predict_by_feat / _predict_by_feat_single /
+ * _bbox_mask_post_process + filter_scores_and_topk [EXT mmdet 3.3.0; call site animeinsseg/__init__.py:450 model.test_step], with
+ * FIXED shapes and no host sync: per level the `nms_pre` highest scores above score_thr (stable descending order), distance2bbox
+ * against the resized-image bounds, rescale to the original image, min_bbox_size filter, then all levels merged in score order.
+ * Slots without a valid candidate carry score -1 and sort last (they can never suppress a valid box in the greedy NMS).
+ *   cls / reg: HOST arrays of n_levels DEVICE pointers to NHWC maps [nb, h_l, w_l, *] (cls: num_classes sigmoid scores per prior,
+ *   reg: 4 relu'd distances in stride units); level_hw {h0, w0, h1, w1, ...}; strides; lds3 {cls, reg, kernel channel pitch} per level.
+ *   outputs per image, in NMS order: scores [nb,K], boxes [nb,K,4] xyxy, src [nb,K] (global prior index, level-major), labels [nb,K],
+ *   class_offsets [nb,K] = label * (max box coordinate + 1) (written when num_classes > 1; may be NULL otherwise).
+ *   K <= csm_det_decode_slots(...) = sum_l min(nms_pre, h_l w_l num_classes) (<= 4096; nms_pre <= 1024; -1 = unsupported).
+ *   scratch: csm_det_decode_scratch_bytes(nb, slots). */
+int csm_det_decode_slots(const int *level_hw, int n_levels, int num_classes, int nms_pre);
+size_t csm_det_decode_scratch_bytes(int nb, int slots);
+int csm_det_decode(const float *const *cls, const float *const *reg, const int *level_hw, const int *strides, const int *lds3,
+                   int n_levels, int nb, int num_classes, float score_thr, int nms_pre, float clamp_w, float clamp_h,
+                   float scale_x, float scale_y, float min_bbox_size, int K, float *scores, float *boxes, int *src, int *labels,
+                   float *class_offsets, void *scratch, void *stream);
+/* After NMS: for the max_keep slots of keep [nb, max_keep] (indices into the K candidates; slots past the kept count are ignored by
+ * the caller) gather scores, boxes, labels, the priors (x, y, stride, stride: MlvlPointGenerator offset 0) and the num_gen_params
+ * dynamic-conv parameters from the per-level kernel maps. */
+int csm_det_gather(const float *const *kern, const int *level_hw, const int *strides, const int *lds3, int n_levels, int nb, int K,
+                   int max_keep, int num_gen_params, const int *keep, const float *scores, const float *boxes, const int *src,
+                   const int *labels, float *kept_scores, float *kept_boxes, int *kept_labels, float *kept_priors,
+                   float *kept_kernels, void *stream);
 
 /* Greedy NMS, replaces mmcv.ops.batched_nms -> nms (C++/CUDA ext; call site: mmdet head, imported at
  * animeinsseg/models/rtmdet_inshead_custom.py:10).  boxes [n,4] xyxy sorted by descending score;

@@ -548,3 +548,30 @@ def test_device_focal_plane_median_matches_numpy():
         assert (np.isnan(got[k]) and np.isnan(want[k])) or got[k] == np.float32(want[k]), (k, got[k], want[k])
     assert got[5] == np.float32(np.nanmax(want))
     assert run(np.zeros((2, H, W), bool))[2] == -1.0
+
+
+def test_hand_written_glue_kernels_match_torch():
+    """the kernels that replaced torch ops on the product path (round 3): mean / std (double accumulation), normalise / de-normalise
+    with clip and threshold, aten bilinear on planes, adaptive-area mask resize + 0.3 threshold (AnimeInstances.resize)"""
+    from cartoonsegmentation_amd import ops
+    from cartoonsegmentation_amd.anime_instances import AnimeInstances
+    F = torch.nn.functional
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn((1, 3, 301, 417), device='cuda', generator=g) * 3 + 0.7
+    ms = ops.mean_std(x)
+    ref = torch.stack([x.double().mean(), x.double().std(unbiased=False)]).float()
+    assert torch.allclose(ms, ref, rtol=1e-6, atol=0)
+    n = ops.normalise(x, ms)
+    assert torch.allclose(n, (x - ms[0]) / (ms[1] + 0.0000001), rtol=1e-6, atol=1e-7)
+    for mode, fn in ((1, lambda t: t.clip(0.0, 1.0)), (2, lambda t: F.threshold(t, 0.0, 0.0)), (0, lambda t: t)):
+        assert torch.allclose(ops.denormalise(n, ms, mode), fn(n * (ms[1] + 0.0000001) + ms[0]), rtol=1e-6, atol=1e-6)
+    for (h, w, ac) in ((150, 200, False), (640, 333, False), (77, 91, True), (301, 417, False)):
+        got, want = ops.resize_bilinear(x, h, w, align_corners=ac), F.interpolate(x, size=(h, w), mode='bilinear', align_corners=ac)
+        assert got.shape == want.shape and torch.allclose(got, want, rtol=1e-5, atol=1e-5), (h, w, ac)
+    masks = torch.rand((3, 250, 310), device='cuda', generator=g) > 0.6
+    masks[1, :, :100] = True
+    for (h, w) in ((125, 155), (100, 123), (400, 512), (250, 311), (83, 31)):
+        inst = AnimeInstances(masks.clone(), torch.tensor([[10, 20, 30, 40]] * 3, dtype=torch.int32, device='cuda'), torch.ones(3, device='cuda'))
+        inst.resize(h, w)
+        want = F.interpolate(masks.float().unsqueeze(1), (h, w), mode='area').squeeze(1) > 0.3
+        assert inst.masks.dtype == torch.bool and torch.equal(inst.masks, want), (h, w)

@@ -129,3 +129,78 @@ def test_infer_accepts_a_path_and_a_directory(tmp_path):
     for nm, o in zip(order, outs):
         r = net.infer(imgs[names.index(nm)], pred_score_thr=0.3, max_instances=2, output_type='numpy')
         assert len(o) == len(r) and (len(r) == 0 or np.array_equal(o.masks, r.masks))
+
+
+def test_device_decode_matches_filter_then_topk_with_ties_and_classes():
+    """csm_det_decode + csm_det_gather (hand-written top-k / merge sort / box decode, csrc/detdecode.hip) against a numpy statement of
+    mmdet's filter_scores_and_topk -> distance2bbox -> rescale -> min_bbox_size filter -> score sort [EXT], on random head maps with
+    HEAVY score ties (stable order: score descending, then prior * nc + class ascending, then level), 3 classes, 2 images, a level
+    with fewer candidates than nms_pre and one with more, and boxes below min_bbox_size"""
+    import ctypes
+    from cartoonsegmentation_amd import _lib
+    from cartoonsegmentation_amd._lib import check, f32, i32, ptr, stream_ptr
+    L = _lib.load()
+    rng = np.random.default_rng(8)
+    nb, nc, G, nms_pre, thr = 2, 3, 7, 40, 0.25
+    hw, strides = [(12, 10), (6, 5), (3, 3)], [8, 16, 32]
+    clamp_w, clamp_h, sx, sy, min_box = 75.0, 90.0, np.float32(1.37), np.float32(0.81), 2.5
+    cls = [(rng.integers(0, 12, (nb, h, w, nc)) / 12.0).astype(np.float32) * 0.9 + 0.05 for h, w in hw]        # 12 distinct values: ties everywhere
+    reg = [rng.uniform(0, 3.0, (nb, h, w, 4)).astype(np.float32) for h, w in hw]
+    reg[0][:, :3] *= 0.02                                                                                         # tiny boxes -> min_bbox_size filter
+    kern = [rng.normal(0, 1, (nb, h, w, G)).astype(np.float32) for h, w in hw]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()                                               # noqa: E731
+    cls_d, reg_d, kern_d = [d(a) for a in cls], [d(a) for a in reg], [d(a) for a in kern]
+    nl = 3
+    vp = ctypes.c_void_p * nl
+    cp_, rp_, kp_ = vp(*[t.data_ptr() for t in cls_d]), vp(*[t.data_ptr() for t in reg_d]), vp(*[t.data_ptr() for t in kern_d])
+    level_hw = (ctypes.c_int * 6)(*[v for h, w in hw for v in (h, w)])
+    st = (ctypes.c_int * 3)(*strides)
+    lds3 = (ctypes.c_int * 9)(*[v for _ in range(3) for v in (nc, 4, G)])
+    slots = L.csm_det_decode_slots(level_hw, i32(nl), i32(nc), i32(nms_pre))
+    assert slots == 40 + 40 + 27
+    K = slots
+    scores = torch.empty((nb, K), device='cuda'); boxes = torch.empty((nb, K, 4), device='cuda')
+    src = torch.empty((nb, K), dtype=torch.int32, device='cuda'); labels = torch.empty((nb, K), dtype=torch.int32, device='cuda')
+    offs = torch.empty((nb, K), device='cuda')
+    scratch = torch.empty(L.csm_det_decode_scratch_bytes(i32(nb), i32(slots)), dtype=torch.uint8, device='cuda')
+    check(L.csm_det_decode(cp_, rp_, level_hw, st, lds3, i32(nl), i32(nb), i32(nc), f32(thr), i32(nms_pre), f32(clamp_w), f32(clamp_h),
+                           f32(float(sx)), f32(float(sy)), f32(min_box), i32(K), ptr(scores), ptr(boxes), ptr(src), ptr(labels), ptr(offs),
+                           ptr(scratch), stream_ptr()))
+    prior0 = [0, 120, 150]
+    for b in range(nb):
+        sc_l, box_l, src_l, lab_l = [], [], [], []
+        for l, ((h, w), s) in enumerate(zip(hw, strides)):
+            flat = cls[l][b].reshape(-1)
+            idx = np.nonzero(flat > np.float32(thr))[0]
+            order = np.argsort(-flat[idx], kind='stable')[:nms_pre]
+            idx = idx[order]
+            p, lab = idx // nc, idx % nc
+            px, py = ((p % w) * s).astype(np.float32), ((p // w) * s).astype(np.float32)
+            dist = reg[l][b].reshape(-1, 4)[p] * np.float32(s)
+            x1 = np.clip(px - dist[:, 0], 0, np.float32(clamp_w)) * sx; y1 = np.clip(py - dist[:, 1], 0, np.float32(clamp_h)) * sy
+            x2 = np.clip(px + dist[:, 2], 0, np.float32(clamp_w)) * sx; y2 = np.clip(py + dist[:, 3], 0, np.float32(clamp_h)) * sy
+            sc_l.append(flat[idx]); box_l.append(np.stack([x1, y1, x2, y2], 1).astype(np.float32)); src_l.append(prior0[l] + p); lab_l.append(lab)
+        sc, bx, sr, lb = np.concatenate(sc_l), np.concatenate(box_l), np.concatenate(src_l), np.concatenate(lab_l)
+        ok = ((bx[:, 2] - bx[:, 0]) > np.float32(min_box)) & ((bx[:, 3] - bx[:, 1]) > np.float32(min_box))
+        assert 0 < ok.sum() < len(ok)
+        sc, bx, sr, lb = sc[ok], bx[ok], sr[ok], lb[ok]
+        order = np.argsort(-sc, kind='stable')
+        sc, bx, sr, lb = sc[order], bx[order], sr[order], lb[order]
+        n = len(sc)
+        got_s = scores[b].cpu().numpy()
+        assert np.array_equal(got_s[:n], sc) and (got_s[n:] == -1.0).all()
+        assert np.array_equal(boxes[b, :n].cpu().numpy(), bx) and np.array_equal(src[b, :n].cpu().numpy(), sr)
+        assert np.array_equal(labels[b, :n].cpu().numpy(), lb)
+        assert np.array_equal(offs[b, :n].cpu().numpy(), (lb.astype(np.float32) * (np.float32(bx.max()) + np.float32(1))).astype(np.float32))
+        # gather of an arbitrary kept list: priors and dynamic-conv parameters of the chosen candidates
+        M = 6
+        keep = torch.tensor([[0, 5, n - 1, 3, 1, 2]] * nb, dtype=torch.int32, device='cuda')
+        ks, kb, kl = torch.empty((nb, M), device='cuda'), torch.empty((nb, M, 4), device='cuda'), torch.empty((nb, M), dtype=torch.int32, device='cuda')
+        kp, kk = torch.empty((nb, M, 4), device='cuda'), torch.empty((nb, M, G), device='cuda')
+        check(L.csm_det_gather(kp_, level_hw, st, lds3, i32(nl), i32(nb), i32(K), i32(M), i32(G), ptr(keep), ptr(scores), ptr(boxes), ptr(src),
+                               ptr(labels), ptr(ks), ptr(kb), ptr(kl), ptr(kp), ptr(kk), stream_ptr()))
+        for j, r in enumerate([0, 5, n - 1, 3, 1, 2]):
+            g = int(sr[r]); l = 2 if g >= 150 else (1 if g >= 120 else 0); p = g - prior0[l]
+            assert np.array_equal(kk[b, j].cpu().numpy(), kern[l][b].reshape(-1, G)[p])
+            assert kp[b, j].cpu().numpy().tolist() == [float((p % hw[l][1]) * strides[l]), float((p // hw[l][1]) * strides[l]), float(strides[l]), float(strides[l])]
+            assert float(ks[b, j]) == float(sc[r]) and np.array_equal(kb[b, j].cpu().numpy(), bx[r]) and int(kl[b, j]) == int(lb[r])
