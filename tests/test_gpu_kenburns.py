@@ -565,9 +565,17 @@ def test_hand_written_glue_kernels_match_torch():
     assert torch.allclose(n, (x - ms[0]) / (ms[1] + 0.0000001), rtol=1e-6, atol=1e-7)
     for mode, fn in ((1, lambda t: t.clip(0.0, 1.0)), (2, lambda t: F.threshold(t, 0.0, 0.0)), (0, lambda t: t)):
         assert torch.allclose(ops.denormalise(n, ms, mode), fn(n * (ms[1] + 0.0000001) + ms[0]), rtol=1e-6, atol=1e-6)
+    # torch's device kernel is built with FMA contraction: its source coordinate scale * (dst + 0.5) - 0.5 can differ from the
+    # unfused evaluation (aten's CPU order, which libcsm355 follows) by one ulp of a coordinate ~ 400, i.e. 3e-5 in the interpolation
+    # weight -> compare a SMOOTH plane tightly (weight noise x small gradient) and white noise at the weight-noise level
+    yy, xx = torch.meshgrid(torch.arange(301, device='cuda'), torch.arange(417, device='cuda'), indexing='ij')
+    smooth = (torch.sin(xx / 40.0) * torch.cos(yy / 55.0))[None, None].float().expand(1, 3, -1, -1).contiguous()
     for (h, w, ac) in ((150, 200, False), (640, 333, False), (77, 91, True), (301, 417, False)):
-        got, want = ops.resize_bilinear(x, h, w, align_corners=ac), F.interpolate(x, size=(h, w), mode='bilinear', align_corners=ac)
-        assert got.shape == want.shape and torch.allclose(got, want, rtol=1e-5, atol=1e-5), (h, w, ac)
+        for src, tol in ((smooth, 1e-5), (x, 2e-3)):
+            got, want = ops.resize_bilinear(src, h, w, align_corners=ac), F.interpolate(src, size=(h, w), mode='bilinear', align_corners=ac)
+            assert got.shape == want.shape and torch.allclose(got, want, rtol=1e-5, atol=tol), (h, w, ac, tol)
+        cpu = F.interpolate(x.cpu(), size=(h, w), mode='bilinear', align_corners=ac)
+        assert (ops.resize_bilinear(x, h, w, align_corners=ac).cpu() - cpu).abs().max() <= 2e-3
     masks = torch.rand((3, 250, 310), device='cuda', generator=g) > 0.6
     masks[1, :, :100] = True
     for (h, w) in ((125, 155), (100, 123), (400, 512), (250, 311), (83, 31)):
