@@ -182,94 +182,37 @@ __device__ __forceinline__ void lds_min_f32(float *addr, float v) {        // wa
     else atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
-// Accumulators are FIXED POINT in LDS.  Measured on gfx950 (phase ablation of this kernel at 1024^2): splatting the five
+// Accumulators are 64-bit FIXED POINT in LDS.  Measured on gfx950 (phase ablation of this kernel at 1024^2): splatting the five
 // channels with ds_add_f32 costs 88 us per frame (~0.2 lane-atomics per clock and CU), with ds_add_u64 19 us, and a
-// sort-by-pixel + pull variant without float atomics 37 us (instruction bound); ds_add_u32 retires twice as fast as ds_add_u64.
-// Every product v * w is formed in fp32 exactly as the reference forms it (VALUE(data) * fltNorthwest, models/utils.py:270-310),
-// converted to an integer and added with an integer atomic: order free -- deterministic, unlike the reference's fp32 atomicAdd.
-//   * weight (the ones channel) and depth: 64 bit, 2^-40 resp. 2^-20 units (|v w| < 2^22 resp. 2^42): the sums are EXACT and
-//     rounded to fp32 once.  A positive product never converts to 0, so `existing > 0` and `depth mask > 0` (the decisions
-//     fill_disocclusion depends on) are exactly the reference's.
-//   * the three colour planes (round 3): 32 bit, 2^-24 units -- half the LDS-atomic time and 6 KB less LDS per tile, which lets all
-//     eight tiles of a CU be resident at once (19.6 KB instead of 25.6 KB per block).  Each contribution is truncated at 2^-24
-//     (a pixel's colour sum is within n 2^-24 of the exact sum, n = its contributions; any fp32 summation order is no closer), and a
-//     32-bit sum cannot hold more than +-128: after the splat the block checks `weight sum x max |colour| < 120` for every pixel
-//     with the EXACT weight plane (|sum v w| <= max |v| sum w); if any pixel fails (pile-ups, colours far outside [0, 1]) the tile's
-//     colours are redone one plane at a time in 64 bit.  Both forms are deterministic.
+// sort-by-pixel + pull variant without float atomics 37 us (instruction bound).  Every product v * w is formed in fp32 exactly as
+// the reference forms it (VALUE(data) * fltNorthwest, models/utils.py:270-310), converted to a 64-bit integer (2^-40 units for
+// colour and weight, 2^-20 for depth: |v w| < 2^22 resp. 2^42) and added with an integer atomic: the sum is exact, order
+// free -- deterministic, unlike the reference's fp32 atomicAdd -- and rounded to fp32 once at the end, i.e. within one ulp of the
+// exact sum every fp32 summation order approximates.  A positive product never converts to 0, so `existing > 0` and
+// `depth mask > 0` (the decisions fill_disocclusion depends on) are exactly the reference's.
 constexpr float kScaleC = 1099511627776.0f;           // 2^40
 constexpr float kScaleD = 1048576.0f;                 // 2^20
-constexpr float kScaleC32 = 16777216.0f;              // 2^24
 __device__ __forceinline__ unsigned long long to_fixed(float prod, float scale) {
     long long q = (long long)(prod * scale);
     if (q == 0) q = prod > 0.0f ? 1 : (prod < 0.0f ? -1 : 0);
     return (unsigned long long)q;
 }
 __device__ __forceinline__ float from_fixed(unsigned long long q, double inv_scale) { return (float)((double)(long long)q * inv_scale); }
-__device__ __forceinline__ unsigned to_fixed32(float prod) { return (unsigned)(int)(prod * kScaleC32); }
-__device__ __forceinline__ float from_fixed32(unsigned q) { return (float)((double)(int)q * (1.0 / 16777216.0)); }
-
-// The rare exact path of k_tile_render (see above): colour plane c once more in 64 bit, straight from the entry list (no register
-// cache), written out before the next plane reuses the space.  Kept out of line so that the common path's register budget (<= 64
-// VGPRs: eight 256-thread blocks per CU) does not pay for it.
-struct RedoArgs {
-    const Entry *entries; int e1; const Entry *spill; const int *spill_tile; int nspill, t;
-    const float *rgb; int64_t N; const float *zd; unsigned long long *plane64; const unsigned long long *acc_w;
-    int tx0, ty0, W, H; float *render; uint8_t *frame;
-};
-__device__ __noinline__ void redo_colour_planes(const RedoArgs &a) {
-    const int tid = threadIdx.x;
-    const int64_t plane = (int64_t)a.H * a.W;
-    for (int c = 0; c < 3; ++c) {
-        for (int i = tid; i < TPIX; i += kBlock) a.plane64[i] = 0ull;
-        __syncthreads();
-        auto one = [&](const Entry &e) {
-            int x0, y0; float w[4];
-            corner_weights(e.fx, e.fy, x0, y0, w);
-            const float v = a.rgb[(int64_t)c * a.N + e.idx];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
-                const int lx = cx - a.tx0, ly = cy - a.ty0;
-                if (!(lx >= 0 && lx < TW && ly >= 0 && ly < TH && cx < a.W && cy < a.H)) continue;
-                const int li = ly * TW + lx;
-                if (!((double)e.err <= (double)a.zd[li] + 1.0)) continue;
-                atomicAdd(&a.plane64[li], to_fixed(v * w[k], kScaleC));
-            }
-        };
-        for (int e = tid; e < a.e1; e += kBlock) one(a.entries[e]);
-        for (int e = tid; e < a.nspill; e += kBlock) if (a.spill_tile[e] == a.t) one(a.spill[e]);
-        __syncthreads();
-        for (int i = tid; i < TPIX; i += kBlock) {
-            const int x = a.tx0 + i % TW, y = a.ty0 + i / TW;
-            if (x < a.W && y < a.H) {
-                const float den = from_fixed(a.acc_w[i], 1.0 / 1099511627776.0) + 0.0000001f;
-                const float r = from_fixed(a.plane64[i], 1.0 / 1099511627776.0) / den;
-                const int64_t o = (int64_t)y * a.W + x;
-                if (a.render) a.render[(int64_t)c * plane + o] = r;
-                a.frame[o * 3 + c] = to_u8(r);
-            }
-        }
-        __syncthreads();
-    }
-}
 
 __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict__ entries, int cap,
                                                          const float *__restrict__ rgb, const float *__restrict__ depth, int64_t N,
                                                          int H, int W, TileGeom g, FrameOut out) {
     __shared__ float zee[ZH * ZW];
     __shared__ float zd[TPIX];
-    __shared__ __attribute__((aligned(8))) unsigned acc32[3 * TPIX];   // colour planes, 2^-24 units (its first 4 KB double as ONE 64-bit plane in the redo)
-    __shared__ unsigned long long acc64[2 * TPIX];                     // [0] depth (2^-20), [1] weight (2^-40): exact
+    __shared__ unsigned long long acc[5 * TPIX];
     __shared__ unsigned rowbits[TH];
     __shared__ int nholes, hole_base;
-    __shared__ unsigned vmax_bits;                                      // max |colour| over the tile's entries, as float bits
     __shared__ unsigned short hole_px[TPIX];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int tx0 = (t % g.ntx) * TW, ty0 = (t / g.ntx) * TH;
     for (int i = tid; i < ZH * ZW; i += kBlock) zee[i] = 1000000.0f;        // models/utils.py:59
-    for (int i = tid; i < 3 * TPIX; i += kBlock) acc32[i] = 0u;
-    for (int i = tid; i < 2 * TPIX; i += kBlock) acc64[i] = 0ull;
-    if (tid == 0) { nholes = 0; vmax_bits = 0u; }
+    for (int i = tid; i < 5 * TPIX; i += kBlock) acc[i] = 0ull;
+    if (tid == 0) nholes = 0;
     __syncthreads();
     const int total = out.totals[(int64_t)t * kTotalStride];
     const int e0 = (int)0, e1 = total < cap ? total : cap;
@@ -329,7 +272,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
     }
     __syncthreads();
     // ---- updateOutput (models/utils.py:215-313): z-test + bilinear splat, C = rgb + depth, + the ones channel -------------------
-    float vmax = 0.0f;
     auto splat = [&](const Entry &e, bool gather, float v0, float v1, float v2, float v3) {
         int x0, y0; float w[4];
         corner_weights(e.fx, e.fy, x0, y0, w);
@@ -345,52 +287,32 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
         }
         if (!any) return;
         if (gather) { const int64_t p = e.idx; v0 = rgb[p]; v1 = rgb[N + p]; v2 = rgb[2 * N + p]; v3 = depth[p]; }
-        vmax = fmaxf(vmax, fmaxf(fabsf(v0), fmaxf(fabsf(v1), fabsf(v2))));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!pass[k]) continue;
             const float wk = w[k];
-            atomicAdd(&acc32[li[k]], to_fixed32(v0 * wk));
-            atomicAdd(&acc32[TPIX + li[k]], to_fixed32(v1 * wk));
-            atomicAdd(&acc32[2 * TPIX + li[k]], to_fixed32(v2 * wk));
-            atomicAdd(&acc64[li[k]], to_fixed(v3 * wk, kScaleD));
-            atomicAdd(&acc64[TPIX + li[k]], to_fixed(1.0f * wk, kScaleC));
+            atomicAdd(&acc[li[k]], to_fixed(v0 * wk, kScaleC));
+            atomicAdd(&acc[TPIX + li[k]], to_fixed(v1 * wk, kScaleC));
+            atomicAdd(&acc[2 * TPIX + li[k]], to_fixed(v2 * wk, kScaleC));
+            atomicAdd(&acc[3 * TPIX + li[k]], to_fixed(v3 * wk, kScaleD));
+            atomicAdd(&acc[4 * TPIX + li[k]], to_fixed(1.0f * wk, kScaleC));
         }
     };
 #pragma unroll
     for (int k = 0; k < kReg; ++k) if (has[k]) splat(en[k], false, c0[k], c1[k], c2[k], c3[k]);
     for (int e = e0 + tid + kReg * kBlock; e < e1; e += kBlock) splat(entries[e], true, 0.0f, 0.0f, 0.0f, 0.0f);
     for (int e = tid; e < nspill; e += kBlock) if (out.spill_tile[e] == t) splat(out.spill[e], true, 0.0f, 0.0f, 0.0f, 0.0f);
-    if (vmax > 0.0f) atomicMax(&vmax_bits, __float_as_uint(vmax));              // non-negative floats order like their bits
     __syncthreads();
-    // can every pixel's 32-bit colour sum hold?  |sum v w| <= max |v| * sum w with the EXACT weight plane (NaN / inf colours fail too)
-    const int64_t plane = (int64_t)H * W;
-    constexpr int kPix = TPIX / kBlock;                                        // pixels per thread (2)
-    int overflow = 0;
-    {
-        const float vm = __uint_as_float(vmax_bits);
-#pragma unroll
-        for (int q = 0; q < kPix; ++q) {
-            const float ew = from_fixed(acc64[TPIX + tid + q * kBlock], 1.0 / 1099511627776.0);
-            overflow |= (ew > 0.0f && !(ew * vm < 120.0f)) ? 1 : 0;
-        }
-    }
-    const bool redo = __syncthreads_or(overflow) != 0;
-    if (redo) {
-        RedoArgs ra{entries, e1, out.spill, out.spill_tile, nspill, t, rgb, N, zd, reinterpret_cast<unsigned long long *>(acc32), acc64 + TPIX,
-                    tx0, ty0, W, H, out.render, out.frame};
-        redo_colour_planes(ra);
-    }
     // ---- models/utils.py:315 normalise; kenburns_effect.py:1039-1040 depth mask + uint8; hole list for fill_disocclusion --------
-#pragma unroll
-    for (int q = 0; q < kPix; ++q) {                                           // a wave = two 32-px rows of the tile
-        const int i = tid + q * kBlock;
+    const int64_t plane = (int64_t)H * W;
+    for (int i = tid; i < TPIX; i += kBlock) {                                // a wave = two 32-px rows of the tile
         const int lx = i % TW, ly = i / TW;
         const int x = tx0 + lx, y = ty0 + ly;
         const bool inside = x < W && y < H;
-        const float e = from_fixed(acc64[TPIX + i], 1.0 / 1099511627776.0);
+        const float e = from_fixed(acc[4 * TPIX + i], 1.0 / 1099511627776.0);
         const float den = e + 0.0000001f;
-        const float r3 = from_fixed(acc64[i], 1.0 / 1048576.0) / den;
+        const float r0 = from_fixed(acc[i], 1.0 / 1099511627776.0) / den, r1 = from_fixed(acc[TPIX + i], 1.0 / 1099511627776.0) / den;
+        const float r2 = from_fixed(acc[2 * TPIX + i], 1.0 / 1099511627776.0) / den, r3 = from_fixed(acc[3 * TPIX + i], 1.0 / 1048576.0) / den;
         const float m = r3 * (e > 0.0f ? 1.0f : 0.0f);
         const bool okp = inside && (double)m > 0.0;                             // common.py:160
         const unsigned long long bits = __ballot(okp);
@@ -401,12 +323,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
         if (!inside) continue;
         const int64_t o = (int64_t)y * W + x;
         out.mdepth[o] = m;
-        if (out.render) out.render[3 * plane + o] = r3;
-        if (!redo) {                                                            // (the redo passes wrote their colours themselves)
-            const float r0 = from_fixed32(acc32[i]) / den, r1 = from_fixed32(acc32[TPIX + i]) / den, r2 = from_fixed32(acc32[2 * TPIX + i]) / den;
-            if (out.render) { out.render[o] = r0; out.render[plane + o] = r1; out.render[2 * plane + o] = r2; }
-            out.frame[o * 3 + 0] = to_u8(r0); out.frame[o * 3 + 1] = to_u8(r1); out.frame[o * 3 + 2] = to_u8(r2);
-        }
+        if (out.render) { out.render[o] = r0; out.render[plane + o] = r1; out.render[2 * plane + o] = r2; out.render[3 * plane + o] = r3; }
+        out.frame[o * 3 + 0] = to_u8(r0); out.frame[o * 3 + 1] = to_u8(r1); out.frame[o * 3 + 2] = to_u8(r2);
         if (!okp) hole_px[atomicAdd(&nholes, 1)] = (unsigned short)i;
     }
     __syncthreads();

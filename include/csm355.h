@@ -100,12 +100,10 @@ int csm_warp_frame(const float *pts, const float *rgb, const float *depth, int64
 
 /* The same frame as csm_warp_frame with the splat done per destination tile in LDS (warptile.hip): points are binned by the
  * 32 x 16 tile(s) their footprint touches (integer atomics only), then one block per tile builds the z-buffer window, degrids,
- * z-tests, accumulates into fixed-point LDS accumulators with integer atomics (order free: a frame is bit-reproducible) -- weight and
- * depth in 64 bit (exact sums), the colour planes in 32 bit at 2^-24 per contribution with an exact 64-bit redo of the tile whenever
- * a pixel's weight sum x max |colour| could overflow them -- normalises and writes the uint8 frame; holes are filled from row /
- * column validity bitmaps.  Same decisions (z-buffer, coverage, fill sources) as csm_warp_frame; a pixel's colour sum is within
- * n 2^-24 (n = its contributions) of the exact sum that every fp32 summation order approximates (the reference's own order is
- * unspecified).
+ * z-tests, accumulates into 64-bit fixed-point LDS accumulators (integer atomics: order free, a frame is bit-reproducible),
+ * normalises and writes the uint8 frame; holes are filled from row / column validity bitmaps.  Same decisions (z-buffer, coverage,
+ * fill sources) as csm_warp_frame; colours within 2^-20 absolute of the exact sum that every fp32 summation order approximates
+ * (the reference's own order is unspecified).
  * csm_warp_tile_supported(H, W): 1 when the frame has at most 8192 tiles (up to ~2048 x 2048); larger frames use csm_warp_frame.
  * scratch: csm_warp_tile_scratch_bytes(H, W, N) bytes, 16-B aligned; its first csm_warp_tile_header_bytes(H, W) bytes must be
  * ZERO before the first call (hipMemset once after allocation) -- every call leaves them re-armed for the next frame. */
