@@ -388,8 +388,7 @@ class FrameWorkload(Workload):
         return out
 
     def variants(self):
-        v = {"batch1": self._fps(batch=1, conv_roofline=True), "batch1_lanes2": self._fps_lanes(1, 2, steps=8), "batch1_lanes3": self._fps_lanes(1, 3, steps=8),
-             "batch8_lanes2": self._fps_lanes(8, 2, steps=3),
+        v = {"batch1": self._fps(batch=1, conv_roofline=True), "batch1_lanes3": self._fps_lanes(1, 3, steps=8), "batch1_lanes4": self._fps_lanes(1, 4, steps=8),
              "batch16": self._fps(batch=16, conv_roofline=True), "instances1": self._fps(instances=1),
              "instances8": self._fps(instances=8), "instances100_batch1": self._fps(batch=1, instances=100, steps=2),
              "det1024_batch4": self._fps(batch=4, det=1024), "video": self._video(),
@@ -602,7 +601,10 @@ def main():
             if b1:             # the literal BASELINE configs[1..2] (one frame per step) next to the headline (configs[3]'s 8 frames per rank)
                 out["batch1"] = {"frames_per_s": b1["frames_per_s"], "ms_per_frame": b1["ms_per_frame"],
                                  "conv_frac_of_mfma_peak": b1.get("conv_frac_of_mfma_peak"),
-                                 "what": "BASELINE configs[1..2] literally: ONE 1024x1024 frame per step (seg + depth + warp)"}
+                                 "frames_per_s_3_in_flight": out["variants"].get("batch1_lanes3", {}).get("frames_per_s"),
+                                 "frames_per_s_4_in_flight": out["variants"].get("batch1_lanes4", {}).get("frames_per_s"),
+                                 "what": "BASELINE configs[1..2] literally: ONE 1024x1024 frame per step (seg + depth + warp), serial loop; "
+                                         "*_in_flight: the same single-frame steps with 3 / 4 frames in flight (FrameLanes)"}
         if world > 1:
             out["gather"] = wl.check_gathered()
             out["weights_broadcast_bytes"] = bcast_bytes
