@@ -43,6 +43,9 @@ def load():
         _lib.csm_warp_tile_header_bytes.restype = ctypes.c_size_t
         _lib.csm_percentile_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_bokeh_depth_scratch_bytes.restype = ctypes.c_size_t
+        _lib.csm_kenburns_frame_scratch_bytes.restype = ctypes.c_size_t
+        _lib.csm_det_decode_scratch_bytes.restype = ctypes.c_size_t
+        _lib.csm_mean_std_scratch_bytes.restype = ctypes.c_size_t
     return _lib
 
 

@@ -347,3 +347,60 @@ extern "C" int csm_masked_u8_median_max(const uint8_t *values, const uint8_t *ma
     k_masked_median_max<<<1, 256, 0, st>>>(hist, n_inst, out);
     return csm::check_launch("k_masked_median_max");
 }
+
+// ---- one output frame of the Ken Burns loop as ONE call (kenburns_effect.py:1027-1072) ----------------------------------------------
+// warp (shift -> splat -> fill -> uint8) [-> colourised depth -> depth-of-field blur] -> crop + resize into the video buffer.  The
+// kernels are the ones behind the separate entry points, launched in the same order with the same arguments; what goes away is
+// the host side of ~12 calls and ~8 allocations per frame, which had become the limit of the frame loop once consecutive frames ran
+// on several streams (round 3: 75 bokeh frames were host bound at ~275 us each).  All scratch is caller-owned.
+namespace {
+inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct FrameScratch { float *vmm; void *sel; void *bdepth; uint8_t *depth_u8; float *dm, *hi, *pa, *pb; uint8_t *blurred; size_t total; };
+inline FrameScratch carve_frame_scratch(void *base, int H, int W) {
+    const size_t P = (size_t)H * W;
+    FrameScratch s; char *p = (char *)base; size_t off = 0;
+    auto take = [&](size_t bytes) { char *q = p ? p + off : nullptr; off += a256(bytes); return (void *)q; };
+    s.vmm = (float *)take(64);
+    s.sel = take(csm_percentile_scratch_bytes());
+    s.bdepth = take(csm_bokeh_depth_scratch_bytes());
+    s.depth_u8 = (uint8_t *)take(P);
+    s.dm = (float *)take(P * 4);
+    s.hi = (float *)take(P * 12); s.pa = (float *)take(P * 12); s.pb = (float *)take(P * 12);
+    s.blurred = (uint8_t *)take(P * 3);
+    s.total = off;
+    return s;
+}
+}  // namespace
+
+extern "C" size_t csm_kenburns_frame_scratch_bytes(int H, int W) { return (H <= 0 || W <= 0) ? 0 : carve_frame_scratch(nullptr, H, W).total; }
+
+extern "C" int csm_kenburns_frame(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal, double baseline,
+                                  float sx, float sy, float sz, void *warp_scratch, float *render /* [4,H,W]; required when dof */,
+                                  uint8_t *frame_u8 /* [H,W,3] warp output (scratch of the caller's lane) */,
+                                  int dof, float focal_plane, int num_samples, float lightness, const uint8_t *gray_r_lut256_host,
+                                  void *tail_scratch /* csm_kenburns_frame_scratch_bytes; its bokeh-depth part zeroed once */,
+                                  int patch_h, int patch_w, float center_x, float center_y, uint8_t *out_hwc, void *stream) {
+    CSM_REQUIRE(frame_u8 && out_hwc && H > 0 && W > 0);
+    CSM_REQUIRE(!dof || (render && tail_scratch && gray_r_lut256_host && num_samples > 0));
+    int rc = csm_warp_frame_tiled(pts, rgb, depth, N, H, W, focal, baseline, sx, sy, sz, warp_scratch, render, frame_u8, stream);
+    if (rc) return rc;
+    const uint8_t *src = frame_u8;
+    if (dof) {
+        const FrameScratch s = carve_frame_scratch(tail_scratch, H, W);
+        const int64_t P = (int64_t)H * W;
+        const float *rdepth = render + 3 * P;                                              // tenRender[0, 3]
+        // colorize(depth, cmap='gray_r')[..., 0] with the 2nd / 85th percentiles (zoedepth/utils/misc.py:97-135)
+        rc = csm_percentile_pair(rdepth, P, 2.0, 85.0, s.vmm, s.sel, stream); if (rc) return rc;
+        rc = csm_colorize_gray_r_dev(rdepth, s.depth_u8, P, s.vmm, gray_r_lut256_host, stream); if (rc) return rc;
+        // bokeh_blur(frame, depth_u8, num_samples, lightness, focal_plane=..., depth_factor=1)  (utils/effects.py:143-181)
+        rc = csm_bokeh_depth_auto(s.depth_u8, s.dm, P, focal_plane, s.bdepth, stream); if (rc) return rc;
+        rc = csm_bokeh_highlight(frame_u8, s.hi, P * 3, lightness, stream); if (rc) return rc;
+        const double PI = 3.14159265358979323846;
+        rc = csm_bokeh_pass(s.hi, s.dm, s.pa, H, W, num_samples, 0.0f, 1.0f, stream); if (rc) return rc;
+        rc = csm_bokeh_pass(s.pa, s.dm, s.pb, H, W, num_samples, (float)cos(-PI / 6), (float)sin(-PI / 6), stream); if (rc) return rc;
+        rc = csm_bokeh_pass_finish(s.pb, s.dm, s.blurred, H, W, num_samples, (float)cos(-PI * 5 / 6), (float)sin(-PI * 5 / 6), lightness, stream);
+        if (rc) return rc;
+        src = s.blurred;
+    }
+    return csm_crop_resize_u8(src, H, W, patch_h, patch_w, center_x, center_y, out_hwc, stream);
+}

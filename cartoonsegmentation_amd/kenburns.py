@@ -734,6 +734,15 @@ class KenBurnsPipeline:
                         st_.wait_stream(main)
                 st_k, wf_k = (main, lanes[0][1]) if (k == 0 or ns == 1) else lanes[k % ns]
                 with torch.cuda.stream(st_k):
+                    fused = wf_k.path == 'tiled' and objCommon.depth_factor == 1 and (k > 0 or not objCommon.depth_field)
+                    if fused:
+                        # the whole frame in one library call (csm_kenburns_frame): same kernels, a twelfth of the host work
+                        dof = None
+                        if objCommon.depth_field:                                     # kenburns_effect.py:1058-1067
+                            focal_int = 1 / (1 + np.exp((0.5 - fltStep) * objCommon.dof_speed))
+                            dof = (focal_int * focal_end + (1 - focal_int) * focal_start, 32, objCommon.lightness_factor)
+                        wf_k.frame_into(out[k], pts, rgb, dep, objCommon['fltFocal'], objCommon['fltBaseline'], shift, ph, pw, W / 2.0, H / 2.0, dof)
+                        continue
                     frame, render = wf_k(pts, rgb, dep, objCommon['fltFocal'], objCommon['fltBaseline'], shift)
                     if objCommon.depth_field:                                         # kenburns_effect.py:1042-1067
                         depth_u8 = ops.colorize_gray_r(render[0, 3])

@@ -129,8 +129,8 @@ def shift_vector(objSettings, objCommon):
 
 
 def _f32x3(shift):
-    s = torch.tensor([float(v) for v in shift], dtype=torch.float32)  # FloatTensor rounding, common.py:74
-    return f32(s[0].item()), f32(s[1].item()), f32(s[2].item())
+    # FloatTensor rounding of the python floats (common.py:74): float64 -> float32, round to nearest even == numpy's conversion
+    return f32(float(_np.float32(shift[0]))), f32(float(_np.float32(shift[1]))), f32(float(_np.float32(shift[2])))
 
 
 def shift_points(tenPoints, shift):
@@ -335,6 +335,31 @@ class WarpFrame:
                                              f64(fltFocal), f64(fltBaseline), sx, sy, sz, ptr(self.scratch),
                                              ptr(self.render), ptr(self.frame), st), "warp_frame")
         return self.frame, self.render
+
+    def frame_into(self, out_hwc, tenPoints, tenImage, tenDepth, fltFocal, fltBaseline, shift, patch_h, patch_w, center_x, center_y,
+                   dof=None):
+        """One output frame of the video loop in ONE library call (csm_kenburns_frame, kenburns_effect.py:1027-1072): warp
+        [-> colourised depth -> depth-of-field blur with dof = (focal_plane, num_samples, lightness_factor)] -> crop + resize into
+        `out_hwc`.  Same kernels and bits as __call__ + colorize_gray_r + bokeh_blur + csm_crop_resize_u8; tiled path only."""
+        import ctypes
+        global _GRAY_R_LUT
+        assert self.path == 'tiled'
+        L = _lib.load()
+        if dof is not None:
+            assert self.render is not None, "depth of field needs WarpFrame(keep_render=True)"
+            if _GRAY_R_LUT is None:
+                lut = ((1.0 - _np.linspace(0.0, 1.0, 256)) * 255).astype(_np.uint8)
+                _GRAY_R_LUT = (ctypes.c_uint8 * 256)(*[int(x) for x in lut])
+            if getattr(self, '_tail', None) is None:
+                self._tail = torch.zeros(L.csm_kenburns_frame_scratch_bytes(i32(self.H), i32(self.W)), dtype=torch.uint8, device=self.device)
+        N = tenPoints.shape[2]
+        sx, sy, sz = _f32x3(shift)
+        fp, ns, lf = (0.0, 32, 1.0) if dof is None else (float(_np.float32(dof[0])), int(dof[1]), float(dof[2]))
+        check(L.csm_kenburns_frame(ptr(tenPoints), ptr(tenImage), ptr(tenDepth), i64(N), i32(self.H), i32(self.W), f64(fltFocal),
+                                   f64(fltBaseline), sx, sy, sz, ptr(self._tile_scratch(N)), ptr(self.render), ptr(self.frame),
+                                   i32(0 if dof is None else 1), f32(fp), i32(ns), f32(lf), _GRAY_R_LUT if dof is not None else None,
+                                   ptr(getattr(self, '_tail', None)), i32(patch_h), i32(patch_w), f32(center_x), f32(center_y),
+                                   ptr(out_hwc), stream_ptr()), "kenburns_frame")
 
 
 # ---- bokeh depth-of-field (utils/effects.py:143-181, depth_modules/zoedepth/utils/misc.py:97-135) ---------------------

@@ -437,6 +437,18 @@ int csm_colorize_gray_r_dev(const float *value, uint8_t *out, int64_t n, const f
 size_t csm_bokeh_depth_scratch_bytes(void);
 int csm_bokeh_depth_auto(const uint8_t *depth_u8, float *out, int64_t n, float focal_plane, void *scratch, void *stream);
 
+/* One output frame of KenBurnsPipeline.process_kenburns (kenburns_effect.py:1027-1072) in ONE call: csm_warp_frame_tiled
+ * [-> csm_percentile_pair(2, 85) -> csm_colorize_gray_r_dev -> csm_bokeh_depth_auto -> csm_bokeh_highlight -> 2 x csm_bokeh_pass ->
+ * csm_bokeh_pass_finish, when dof != 0 (depth_field, depth_factor 1)] -> csm_crop_resize_u8 into out_hwc.  Same kernels, order and
+ * arguments as the separate calls (bit-identical frames); it exists because the host side of a dozen calls per frame was the limit
+ * of the frame loop.  warp_scratch as for csm_warp_frame_tiled; render [4,H,W] is required when dof; frame_u8 [H,W,3] receives the
+ * un-cropped warp; tail_scratch: csm_kenburns_frame_scratch_bytes(H, W) bytes, zeroed ONCE by the caller (its bokeh-depth ticket). */
+size_t csm_kenburns_frame_scratch_bytes(int H, int W);
+int csm_kenburns_frame(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal, double baseline,
+                       float sx, float sy, float sz, void *warp_scratch, float *render, uint8_t *frame_u8, int dof, float focal_plane,
+                       int num_samples, float lightness, const uint8_t *gray_r_lut256_host, void *tail_scratch, int patch_h, int patch_w,
+                       float center_x, float center_y, uint8_t *out_hwc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -583,3 +583,32 @@ def test_hand_written_glue_kernels_match_torch():
         inst.resize(h, w)
         want = F.interpolate(masks.float().unsqueeze(1), (h, w), mode='area').squeeze(1) > 0.3
         assert inst.masks.dtype == torch.bool and torch.equal(inst.masks, want), (h, w)
+
+
+def test_fused_frame_call_equals_the_separate_calls():
+    """csm_kenburns_frame (one library call per output frame) == WarpFrame() + colorize_gray_r + bokeh_blur + csm_crop_resize_u8, byte
+    for byte, with and without the depth-of-field tail"""
+    from cartoonsegmentation_amd import _lib, ops, synth
+    from cartoonsegmentation_amd._lib import check, f32, i32, ptr, stream_ptr
+    L = _lib.load()
+    H, W = 200, 264
+    sc = synth.warp_scene(H, W, 9)
+    disp = torch.from_numpy(sc['disp']).cuda()
+    disp = disp / disp.max() * sc['baseline']
+    depth, _, pts, _ = ops.disparity_to_points(disp, sc['focal'], sc['baseline'])
+    pts, dep, rgb = pts.view(1, 3, -1).contiguous(), depth.view(1, 1, -1).contiguous(), torch.from_numpy(sc['rgb']).cuda()
+    ph, pw = int(0.9 * H), int(0.93 * W)
+    for dof in (None, (117.25, 32, 13)):
+        for shift in ([3.0, -2.0, -6.0], [-1.5, 0.25, 2.0]):
+            a = ops.WarpFrame(H, W, torch.device('cuda'), keep_render=True)
+            frame, render = a(pts, rgb, dep, sc['focal'], sc['baseline'], shift)
+            if dof is not None:
+                d8 = ops.colorize_gray_r(render[0, 3])
+                frame = ops.bokeh_blur(frame, d8, dof[1], dof[2], focal_plane=dof[0], use_cuda=True, depth_factor=1)
+            want = torch.empty((H, W, 3), dtype=torch.uint8, device='cuda')
+            check(L.csm_crop_resize_u8(ptr(frame), i32(H), i32(W), i32(ph), i32(pw), f32(W / 2.0), f32(H / 2.0), ptr(want), stream_ptr()))
+            b = ops.WarpFrame(H, W, torch.device('cuda'), keep_render=True)
+            got = torch.empty((H, W, 3), dtype=torch.uint8, device='cuda')
+            b.frame_into(got, pts, rgb, dep, sc['focal'], sc['baseline'], shift, ph, pw, W / 2.0, H / 2.0, dof)
+            b.frame_into(got, pts, rgb, dep, sc['focal'], sc['baseline'], shift, ph, pw, W / 2.0, H / 2.0, dof)     # scratch re-arms itself
+            assert torch.equal(got, want), (dof, shift)
