@@ -36,6 +36,8 @@ def parse():
                                                         "(64 frames on 8 GPUs), and the same per-rank work at every N (weak scaling)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra single-GPU measurements (batch / instances / det size / video)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the per-op HIP-event pass, so that the process executes "
+                                                               "exactly 1 + warmup + steps steps (rocprofv3 totals divide cleanly)")
     ap.add_argument("--cpu-seconds", type=float, default=90.0, help="budget of the host-side oracle run (full-size nets; stages that "
                                                                     "would not fit are scaled from the measured GFLOP/s and say so)")
     return ap.parse_args()
@@ -475,7 +477,9 @@ class FrameWorkload(Workload):
                 "traffic": load_traffic("k_conv"), "traffic_source": TRAFFIC_SOURCE,
                 "algorithmic_bytes_per_launch": int(alg_bytes / max(n_launch, 1)),
                 "algorithmic_flops_per_frame": tot_fl,
-                "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_step": n_launch, "per_net": per_net}
+                "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_step": n_launch, "conv_ms_per_step": round(tot_ms, 3),
+                "note": "a launch = one conv op of a layer program (a mixed-tile or split-K op issues two kernels: rocprofv3's per-kernel "
+                        "average is lower, its k_conv_* total per step is the comparable figure -- profiles/README.md)", "per_net": per_net}
 
     def extra(self):
         return {}
@@ -591,7 +595,7 @@ def main():
                "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
                "config": wl.config(world)}
-        out["roofline"] = wl.roofline()
+        out["roofline"] = None if a.no_roofline else wl.roofline()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline(a.cpu_seconds)
         out.update(wl.extra())

@@ -17,15 +17,16 @@ timeout 100 python tools/time_autozoom.py 1024 2>/dev/null | grep autozoom | hea
 [ "$2" = "quick" ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 RP="timeout 200 rocprofv3 --kernel-trace --stats --output-format csv"
-$RP -d $OUT/stats -o frame -- python /root/repo/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-variants > $OUT/stats.log 2>&1
+# --no-roofline: the process then executes exactly 1 + warmup + steps = 9 steps (no per-op event pass), so totals divide cleanly
+$RP -d $OUT/stats -o frame -- python /root/repo/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-variants --no-roofline > $OUT/stats.log 2>&1
 # same workload with the LeReS side stream off: kernels do not overlap, so durations are per-kernel clean (HIP-event comparable)
-CSM_OVERLAP_DEPTH=0 $RP -d $OUT/stats_serial -o frame -- python /root/repo/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-variants > $OUT/stats_serial.log 2>&1
+CSM_OVERLAP_DEPTH=0 $RP -d $OUT/stats_serial -o frame -- python /root/repo/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-variants --no-roofline > $OUT/stats_serial.log 2>&1
 $RP -d $OUT/stats_warp -o warp -- python /root/repo/bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_warp.log 2>&1
 CSM_WARP_PATH=atomics $RP -d $OUT/stats_warp_atomics -o warp -- python /root/repo/bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_warp_atomics.log 2>&1
 $RP -d $OUT/stats_video -o video -- python /root/repo/tools/video_breakdown.py > $OUT/stats_video.log 2>&1
 $RP -d $OUT/stats_autozoom -o az -- python /root/repo/tools/time_autozoom.py 1024 > $OUT/stats_autozoom.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o frame -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants > $OUT/pmc_$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o frame -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-roofline > $OUT/pmc_$C.log 2>&1
   timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmcw_$C -o warp -- python /root/repo/bench.py --workload warp --steps 20 --warmup 2 --no-cpu-baseline > $OUT/pmcw_$C.log 2>&1
 done
 python - <<PY
@@ -36,7 +37,10 @@ for f in sorted(glob.glob("$OUT/stats*/**/*kernel_stats.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         if "k_conv_" in r["Name"]: calls+=int(r["Calls"]); tot+=int(r["TotalDurationNs"])
     if calls:
-        msg="ALL k_conv_* launches: calls %d total %.3f ms average %.2f us"%(calls,tot/1e6,tot/calls/1e3)
+        msg="ALL k_conv_* kernel launches: calls %d total %.3f ms average %.2f us"%(calls,tot/1e6,tot/calls/1e3)
+        if "/stats/" in f or "/stats_serial/" in f:      # bench.py --steps 6 --warmup 2 --no-roofline = 9 executed steps
+            ops=json.load(open("$OUT/bench_frame.json"))["roofline"]["launches_per_step"]
+            msg+="; 9 steps -> %.3f ms of conv kernels per step = %.2f us per conv op (%d ops per step; bench.py's HIP-event figure: roofline.avg_launch_us)"%(tot/1e6/9,tot/9/ops/1e3,ops)
         print(msg); open(f.replace("kernel_stats.csv","conv_summary.txt"),"w").write(msg+"\n")
 tr={}
 for kind,key in (("FETCH_SIZE","fetch_KB"),("WRITE_SIZE","write_KB")):
@@ -53,9 +57,14 @@ for kind,key in (("FETCH_SIZE","fetch_KB"),("WRITE_SIZE","write_KB")):
 json.dump(tr, open("$OUT/pmc_summary.json","w"), indent=1)
 # HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -- MI355X_MICROARCH.md, HBM)
 traffic={k:int(2*v.get("fetch_KB",0)*1024+v.get("write_KB",0)*1024) for k,v in tr.items() if k.startswith("k_")}
+# conv: per OP of the layer programs (a mixed-tile / split-K op issues two kernels): total over the run / (4 executed steps x ops per step)
+if "k_conv" in tr:
+    ops=json.load(open("$OUT/bench_frame.json"))["roofline"]["launches_per_step"]
+    tot=2*tr["k_conv"].get("fetch_KB",0)*1024*tr["k_conv"].get("launches_fetch_KB",0)+tr["k_conv"].get("write_KB",0)*1024*tr["k_conv"].get("launches_write_KB",0)
+    traffic["k_conv_per_kernel_launch"]=traffic["k_conv"]; traffic["k_conv"]=int(tot/4/ops); traffic["k_conv_per_step"]=int(tot/4)
 chain=[k for k in ("k_tile_bin","k_tile_render","k_tile_holes") if k in traffic]
 if chain: traffic["warp_chain_tiled"]=sum(traffic[k] for k in chain)
-traffic["_note"]="HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md; WRITE_SIZE uncalibrated); separate --pmc passes; k_conv = launch-weighted average over all conv launches (k_conv_dma / k_conv_patch tiles + k_conv_mfma) of the frame workload (batch 8); warp_chain_tiled = sum over the three kernels (k_tile_bin, k_tile_render, k_tile_holes) of one csm_warp_frame_tiled call"
+traffic["_note"]="HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md; WRITE_SIZE uncalibrated); separate --pmc passes; k_conv = per conv OP of the layer programs: bytes of all k_conv_* kernels of the run / (4 executed steps of bench.py --steps 2 --warmup 1 --no-roofline x conv ops per step), frame workload at batch 8; warp_chain_tiled = sum over the three kernels (k_tile_bin, k_tile_render, k_tile_holes) of one csm_warp_frame_tiled call"
 json.dump(traffic, open("$OUT/traffic.json","w"), indent=1)
 for k,v in sorted(tr.items(), key=lambda kv:-kv[1].get("fetch_KB",0))[:16]: print(k, v)
 PY
