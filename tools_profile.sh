@@ -35,7 +35,7 @@ for f in sorted(glob.glob("$OUT/stats*/**/*kernel_stats.csv", recursive=True)):
     print(f); print("".join(l[:170]+"\n" for l in open(f).readlines()[:12]))
     calls=tot=0
     for r in csv.DictReader(open(f)):
-        if "k_conv_" in r["Name"]: calls+=int(r["Calls"]); tot+=int(r["TotalDurationNs"])
+        if "k_conv_" in r["Name"] or "k_splitk_reduce" in r["Name"]: calls+=int(r["Calls"]); tot+=int(r["TotalDurationNs"])   # the reduce kernel belongs to its conv op
     if calls:
         msg="ALL k_conv_* kernel launches: calls %d total %.3f ms average %.2f us"%(calls,tot/1e6,tot/calls/1e3)
         if "/stats/" in f or "/stats_serial/" in f:      # bench.py --steps 6 --warmup 2 --no-roofline = 9 executed steps
@@ -50,7 +50,7 @@ for kind,key in (("FETCH_SIZE","fetch_KB"),("WRITE_SIZE","write_KB")):
             for r in csv.DictReader(open(f)):
                 k=r["Kernel_Name"]; k=k[k.find("k_"):][:24] if "k_" in k else k[:24]
                 k=k.split("(")[0].split("<")[0]
-                if k.startswith("k_conv_"): k="k_conv"            # all conv tile instantiations together
+                if k.startswith("k_conv_") or k.startswith("k_splitk_reduce"): k="k_conv"            # all conv tile instantiations (+ split-K reduce) together
                 agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
         for k,(n,v) in agg.items():
             tr.setdefault(k,{})[key]=round(v/n,1); tr[k]["launches_"+key]=n
