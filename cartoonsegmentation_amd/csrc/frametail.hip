@@ -4,9 +4,10 @@
 // scalars back, then reads three more for the bokeh depth map: ~230 us of sort kernels plus seven host syncs per frame, 75 frames
 // per video.  Here:
 //   csm_percentile_pair   EXACT order statistics by a 3-pass radix select on the order-preserving integer image of the floats
-//                         (11 + 11 + 10 bits; per-block LDS histograms -> per-block partials -> one small pick kernel per pass;
-//                         the four ranks of the two percentiles travel together) + numpy's linear interpolation rule; the results
-//                         stay in device memory.
+//                         (16 + 8 + 8 bits; wave-aggregated counts in LDS, one table copy per XCD behind them, the last block of a
+//                         pass picks the buckets: THREE launches; the four ranks of the two percentiles travel together) + numpy's
+//                         linear interpolation rule; the results stay in device memory.
+//                         (Round 2: 11 + 11 + 10 bits with per-block partials and separate pick kernels: six launches, 117 us.)
 //   csm_colorize_gray_r_dev  colorize(value, cmap='gray_r') reading vmin / vmax from device memory, LUT applied in the kernel.
 //   csm_bokeh_depth_auto  the depth map of bokeh_blur (utils/effects.py:146-163): its three scalar reductions run over the 256-bin
 //                         histogram of the uint8 depth (max d; min and max of dmax - |d - focal| only depend on which values occur).
@@ -16,9 +17,14 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kSelBlocks = 64;        // blocks of the histogram passes (partials: kSelBlocks x 4 ranks x 2048 bins; the pick kernel
-                                      // reads them all: with 256 blocks it took 69 us per pass, 3x the histogram itself)
-constexpr int kBins = 2048;
+constexpr int kSelGrid = 256;         // blocks of a selection pass
+constexpr int kCoarse = 256;          // a 16-bit digit is counted twice: 256 coarse bins (its top 8 bits) and 65536 fine bins
+constexpr int kFine = 65536;
+constexpr int kWin = 4096;            // fine bins a block keeps in LDS (a window around its first element; the rest goes to HBM)
+constexpr int kHistWords = kCoarse + kFine;
+constexpr int kXcd = 8;               // one copy of every counting table per XCD: a line that all eight L2s update ping-pongs between
+                                      // them (measured: 1.4 ns per atomic, 730 us for a plane that misses the LDS window); a line
+                                      // that only one XCD's blocks touch stays in that L2
 
 __device__ __forceinline__ unsigned ordered_key(float f) {      // monotone float -> unsigned map (total order incl. negatives)
     unsigned u = __float_as_uint(f);
@@ -28,152 +34,358 @@ __device__ __forceinline__ float key_to_float(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-struct SelState {            // device-resident state of the 4 concurrent selections
-    unsigned prefix[4];      // key bits fixed so far (high bits)
-    unsigned rank[4];        // rank still to find among the elements matching the prefix
-    unsigned ticket;         // blocks of the last pick pass that are done (the last one computes the result); 0 between calls
+struct SelState {            // device-resident state of the 4 concurrent selections (64 bytes)
+    unsigned prefix[4];      // top 16 key bits of each order statistic (written by the last block of pass 1)
+    unsigned rank[4];        // its rank among the elements that share those bits
+    unsigned ticket;         // blocks of the running pass that are done (the last one finishes the pass); 0 between passes
+    unsigned pad[7];
 };
-struct SelInit { unsigned rank[4]; };                     // the four ranks of a call (arguments of the first histogram pass)
+struct SelInit { unsigned rank[4]; };                     // the four ranks of a call
 
-// pass p: shift / bits of the digit, mask of the already fixed bits
-__device__ __forceinline__ void pass_geom(int p, int &shift, int &bits) {
-    if (p == 0) { shift = 21; bits = 11; } else if (p == 1) { shift = 10; bits = 11; } else { shift = 0; bits = 10; }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the XCD this workgroup runs on (which L2 its atomics execute in); only a placement hint -- any value gives the same counts
+__device__ __forceinline__ unsigned xcd_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & (unsigned)(kXcd - 1);
+}
+// Before a block takes its ticket its counts must have been PERFORMED (they are atomic read-modify-writes, read back by the last block
+// with coherent atomic loads: single-location coherence needs no cache maintenance, only completion -- on gfx9 vmcnt covers atomics
+// and stores).  A full __threadfence() here is a buffer_wbl2 per block: 256 write-backs of the L2 made each pass 35 us long.
+__device__ __forceinline__ void counts_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// sum of one bin over the XCD copies of a table (`tab` = copy 0, copies kXcdStride words apart)
+__device__ __forceinline__ unsigned ld_bin(const unsigned *tab, int64_t stride, unsigned bin) {
+    unsigned c = 0u;
+#pragma unroll
+    for (int x = 0; x < kXcd; ++x) c += ld_agent(tab + x * stride + bin);
+    return c;
 }
 
-__global__ __launch_bounds__(kBlock) void k_sel_hist(const float *__restrict__ v, int64_t n, int pass, SelState *__restrict__ st, SelInit init,
-                                                      unsigned *__restrict__ partial /* [4][kSelBlocks][kBins] */) {
-    __shared__ unsigned h[4][kBins];
-    int shift, bits; pass_geom(pass, shift, bits);
-    const int nb = 1 << bits;
-    unsigned pre[4];
-    // pass 0 does not read the state (no bits are fixed yet): block 0 INITIALISES it for the pick kernel that follows -- what
-    // used to be a separate one-thread launch (a launch costs ~4.8 us on this stack whatever it does)
+// inclusive scan over the 256 threads of a block (wave shuffles + 4 wave totals through LDS)
+__device__ __forceinline__ unsigned block_scan_256(unsigned x, unsigned *wsum /* LDS[4] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned v = x;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pre[r] = pass == 0 ? 0u : st->prefix[r];
-    if (pass == 0 && blockIdx.x == 0 && threadIdx.x < 4) { st->prefix[threadIdx.x] = 0u; st->rank[threadIdx.x] = init.rank[threadIdx.x]; }
-    if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 4) st->ticket = 0u;
-    // ranks that share a prefix share a histogram (pass 0: all four)
-    int owner[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { owner[r] = r; for (int q = 0; q < r; ++q) if (pass == 0 || pre[q] == pre[r]) { owner[r] = owner[q]; break; } }
-    for (int i = threadIdx.x; i < 4 * kBins; i += kBlock) (&h[0][0])[i] = 0u;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    __syncthreads();                                       // wsum may still be read from the previous scan
+    if (lane == 63) wsum[w] = v;
     __syncthreads();
-    const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + bits));
-    // kUnroll independent loads per trip (one load per trip left the pass latency bound: 64 dependent round trips per thread;
-    // a ballot-aggregated LDS add -- one atomic per distinct bin per wave -- measured SLOWER than the plain atomic, 31 vs 25 us)
-    constexpr int kUnroll = 8;
+    unsigned add = 0u;
+    for (int q = 0; q < w; ++q) add += wsum[q];
+    return v + add;
+}
+
+// One digit of one element per lane into a two-level histogram.  A wave reads 64 (x4) neighbouring pixels; on a depth map they
+// mostly share the digit, and 64 atomics on one address serialise -- so up to three rounds of "the first pending lane counts
+// everybody who has its digit" run before the leftovers add themselves.  Fine bins inside the block's LDS window and all coarse
+// bins are LDS atomics (flushed once per block); fine bins outside the window go to the table in HBM directly.
+struct HistTarget { unsigned *lds_fine; unsigned *lds_coarse; unsigned *g_fine; unsigned win_base; };
+__device__ __forceinline__ void hist_count(const HistTarget &t, unsigned d, unsigned cnt) {
+    atomicAdd(&t.lds_coarse[d >> 8], cnt);
+    const unsigned w = d - t.win_base;
+    if (w < (unsigned)kWin) atomicAdd(&t.lds_fine[w], cnt); else atomicAdd(&t.g_fine[d], cnt);
+}
+__device__ __forceinline__ void wave_hist_add(const HistTarget &t, bool hit, unsigned d) {
+    unsigned long long todo = __ballot(hit);
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int it = 0; it < 3 && todo != 0ull; ++it) {                                  // wave-uniform
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        const unsigned dl = (unsigned)__builtin_amdgcn_readlane((int)d, leader);
+        const unsigned long long same = __ballot(hit && d == dl) & todo;
+        if (lane == leader) hist_count(t, dl, (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) hist_count(t, d, 1u);
+}
+
+// flush of a block's LDS histograms into the tables in HBM (non-zero bins only)
+__device__ __forceinline__ void hist_flush(const HistTarget &t, unsigned *g_coarse) {
+    for (int i = threadIdx.x; i < kWin; i += kBlock) { const unsigned c = t.lds_fine[i]; if (c && t.win_base + i < (unsigned)kFine) atomicAdd(&t.g_fine[t.win_base + i], c); }
+    for (int i = threadIdx.x; i < kCoarse; i += kBlock) { const unsigned c = t.lds_coarse[i]; if (c) atomicAdd(&g_coarse[i], c); }
+}
+
+// which of the 256 bins (one count per thread, already loaded) holds `rank`: the bin and the rank inside it, through LDS.
+// All 256 threads call it; the loads of all four ranks are issued BEFORE the first call (they are coherent reads that miss every
+// cache, ~2 us each: issued one after the other they made the tail of a pass 15 us long).
+__device__ __forceinline__ void pick_bin(unsigned count, unsigned rank, unsigned *wsum, unsigned *res2 /* LDS[2] */) {
+    const unsigned incl = block_scan_256(count, wsum), excl = incl - count;
+    if (rank >= excl && rank < incl) { res2[0] = threadIdx.x; res2[1] = rank - excl; }
+    __syncthreads();
+}
+
+// element loop shared by the two passes: 4 float4 loads in flight per lane, wave-converged calls of `body(live, value)`
+template <class F>
+__device__ __forceinline__ void for_each_value(const float *__restrict__ v, int64_t n, F body) {
+    const int64_t n4 = (((uintptr_t)v & 15) == 0) ? n / 4 : 0;
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t base = (int64_t)blockIdx.x * kBlock + threadIdx.x; base - threadIdx.x < n; base += stride * kUnroll) {
-        float val[kUnroll];
+    constexpr int kUnroll = 4;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n4; base += stride * kUnroll) {
+        float4 q[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) { const int64_t i = base + u * stride; val[u] = i < n ? v[i] : 0.0f; }
+        for (int u = 0; u < kUnroll; ++u) { const int64_t i = base + u * stride + threadIdx.x; q[u] = i < n4 ? v4[i] : float4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const bool live = base + u * stride < n;
-            const unsigned k = ordered_key(val[u]);
-            const unsigned d = (k >> shift) & (unsigned)(nb - 1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (owner[r] != r) continue;                                   // block-uniform
-                const bool hit = live && (k & himask) == (pre[r] & himask);
-                // a wave reads 64 neighbouring pixels: on a depth map they mostly share the digit (always in pass 0, whose
-                // digit is sign + exponent + 2 mantissa bits), and 64 LDS atomics on one address serialise.  One ballot decides:
-                // every hit lane has the first hit lane's digit -> that lane adds the count; otherwise plain atomics.
-                const unsigned long long hits = __ballot(hit);
-                if (hits == 0ull) continue;                                    // wave-uniform
-                const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)hits) - 1);
-                const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)d, first);
-                if (__ballot(hit && d == d0) == hits) { if ((int)(threadIdx.x & 63) == first) atomicAdd(&h[r][d0], (unsigned)__popcll(hits)); }
-                else if (hit) atomicAdd(&h[r][d], 1u);
-            }
+            const bool live = base + u * stride + threadIdx.x < n4;
+            body(live, q[u].x); body(live, q[u].y); body(live, q[u].z); body(live, q[u].w);
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 4 * kBins; i += kBlock) {
-        const int r = i / kBins, d = i % kBins;
-        if (d < nb) partial[((int64_t)r * gridDim.x + blockIdx.x) * kBins + d] = h[owner[r]][d];
+    for (int64_t base = n4 * 4 + (int64_t)blockIdx.x * kBlock; base < n; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < n;
+        body(live, live ? v[i] : 0.0f);
     }
 }
 
-// one block per rank: column sums of the partials, scan, pick the digit that holds the rank, advance prefix / rank
-__device__ __forceinline__ void sel_finish(const volatile SelState *st, double t_lo, double t_hi, float *out2);
-
-__global__ __launch_bounds__(1024) void k_sel_pick(const unsigned *__restrict__ partial, int nblocks, int pass, SelState *__restrict__ st,
-                                                    double t_lo, double t_hi, float *__restrict__ out2) {
-    __shared__ unsigned col[kBins];
-    __shared__ unsigned scan[1024];
-    int shift, bits; pass_geom(pass, shift, bits);
-    const int nb = 1 << bits, r = blockIdx.x, tid = threadIdx.x;
-    const unsigned rank = st->rank[r];                          // read by everyone BEFORE the barriers; one thread rewrites it at the end
-    for (int d = tid; d < nb; d += 1024) {
-        const unsigned *P = partial + (int64_t)r * nblocks * kBins + d;
-        unsigned acc16[16];                                      // sixteen independent load streams (integer sums: any order)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc16[q] = 0u;
-        int b = 0;
-        for (; b + 15 < nblocks; b += 16) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc16[q] += P[(int64_t)(b + q) * kBins];
-        }
-        for (; b < nblocks; ++b) acc16[0] += P[(int64_t)b * kBins];
-        unsigned tot = 0u;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tot += acc16[q];
-        col[d] = tot;
-    }
+// pass 1: histogram of the TOP 16 key bits of every element; the last block to finish finds, for each of the four ranks, the
+// 16-bit bucket that holds it.
+__global__ __launch_bounds__(kBlock) void k_sel_top16(const float *__restrict__ v, int64_t n, SelState *__restrict__ st, SelInit init,
+                                                       unsigned *__restrict__ g /* [kXcd][kHistWords], zero on entry (cleared by pass 2 of the previous call) */) {
+    __shared__ unsigned hf[kWin];
+    __shared__ unsigned hc[kCoarse];
+    __shared__ unsigned wsum[4], sbin[4], sbefore[4], res2[2];
+    __shared__ bool last;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kWin; i += kBlock) hf[i] = 0u;
+    unsigned *gx = g + (int64_t)xcd_id() * kHistWords;                    // this XCD's copy of the pass-1 tables
+    hc[tid] = 0u;
+    // window: centred on the block's first element
+    const int64_t first = (int64_t)blockIdx.x * kBlock * 4;
+    const unsigned d_first = ordered_key(v[first < n ? first : 0]) >> 16;
+    HistTarget t{hf, hc, gx + kCoarse, d_first > (unsigned)(kWin / 2) ? d_first - (unsigned)(kWin / 2) : 0u};
     __syncthreads();
-    // inclusive scan over nb (<= 2048) counts: two per thread + Hillis-Steele over 1024
-    const unsigned a = 2 * tid < nb ? col[2 * tid] : 0u, b2 = 2 * tid + 1 < nb ? col[2 * tid + 1] : 0u;
-    scan[tid] = a + b2;
+    for_each_value(v, n, [&](bool live, float x) { wave_hist_add(t, live, ordered_key(x) >> 16); });
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const unsigned t = tid >= off ? scan[tid - off] : 0u;
+    hist_flush(t, gx);
+    counts_done();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;                                   // (the reads below are coherent atomic loads of atomically written counts: no fence)
+    const unsigned c = ld_bin(g, kHistWords, (unsigned)tid);
+    const unsigned incl = block_scan_256(c, wsum), excl = incl - c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (init.rank[r] >= excl && init.rank[r] < incl) { sbin[r] = (unsigned)tid; sbefore[r] = excl; }
+    __syncthreads();
+    unsigned f[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f[r] = ld_bin(g + kCoarse, kHistWords, sbin[r] * 256u + (unsigned)tid);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pick_bin(f[r], init.rank[r] - sbefore[r], wsum, res2);
+        if (tid == 0) { st->prefix[r] = sbin[r] * 256u + res2[0]; st->rank[r] = res2[1]; }
         __syncthreads();
-        scan[tid] += t;
-        __syncthreads();
     }
-    const unsigned before = tid ? scan[tid - 1] : 0u;           // elements in digits < 2 tid
-    // the digit d with  count(< d) <= rank < count(<= d)
-    if (rank >= before && rank < before + a && 2 * tid < nb) { st->prefix[r] |= (unsigned)(2 * tid) << shift; st->rank[r] = rank - before; __threadfence(); }
-    else if (rank >= before + a && rank < before + a + b2 && 2 * tid + 1 < nb) { st->prefix[r] |= (unsigned)(2 * tid + 1) << shift; st->rank[r] = rank - before - a; __threadfence(); }
-    if (pass != 2) return;
-    // last pass: the block that finishes last turns the four order statistics into the two percentiles (was a fourth launch)
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
-            __threadfence();
-            sel_finish(st, t_lo, t_hi, out2);
-            st->ticket = 0u;
-        }
-    }
+    if (tid == 0) st->ticket = 0u;
 }
 
 // numpy percentile, method 'linear' (numpy 1.26 _lerp): a + (b - a) t for t < 0.5, else b - (b - a)(1 - t); arithmetic in float64 on
 // float32 samples, result rounded to float32 -- what depth_modules/zoedepth/utils/misc.py:118-119 gets from np.percentile
-__device__ __forceinline__ void sel_finish(const volatile SelState *st, double t_lo, double t_hi, float *out2) {
-    const double a0 = (double)key_to_float(st->prefix[0]), b0 = (double)key_to_float(st->prefix[1]);
-    const double a1 = (double)key_to_float(st->prefix[2]), b1 = (double)key_to_float(st->prefix[3]);
+__device__ __forceinline__ void sel_finish(const unsigned *key4, double t_lo, double t_hi, float *out2) {
+    const double a0 = (double)key_to_float(key4[0]), b0 = (double)key_to_float(key4[1]);
+    const double a1 = (double)key_to_float(key4[2]), b1 = (double)key_to_float(key4[3]);
     const double r0 = t_lo < 0.5 ? a0 + (b0 - a0) * t_lo : b0 - (b0 - a0) * (1.0 - t_lo);
     const double r1 = t_hi < 0.5 ? a1 + (b1 - a1) * t_hi : b1 - (b1 - a1) * (1.0 - t_hi);
     out2[0] = (float)r0; out2[1] = (float)r1;
 }
 
+// one byte per lane into a block's 256-bin LDS histogram; lanes of a wave that share the byte (neighbouring pixels) are counted by one
+__device__ __forceinline__ void wave_hist256_add(unsigned *h, bool live, unsigned b) {
+    unsigned long long todo = __ballot(live);
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int it = 0; it < 3 && todo != 0ull; ++it) {
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        const unsigned bl = (unsigned)__builtin_amdgcn_readlane((int)b, leader);
+        const unsigned long long same = __ballot(live && b == bl) & todo;
+        if (lane == leader) atomicAdd(&h[bl], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&h[b], 1u);
+}
+
+// passes 2 and 3: the next 8 key bits (SHIFT = 8, then 0) of the elements that match a rank's prefix, counted in LDS only (256 bins per
+// distinct prefix) whatever the distribution; the last block advances prefix / rank and clears the small tables; the final pass
+// interpolates the two percentiles.  Pass 2 also clears the pass-1 tables for the next call.
+// (A single 16-bit second pass was tried first: the matching elements of a real render depth plane are many and their low bits are
+// spread over all 65536 bins -- 35 ... 300 us of L2 atomics per frame.)
+template <int SHIFT>
+__global__ __launch_bounds__(kBlock) void k_sel_digit8(const float *__restrict__ v, int64_t n, SelState *__restrict__ st, double t_lo, double t_hi,
+                                                        float *__restrict__ out2, unsigned *__restrict__ g /* pass-1 tables */,
+                                                        unsigned *__restrict__ g8 /* [kXcd][4][256], zero on entry, left zero */) {
+    __shared__ unsigned hc[4][256];
+    __shared__ unsigned wsum[4], res2[2], key4[4];
+    __shared__ bool last;
+    const int tid = threadIdx.x;
+    if (SHIFT == 8)
+        for (int i = blockIdx.x * kBlock + tid; i < kXcd * kHistWords / 4; i += gridDim.x * kBlock)
+            __builtin_nontemporal_store(u32x4{0u, 0u, 0u, 0u}, &reinterpret_cast<u32x4 *>(g)[i]);
+    unsigned pre[4]; int owner[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pre[r] = st->prefix[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { owner[r] = r; for (int q = 0; q < r; ++q) if (pre[q] == pre[r]) { owner[r] = owner[q]; break; } }   // ranks with one prefix share a table
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hc[r][tid] = 0u;
+    __syncthreads();
+    for_each_value(v, n, [&](bool live, float x) {
+        const unsigned k = ordered_key(x), hi = k >> (SHIFT + 8), d = (k >> SHIFT) & 255u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (owner[r] != r) continue;                                          // block-uniform
+            const bool hit = live && hi == pre[r];
+            if (__ballot(hit) == 0ull) continue;                                  // wave-uniform
+            wave_hist256_add(hc[r], hit, d);
+        }
+    });
+    __syncthreads();
+    unsigned *g8x = g8 + xcd_id() * 1024u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (owner[r] != r) continue;
+        const unsigned c = hc[r][tid];
+        if (c) atomicAdd(&g8x[r * 256 + tid], c);
+    }
+    counts_done();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;                                   // (the reads below are coherent atomic loads of atomically written counts: no fence)
+    unsigned c[4], rk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c[r] = ld_bin(g8 + owner[r] * 256, 1024, (unsigned)tid); rk[r] = st->rank[r]; }
+#pragma unroll
+    for (int x = 0; x < kXcd * 4; ++x) g8[x * 256 + tid] = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pick_bin(c[r], rk[r], wsum, res2);
+        if (tid == 0) { key4[r] = (pre[r] << 8) | res2[0]; st->prefix[r] = key4[r]; st->rank[r] = res2[1]; }
+        __syncthreads();
+    }
+    if (tid == 0) { if (SHIFT == 0) sel_finish(key4, t_lo, t_hi, out2); st->ticket = 0u; }
+}
+
 struct Lut256 { uint8_t v[256]; };
+
+__global__ __launch_bounds__(kBlock) void k_colorize_dev(const float *__restrict__ v, uint8_t *__restrict__ out, int64_t n,
+                                                          const float *__restrict__ vmm, Lut256 lut);
+// the matplotlib index of one value (Colormap.__call__: xa = x*256; xa==256 -> 255; clip to [-1, 256]; int(); under / over -> ends)
+__device__ __forceinline__ int cmap_index(float v, float vmin, float vmax) {
+    const float x = vmin != vmax ? (v - vmin) / (vmax - vmin) : 0.0f;
+    float xa = x * 256.0f;
+    if (xa == 256.0f) xa = 255.0f;
+    xa = fminf(fmaxf(xa, -1.0f), 256.0f);
+    const int k = (int)xa;
+    return k < 0 ? 0 : (k > 255 ? 255 : k);
+}
+
+// stats3 = {dmax, mn, mx2} exactly as utils/effects.py:146-153 computes them with float32 numpy reductions, from "which uint8 values
+// occur" (present[256] in LDS); all 256 threads of a block call it
+__device__ __forceinline__ void bokeh_stats_block(const int *present, float *red /* LDS[256] */, float focal, float *__restrict__ stats3) {
+    const int tid = threadIdx.x;
+    red[tid] = present[tid] ? (float)tid : -1.0f;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    const float dmax = red[0];
+    __syncthreads();
+    const float t = dmax - fabsf((float)tid - focal);           // depth = depth.max() - |depth - focal_plane|
+    red[tid] = present[tid] ? t : INFINITY;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] = fminf(red[tid], red[tid + s]); __syncthreads(); }
+    const float mn = red[0];
+    __syncthreads();
+    red[tid] = present[tid] ? t - mn : -INFINITY;               // depth -= depth.min(); depth.max()
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
+    if (tid == 0) { stats3[0] = dmax; stats3[1] = mn; stats3[2] = red[0]; }
+}
+
+// frame loop: colorize + the histogram of its uint8 output + (last block) the three scalars of the bokeh depth map -- what were
+// k_colorize_dev, k_u8_hist and k_bokeh_stats (3 launches, 29 us).  hist256 ([kXcd][256], one copy per XCD: see kXcd) / ticket: zero
+// on entry, left zero.  (First version: 1024 blocks flushing into ONE table = 30 K contended atomics, 71 us.)
+__global__ __launch_bounds__(kBlock) void k_colorize_stats(const float *__restrict__ v, uint8_t *__restrict__ out, int64_t n,
+                                                            const float *__restrict__ vmm, Lut256 lut, unsigned *__restrict__ hist256,
+                                                            unsigned *__restrict__ ticket, float focal, float *__restrict__ stats3) {
+    __shared__ unsigned h[256];
+    __shared__ int present[256];
+    __shared__ float red[256];
+    __shared__ bool last;
+    const int tid = threadIdx.x;
+    h[tid] = 0u;
+    __syncthreads();
+    const float vmin = vmm[0], vmax = vmm[1];
+    const bool vec = (((uintptr_t)v & 15) == 0) && (((uintptr_t)out & 3) == 0);
+    const int64_t n4 = vec ? n / 4 : 0;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n4; base += (int64_t)gridDim.x * kBlock) {     // wave-converged trips
+        const int64_t i = base + tid;
+        const bool live = i < n4;
+        const float4 q = live ? reinterpret_cast<const float4 *>(v)[i] : float4{0.f, 0.f, 0.f, 0.f};
+        const unsigned b0 = lut.v[cmap_index(q.x, vmin, vmax)], b1 = lut.v[cmap_index(q.y, vmin, vmax)];
+        const unsigned b2 = lut.v[cmap_index(q.z, vmin, vmax)], b3 = lut.v[cmap_index(q.w, vmin, vmax)];
+        if (live) reinterpret_cast<unsigned *>(out)[i] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        wave_hist256_add(h, live, b0); wave_hist256_add(h, live, b1); wave_hist256_add(h, live, b2); wave_hist256_add(h, live, b3);
+    }
+    for (int64_t base = n4 * 4 + (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = base + tid;
+        const bool live = i < n;
+        const unsigned b = lut.v[cmap_index(live ? v[i] : 0.0f, vmin, vmax)];
+        if (live) out[i] = (uint8_t)b;
+        wave_hist256_add(h, live, b);
+    }
+    __syncthreads();
+    if (h[tid]) atomicAdd(&hist256[xcd_id() * 256u + tid], h[tid]);
+    counts_done();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;                                   // (the reads below are coherent atomic loads of atomically written counts: no fence)
+    present[tid] = ld_bin(hist256, 256, (unsigned)tid) != 0u;
+#pragma unroll
+    for (int x = 0; x < kXcd; ++x) hist256[x * 256 + tid] = 0u;
+    __syncthreads();
+    bokeh_stats_block(present, red, focal, stats3);
+    if (tid == 0) *ticket = 0u;
+}
+
+// frame loop: the bokeh depth plane (utils/effects.py:146-153, :162-163) and the highlighted image (img / 255)^lightness
+// (:155-156) in one pass (were k_bokeh_depth_dev + k_bokeh_highlight).  Both are functions of one byte: a block tabulates the 2 x 256
+// values once (one powf per thread instead of twelve), then every lane turns 4-byte words into float4s -- loads and stores of a
+// wave are contiguous.
+__global__ __launch_bounds__(kBlock) void k_bokeh_prep(const uint8_t *__restrict__ d8, const uint8_t *__restrict__ img, float *__restrict__ dm,
+                                                        float *__restrict__ hi, int64_t n, float focal, const float *__restrict__ stats3, float lf) {
+    __shared__ float dl[256], hl[256];
+    const int tid = threadIdx.x;
+    {
+        const float dmax = stats3[0], mn = stats3[1], mx2 = stats3[2];
+        float t = dmax - fabsf((float)tid - focal); t = t - mn; t = t / mx2; t = 1.0f - t;
+        dl[tid] = t * 0.0005f;
+        hl[tid] = powf((float)tid / 255.0f, lf);
+    }
+    __syncthreads();
+    const bool vec = (((uintptr_t)d8 | (uintptr_t)img) & 3) == 0 && (((uintptr_t)dm | (uintptr_t)hi) & 15) == 0;
+    const int64_t nd = vec ? n / 4 : 0, ni = vec ? (n * 3) / 4 : 0;          // whole 4-byte words of the depth plane / of the image
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + tid; j < nd; j += (int64_t)gridDim.x * kBlock) {
+        const unsigned w = reinterpret_cast<const unsigned *>(d8)[j];
+        reinterpret_cast<float4 *>(dm)[j] = float4{dl[w & 255u], dl[(w >> 8) & 255u], dl[(w >> 16) & 255u], dl[w >> 24]};
+    }
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + tid; j < ni; j += (int64_t)gridDim.x * kBlock) {
+        const unsigned w = reinterpret_cast<const unsigned *>(img)[j];
+        reinterpret_cast<float4 *>(hi)[j] = float4{hl[w & 255u], hl[(w >> 8) & 255u], hl[(w >> 16) & 255u], hl[w >> 24]};
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t j = nd * 4 + tid; j < n; j += kBlock) dm[j] = dl[d8[j]];
+        for (int64_t j = ni * 4 + tid; j < n * 3; j += kBlock) hi[j] = hl[img[j]];
+    }
+}
 
 __global__ __launch_bounds__(kBlock) void k_colorize_dev(const float *__restrict__ v, uint8_t *__restrict__ out, int64_t n,
                                                           const float *__restrict__ vmm, Lut256 lut) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const float vmin = vmm[0], vmax = vmm[1];
-    float x = vmin != vmax ? (v[i] - vmin) / (vmax - vmin) : 0.0f;
-    // matplotlib Colormap.__call__: xa = x*256; xa==256 -> 255; clip to [-1, 256]; int(); <0 -> under (lut[0]), >255 -> over (lut[255])
-    float xa = x * 256.0f;
-    if (xa == 256.0f) xa = 255.0f;
-    xa = fminf(fmaxf(xa, -1.0f), 256.0f);
-    int k = (int)xa;
-    k = k < 0 ? 0 : (k > 255 ? 255 : k);
-    out[i] = lut.v[k];
+    out[i] = lut.v[cmap_index(v[i], vmm[0], vmm[1])];
 }
 
 // ---- bokeh depth: scalars from the histogram of the uint8 depth --------------------------------------------------------------
@@ -204,7 +416,6 @@ __global__ __launch_bounds__(kBlock) void k_u8_hist(const uint8_t *__restrict__ 
     partial[(int64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
-// stats3 = {dmax, mn, mx2} exactly as utils/effects.py:146-153 computes them with float32 numpy reductions
 __global__ __launch_bounds__(256) void k_bokeh_stats(const unsigned *__restrict__ partial, int nblocks, float focal, float *__restrict__ stats3) {
     __shared__ float red[256];
     __shared__ int present[256];
@@ -213,21 +424,7 @@ __global__ __launch_bounds__(256) void k_bokeh_stats(const unsigned *__restrict_
     for (int b = 0; b < nblocks; ++b) c += partial[(int64_t)b * 256 + tid];
     present[tid] = c != 0u;
     __syncthreads();
-    red[tid] = present[tid] ? (float)tid : -1.0f;
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
-    const float dmax = red[0];
-    __syncthreads();
-    const float t = dmax - fabsf((float)tid - focal);           // depth = depth.max() - |depth - focal_plane|
-    red[tid] = present[tid] ? t : INFINITY;
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] = fminf(red[tid], red[tid + s]); __syncthreads(); }
-    const float mn = red[0];
-    __syncthreads();
-    red[tid] = present[tid] ? t - mn : -INFINITY;               // depth -= depth.min(); depth.max()
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
-    if (tid == 0) { stats3[0] = dmax; stats3[1] = mn; stats3[2] = red[0]; }
+    bokeh_stats_block(present, red, focal, stats3);
 }
 
 __global__ __launch_bounds__(kBlock) void k_bokeh_depth_dev(const uint8_t *__restrict__ d8, float *__restrict__ out, int64_t n, float focal,
@@ -244,26 +441,27 @@ __global__ __launch_bounds__(kBlock) void k_bokeh_depth_dev(const uint8_t *__res
 
 }  // namespace
 
-extern "C" size_t csm_percentile_scratch_bytes(void) { return sizeof(SelState) + 64 + sizeof(unsigned) * 4 * (size_t)kSelBlocks * kBins; }
+extern "C" size_t csm_percentile_scratch_bytes(void) { return sizeof(SelState) + sizeof(unsigned) * ((size_t)kXcd * kHistWords + (size_t)kXcd * 4 * 256); }
 
 extern "C" int csm_percentile_pair(const float *value, int64_t n, double q_lo, double q_hi, float *out2, void *scratch, void *stream) {
     CSM_REQUIRE(value && out2 && scratch && n > 0 && n < (1ll << 32) && q_lo >= 0.0 && q_lo <= 100.0 && q_hi >= 0.0 && q_hi <= 100.0);
     hipStream_t st = (hipStream_t)stream;
     SelState *state = (SelState *)scratch;
-    unsigned *partial = (unsigned *)((char *)scratch + 64);
+    unsigned *tables = (unsigned *)((char *)scratch + sizeof(SelState)), *tables8 = tables + (size_t)kXcd * kHistWords;
     // numpy: virtual index (n - 1) q / 100, lower / upper neighbours, interpolation weight
     const double v0 = (double)(n - 1) * (q_lo / 100.0), v1 = (double)(n - 1) * (q_hi / 100.0);
     const int64_t l0 = (int64_t)v0, l1 = (int64_t)v1;
     const int64_t h0 = l0 + 1 < n ? l0 + 1 : n - 1, h1 = l1 + 1 < n ? l1 + 1 : n - 1;
     SelInit init; init.rank[0] = (unsigned)l0; init.rank[1] = (unsigned)h0; init.rank[2] = (unsigned)l1; init.rank[3] = (unsigned)h1;
-    int rc;
-    for (int pass = 0; pass < 3; ++pass) {
-        k_sel_hist<<<kSelBlocks, kBlock, 0, st>>>(value, n, pass, state, init, partial);
-        rc = csm::check_launch("k_sel_hist"); if (rc) return rc;
-        k_sel_pick<<<4, 1024, 0, st>>>(partial, kSelBlocks, pass, state, v0 - (double)l0, v1 - (double)l1, out2);
-        rc = csm::check_launch("k_sel_pick"); if (rc) return rc;
-    }
-    return CSM_OK;
+    const int64_t want = (n + kBlock * 16 - 1) / (kBlock * 16);
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > kSelGrid ? kSelGrid : want));
+    const double t_lo = v0 - (double)l0, t_hi = v1 - (double)l1;
+    k_sel_top16<<<grid, kBlock, 0, st>>>(value, n, state, init, tables);
+    int rc = csm::check_launch("k_sel_top16"); if (rc) return rc;
+    k_sel_digit8<8><<<grid, kBlock, 0, st>>>(value, n, state, t_lo, t_hi, out2, tables, tables8);
+    rc = csm::check_launch("k_sel_digit8"); if (rc) return rc;
+    k_sel_digit8<0><<<grid, kBlock, 0, st>>>(value, n, state, t_lo, t_hi, out2, tables, tables8);
+    return csm::check_launch("k_sel_digit8");
 }
 
 extern "C" int csm_colorize_gray_r_dev(const float *value, uint8_t *out, int64_t n, const float *vmin_vmax_dev, const uint8_t *lut256_host,
@@ -378,7 +576,7 @@ extern "C" int csm_kenburns_frame(const float *pts, const float *rgb, const floa
                                   float sx, float sy, float sz, void *warp_scratch, float *render /* [4,H,W]; required when dof */,
                                   uint8_t *frame_u8 /* [H,W,3] warp output (scratch of the caller's lane) */,
                                   int dof, float focal_plane, int num_samples, float lightness, const uint8_t *gray_r_lut256_host,
-                                  void *tail_scratch /* csm_kenburns_frame_scratch_bytes; its bokeh-depth part zeroed once */,
+                                  void *tail_scratch /* csm_kenburns_frame_scratch_bytes; zeroed once by the caller */,
                                   int patch_h, int patch_w, float center_x, float center_y, uint8_t *out_hwc, void *stream) {
     CSM_REQUIRE(frame_u8 && out_hwc && H > 0 && W > 0);
     CSM_REQUIRE(!dof || (render && tail_scratch && gray_r_lut256_host && num_samples > 0));
@@ -391,10 +589,18 @@ extern "C" int csm_kenburns_frame(const float *pts, const float *rgb, const floa
         const float *rdepth = render + 3 * P;                                              // tenRender[0, 3]
         // colorize(depth, cmap='gray_r')[..., 0] with the 2nd / 85th percentiles (zoedepth/utils/misc.py:97-135)
         rc = csm_percentile_pair(rdepth, P, 2.0, 85.0, s.vmm, s.sel, stream); if (rc) return rc;
-        rc = csm_colorize_gray_r_dev(rdepth, s.depth_u8, P, s.vmm, gray_r_lut256_host, stream); if (rc) return rc;
-        // bokeh_blur(frame, depth_u8, num_samples, lightness, focal_plane=..., depth_factor=1)  (utils/effects.py:143-181)
-        rc = csm_bokeh_depth_auto(s.depth_u8, s.dm, P, focal_plane, s.bdepth, stream); if (rc) return rc;
-        rc = csm_bokeh_highlight(frame_u8, s.hi, P * 3, lightness, stream); if (rc) return rc;
+        // colourised depth + its histogram + the three scalars of the bokeh depth map (one launch), then depth plane + highlights (one launch)
+        {
+            Lut256 lut;
+            for (int i = 0; i < 256; ++i) lut.v[i] = gray_r_lut256_host[i];
+            float *stats3 = (float *)s.bdepth;
+            unsigned *ticket = (unsigned *)((char *)s.bdepth + 48), *hist256 = (unsigned *)((char *)s.bdepth + 64);   // [kXcd][256]
+            const unsigned blocks = (unsigned)csm::cdiv(csm::cdiv(P, 4), kBlock);
+            k_colorize_stats<<<blocks < 256u ? blocks : 256u, kBlock, 0, (hipStream_t)stream>>>(rdepth, s.depth_u8, P, s.vmm, lut, hist256, ticket, focal_plane, stats3);
+            rc = csm::check_launch("k_colorize_stats"); if (rc) return rc;
+            k_bokeh_prep<<<blocks < 1024u ? blocks : 1024u, kBlock, 0, (hipStream_t)stream>>>(s.depth_u8, frame_u8, s.dm, s.hi, P, focal_plane, stats3, lightness);
+            rc = csm::check_launch("k_bokeh_prep"); if (rc) return rc;
+        }
         const double PI = 3.14159265358979323846;
         rc = csm_bokeh_pass(s.hi, s.dm, s.pa, H, W, num_samples, 0.0f, 1.0f, stream); if (rc) return rc;
         rc = csm_bokeh_pass(s.pa, s.dm, s.pb, H, W, num_samples, (float)cos(-PI / 6), (float)sin(-PI / 6), stream); if (rc) return rc;

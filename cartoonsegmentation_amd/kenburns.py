@@ -716,7 +716,7 @@ class KenBurnsPipeline:
             def lane_wf(i):                                                      # warp scratch per lane, kept across videos of one size
                 key = (H, W, bool(objCommon.depth_field), i)
                 if key not in self._lane_wf:
-                    self._lane_wf = {kk: v for kk, v in self._lane_wf.items() if kk[:3] == key[:3]}    # another size: drop the old sets
+                    self._lane_wf = {kk: v for kk, v in self._lane_wf.items() if kk[:2] == key[:2]}    # another frame size: drop the old sets
                     self._lane_wf[key] = ops.WarpFrame(H, W, self.device, keep_render=bool(objCommon.depth_field))
                 return self._lane_wf[key]
             lanes = [(main if ns == 1 else self._frame_streams[i], wf if i == 0 else lane_wf(i)) for i in range(ns)]

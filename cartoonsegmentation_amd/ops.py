@@ -396,7 +396,7 @@ def _tail_scratch(dev):
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     if key not in _TAIL_SCRATCH:
         L = _lib.load()
-        _TAIL_SCRATCH[key] = (torch.empty(L.csm_percentile_scratch_bytes(), dtype=torch.uint8, device=dev),
+        _TAIL_SCRATCH[key] = (torch.zeros(L.csm_percentile_scratch_bytes(), dtype=torch.uint8, device=dev),          # counting tables start cleared
                               torch.zeros(L.csm_bokeh_depth_scratch_bytes(), dtype=torch.uint8, device=dev),   # completion counter starts at 0
                               torch.empty(2, dtype=torch.float32, device=dev))
     return _TAIL_SCRATCH[key]

@@ -425,7 +425,8 @@ int csm_colorize_gray_r(const float *value, uint8_t *out, int64_t n, float vmin,
 
 /* The same three steps without host round trips (frametail.hip) -- the per-frame tail of kenburns_effect.py:1042-1067:
  * csm_percentile_pair: out2 (DEVICE) = {np.percentile(value, q_lo), np.percentile(value, q_hi)} (method 'linear'), exact, by a
- *   3-pass radix select instead of a sort; scratch = csm_percentile_scratch_bytes() device bytes.
+ *   3-pass (16 + 8 + 8 bit) radix select instead of a sort, three launches; scratch = csm_percentile_scratch_bytes() device bytes, ZEROED
+ *   ONCE by the caller (every call leaves the counting tables it needs next time cleared) and used by one stream at a time.
  * csm_colorize_gray_r_dev: csm_colorize_gray_r with vmin / vmax read from device memory and the matplotlib byte LUT (256 HOST
  *   bytes, index -> grey level) applied in the kernel.
  * csm_bokeh_depth_auto: csm_bokeh_depth with dmax / mn / mx2 derived on the device from the histogram of depth_u8; scratch =
@@ -442,7 +443,7 @@ int csm_bokeh_depth_auto(const uint8_t *depth_u8, float *out, int64_t n, float f
  * csm_bokeh_pass_finish, when dof != 0 (depth_field, depth_factor 1)] -> csm_crop_resize_u8 into out_hwc.  Same kernels, order and
  * arguments as the separate calls (bit-identical frames); it exists because the host side of a dozen calls per frame was the limit
  * of the frame loop.  warp_scratch as for csm_warp_frame_tiled; render [4,H,W] is required when dof; frame_u8 [H,W,3] receives the
- * un-cropped warp; tail_scratch: csm_kenburns_frame_scratch_bytes(H, W) bytes, zeroed ONCE by the caller (its bokeh-depth ticket). */
+ * un-cropped warp; tail_scratch: csm_kenburns_frame_scratch_bytes(H, W) bytes, zeroed ONCE by the caller (tickets and counting tables: every call leaves them cleared). */
 size_t csm_kenburns_frame_scratch_bytes(int H, int W);
 int csm_kenburns_frame(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal, double baseline,
                        float sx, float sy, float sz, void *warp_scratch, float *render, uint8_t *frame_u8, int dof, float focal_plane,

@@ -368,24 +368,31 @@ def test_default_depth_estimator_pipeline():
 
 
 def test_device_percentiles_and_bokeh_stats_are_exact():
-    """csm_percentile_pair (3-pass radix select, no sort, no host sync) == the order statistics of the sorted array for awkward
-    inputs (negatives, signed zeros, heavy ties, tiny / huge magnitudes), and csm_bokeh_depth_auto == csm_bokeh_depth fed with the
+    """csm_percentile_pair (2-pass 16 + 16 bit radix select, no sort, no host sync; one scratch re-used by every call: each call
+    must leave its counting tables cleared) == the order statistics of the sorted array for awkward inputs (negatives, signed zeros,
+    heavy ties, tiny / huge magnitudes, two far-apart clusters, a constant plane, a smooth ramp, an unaligned plane), and
+    csm_bokeh_depth_auto == csm_bokeh_depth fed with the
     host-side reductions"""
     from cartoonsegmentation_amd import _lib
     from cartoonsegmentation_amd._lib import check, f32, f64, i64, ptr, stream_ptr
     from oracle import kenburns as okb
     L = _lib.load()
     rng = np.random.default_rng(12)
-    sel = torch.empty(L.csm_percentile_scratch_bytes(), dtype=torch.uint8, device='cuda')
+    sel = torch.zeros(L.csm_percentile_scratch_bytes(), dtype=torch.uint8, device='cuda')       # zeroed ONCE (the contract)
     out2 = torch.empty(2, device='cuda')
+    yy, xx = np.mgrid[0:720, 0:1280]
     cases = [rng.normal(0, 1, 100003).astype(np.float32),
              np.concatenate([np.zeros(5000, np.float32), -np.zeros(5000, np.float32), rng.uniform(-1e-30, 1e30, 777).astype(np.float32)]),
              np.round(rng.uniform(0, 8, 1 << 20)).astype(np.float32),                    # heavy ties
              rng.uniform(200, 900, 1024 * 1024).astype(np.float32),                      # like a render depth plane
-             np.array([3.0], np.float32), np.array([2.0, -7.5], np.float32)]
-    for a in cases:
+             np.array([3.0], np.float32), np.array([2.0, -7.5], np.float32),
+             np.concatenate([rng.normal(1.0, 0.01, 300000), rng.normal(-5e4, 10.0, 200001)]).astype(np.float32),   # two clusters, far apart in key space
+             np.full(70001, 2.75, np.float32),                                           # constant plane
+             (3.0 + 0.002 * yy + 0.0005 * xx + 0.3 * np.sin(xx / 90.0)).astype(np.float32).ravel(),   # smooth depth ramp (the frame loop's case)
+             rng.uniform(1, 2, 4099).astype(np.float32)]
+    for ci, a in enumerate(cases):
         for q_lo, q_hi in ((2.0, 85.0), (0.0, 100.0), (50.0, 99.9)):
-            d = torch.from_numpy(a).cuda()
+            d = torch.from_numpy(np.concatenate([np.zeros(1, np.float32), a])).cuda()[1:] if ci == len(cases) - 1 else torch.from_numpy(a).cuda()   # last: 4-byte aligned only
             check(L.csm_percentile_pair(ptr(d), i64(a.size), f64(q_lo), f64(q_hi), ptr(out2), ptr(sel), stream_ptr()))
             got = out2.cpu().numpy()
             assert got[0] == okb._percentile(a, q_lo) and got[1] == okb._percentile(a, q_hi), (a.size, q_lo, q_hi, got)

@@ -56,6 +56,13 @@ if __name__ == '__main__':
     if 'leres' in which:
         p = nets.build_leres(SynthWeights('leres.'), B, 640, 640)
         prof('leres n=%d 640' % B, p, [torch.randn(B, 3, 640, 640, device=dev), torch.empty(B, 1, 640, 640, device=dev)])
+    if 'inpaint' in which:                      # the GridNet of the point-cloud inpainting at 1024^2 (one of the two passes of a video)
+        from cartoonsegmentation_amd.nets.inpaint import build_inpaint_context, build_inpaint_grid
+        ws = SynthWeights('inpaint.')
+        p = build_inpaint_context(ws, 1024, 1024)
+        prof('inpaint context 1024', p, [torch.randn(1, 4, 1024, 1024, device=dev), torch.empty(1, 64, 1024, 1024, device=dev)])
+        p = build_inpaint_grid(ws, 1024, 1024)
+        prof('inpaint grid 1024', p, [torch.randn(1, 69, 1024, 1024, device=dev), torch.empty(1, 3, 1024, 1024, device=dev), torch.empty(1, 1, 1024, 1024, device=dev)])
     if 'rtmdet' in which:
         rp, _ = nets.build_rtmdet(SynthWeights('rtmdet.'), B, 640, 640)
         prof('rtmdet n=%d 640' % B, rp.prog, [torch.randn(B, 3, 640, 640, device=dev)])
