@@ -77,8 +77,7 @@ __device__ __forceinline__ unsigned block_scan_256(unsigned x, unsigned *wsum /*
 }
 
 // One digit of one element per lane into a two-level histogram.  A wave reads 64 (x4) neighbouring pixels; on a depth map they
-// mostly share the digit, and 64 atomics on one address serialise -- so up to three rounds of "the first pending lane counts
-// everybody who has its digit" run before the leftovers add themselves.  Fine bins inside the block's LDS window and all coarse
+// mostly share the digit, and 64 atomics on one address serialise -- so a wave whose hit lanes all share the digit adds once.  Fine bins inside the block's LDS window and all coarse
 // bins are LDS atomics (flushed once per block); fine bins outside the window go to the table in HBM directly.
 struct HistTarget { unsigned *lds_fine; unsigned *lds_coarse; unsigned *g_fine; unsigned win_base; };
 __device__ __forceinline__ void hist_count(const HistTarget &t, unsigned d, unsigned cnt) {
@@ -87,10 +86,20 @@ __device__ __forceinline__ void hist_count(const HistTarget &t, unsigned d, unsi
     if (w < (unsigned)kWin) atomicAdd(&t.lds_fine[w], cnt); else atomicAdd(&t.g_fine[d], cnt);
 }
 __device__ __forceinline__ void wave_hist_add(const HistTarget &t, bool hit, unsigned d) {
-    unsigned long long todo = __ballot(hit);
+    const unsigned long long hits = __ballot(hit);
+    if (hits == 0ull) return;                                                      // wave-uniform
+    const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)hits) - 1);
+    const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)d, first);
+    // ONE ballot decides: every hit lane has the first hit lane's digit -> that lane adds the count; otherwise plain atomics (a
+    // leader loop over the distinct digits of a wave was measured slower: LDS same-address atomics cost less than its scalar trips)
     const int lane = threadIdx.x & 63;
+    if (__ballot(hit && d == d0) == hits) { if (lane == first) hist_count(t, d0, (unsigned)__popcll(hits)); return; }
+    const bool inside = d - t.win_base < (unsigned)kWin;
+    if (hit && inside) hist_count(t, d, 1u);
+    // digits outside the LDS window cost an L2 atomic each: there the distinct values of the wave are counted one by one
+    unsigned long long todo = __ballot(hit && !inside);
 #pragma unroll 1
-    for (int it = 0; it < 3 && todo != 0ull; ++it) {                                  // wave-uniform
+    for (int it = 0; it < 8 && todo != 0ull; ++it) {
         const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
         const unsigned dl = (unsigned)__builtin_amdgcn_readlane((int)d, leader);
         const unsigned long long same = __ballot(hit && d == dl) & todo;
@@ -194,17 +203,12 @@ __device__ __forceinline__ void sel_finish(const unsigned *key4, double t_lo, do
 
 // one byte per lane into a block's 256-bin LDS histogram; lanes of a wave that share the byte (neighbouring pixels) are counted by one
 __device__ __forceinline__ void wave_hist256_add(unsigned *h, bool live, unsigned b) {
-    unsigned long long todo = __ballot(live);
-    const int lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int it = 0; it < 3 && todo != 0ull; ++it) {
-        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-        const unsigned bl = (unsigned)__builtin_amdgcn_readlane((int)b, leader);
-        const unsigned long long same = __ballot(live && b == bl) & todo;
-        if (lane == leader) atomicAdd(&h[bl], (unsigned)__popcll(same));
-        todo &= ~same;
-    }
-    if ((todo >> lane) & 1ull) atomicAdd(&h[b], 1u);
+    const unsigned long long hits = __ballot(live);
+    if (hits == 0ull) return;
+    const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)hits) - 1);
+    const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)b, first);
+    if (__ballot(live && b == b0) == hits) { if ((int)(threadIdx.x & 63) == first) atomicAdd(&h[b0], (unsigned)__popcll(hits)); }
+    else if (live) atomicAdd(&h[b], 1u);
 }
 
 // passes 2 and 3: the next 8 key bits (SHIFT = 8, then 0) of the elements that match a rank's prefix, counted in LDS only (256 bins per
