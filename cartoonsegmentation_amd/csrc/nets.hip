@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void src_index(int dst, int in_size, int out_size, fl
 // bilinear resize: VEC = 4 handles 4 channels per lane with 16-byte accesses (c, pitches and bases 16-byte aligned),
 // VEC = 1 is the generic path (single-channel side outputs).  Same expression per element in both.
 template <int VEC>
-__global__ __launch_bounds__(256) void k_bilinear(View in, View out, int align, float sh, float sw) {
+__global__ __launch_bounds__(256) void k_bilinear(View in, View out, int align, float sh, float sw, int act, const float *__restrict__ slope) {
     const int cv = out.c / VEC;
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = (int64_t)out.n * out.h * out.w * cv;
@@ -1154,9 +1154,14 @@ __global__ __launch_bounds__(256) void k_bilinear(View in, View out, int align, 
         r.y = hl0 * (wl0 * p00.y + wl1 * p01.y) + hl1 * (wl0 * p10.y + wl1 * p11.y);
         r.z = hl0 * (wl0 * p00.z + wl1 * p01.z) + hl1 * (wl0 * p10.z + wl1 * p11.z);
         r.w = hl0 * (wl0 * p00.w + wl1 * p01.w) + hl1 * (wl0 * p10.w + wl1 * p11.w);
+        if (act) {
+            r.x = apply_act(r.x, act, slope ? slope[c] : 0.0f); r.y = apply_act(r.y, act, slope ? slope[c + 1] : 0.0f);
+            r.z = apply_act(r.z, act, slope ? slope[c + 2] : 0.0f); r.w = apply_act(r.w, act, slope ? slope[c + 3] : 0.0f);
+        }
         *reinterpret_cast<float4 *>(O) = r;
     } else {
-        O[0] = hl0 * (wl0 * a00[0] + wl1 * a01[0]) + hl1 * (wl0 * a10[0] + wl1 * a11[0]);
+        const float r = hl0 * (wl0 * a00[0] + wl1 * a01[0]) + hl1 * (wl0 * a10[0] + wl1 * a11[0]);
+        O[0] = act ? apply_act(r, act, slope ? slope[c] : 0.0f) : r;
     }
 }
 
@@ -1174,6 +1179,31 @@ __global__ __launch_bounds__(256) void k_nearest(View in, View out) {
 }
 
 // out = act(a + b), or unary act / copy when b.p == nullptr
+// float4 form of k_eltwise for modes 0 (act / copy) and 1 (add): channel counts and strides that are multiples of 4, 16-B aligned
+// views (everything the layer programs produce).  Same arithmetic per element; 1 thread = 4 channels of one pixel.
+__global__ __launch_bounds__(256) void k_eltwise4(View a, View b, View out, int act, int mode, const float *__restrict__ slope) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = out.c >> 2;
+    const int64_t total = (int64_t)out.n * out.h * out.w * c4n;
+    if (idx >= total) return;
+    const int c = (int)(idx % c4n) * 4; const int64_t pix = idx / c4n;
+    float4 v = *reinterpret_cast<const float4 *>(a.p + pix * a.ld + c);
+    if (mode == 1) {
+        const float4 w = *reinterpret_cast<const float4 *>(b.p + pix * b.ld + c);
+        v.x = v.x + w.x; v.y = v.y + w.y; v.z = v.z + w.z; v.w = v.w + w.w;
+    }
+    float4 sl = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (slope) sl = *reinterpret_cast<const float4 *>(slope + c);
+    v.x = apply_act(v.x, act, sl.x); v.y = apply_act(v.y, act, sl.y); v.z = apply_act(v.z, act, sl.z); v.w = apply_act(v.w, act, sl.w);
+    *reinterpret_cast<float4 *>(out.p + pix * out.ld + c) = v;
+}
+static bool eltwise4_ok(const View &a, const View *b, const View &out, const float *slope) {
+    uintptr_t bits = (uintptr_t)a.p | (uintptr_t)out.p | (uintptr_t)slope;
+    int lds = a.ld | out.ld | out.c;
+    if (b) { bits |= (uintptr_t)b->p; lds |= b->ld; }
+    return !(bits & 15) && !(lds & 3);
+}
+
 __global__ __launch_bounds__(256) void k_eltwise(View a, View b, View out, int act, int mode, const float *__restrict__ slope) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = (int64_t)out.n * out.h * out.w * out.c;
@@ -1656,8 +1686,9 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 if (align) { sh = out.h > 1 ? (float)(in.h - 1) / (float)(out.h - 1) : 0.0f; sw = out.w > 1 ? (float)(in.w - 1) / (float)(out.w - 1) : 0.0f; }
                 else { sh = (float)in.h / (float)out.h; sw = (float)in.w / (float)out.w; }
                 bool vec = !(out.c & 3) && !(in.ld & 3) && !(out.ld & 3) && !(((uintptr_t)in.p | (uintptr_t)out.p) & 15);
-                if (vec) k_bilinear<4><<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw);
-                else k_bilinear<1><<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw);
+                const float *bsl = op.aux_off >= 0 ? weights + op.aux_off : nullptr;
+                if (vec) k_bilinear<4><<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw, op.act, bsl);
+                else k_bilinear<1><<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw, op.act, bsl);
                 break;
             }
             case CSM_OP_NEAREST:
@@ -1668,16 +1699,23 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 if (in.h < out.h || in.w < out.w || in.h > out.h + 1 || in.w > out.w + 1 || in1.h != out.h || in1.w != out.w) {
                     csm::set_error("op %d: add: the first operand may exceed the output by at most one row / column", i); return CSM_ERR_ARG;
                 }
-                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act,
-                                                                                            (in.h != out.h || in.w != out.w) ? 3 : 1, nullptr);
+                if (in.h == out.h && in.w == out.w && eltwise4_ok(in, &in1, out, nullptr))
+                    k_eltwise4<<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, in1, out, op.act, 1, nullptr);
+                else
+                    k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act,
+                                                                                                (in.h != out.h || in.w != out.w) ? 3 : 1, nullptr);
                 break;
             case CSM_OP_SCALE:
                 k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.act, 2, nullptr);
                 break;
             case CSM_OP_ACT:
             case CSM_OP_COPY:
-                k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.kind == CSM_OP_ACT ? op.act : 0, 0,
-                                                                                              op.aux_off >= 0 ? weights + op.aux_off : nullptr);
+                if (eltwise4_ok(in, nullptr, out, op.aux_off >= 0 ? weights + op.aux_off : nullptr))
+                    k_eltwise4<<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, in1, out, op.kind == CSM_OP_ACT ? op.act : 0, 0,
+                                                                                                        op.aux_off >= 0 ? weights + op.aux_off : nullptr);
+                else
+                    k_eltwise<<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, in1, out, op.kind == CSM_OP_ACT ? op.act : 0, 0,
+                                                                                                  op.aux_off >= 0 ? weights + op.aux_off : nullptr);
                 break;
             case CSM_OP_GAVGPOOL:
                 if (!(in.c & 31) && !(in.ld & 3) && !(((uintptr_t)in.p) & 15)) k_gavgpool32<<<dim3(in.c / 32, in.n), 256, 0, st>>>(in, out);

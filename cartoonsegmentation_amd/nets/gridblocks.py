@@ -39,8 +39,7 @@ def downsample(p, ws, name, ch, x, res=None, out=None):
 
 def upsample(p, ws, name, ch, x, res=None, out=None):
     c0, c1, c2 = ch
-    u = p.bilinear(x, (x.h * 2, x.w * 2), align_corners=False)
-    a = p.act(u, 'prelu', slope=_prelu(ws, name + '.netMain.1', c0))
+    a = p.bilinear(x, (x.h * 2, x.w * 2), align_corners=False, act='prelu', slope=_prelu(ws, name + '.netMain.1', c0))   # Upsample + PReLU, one pass
     w1, b1 = conv_plain(ws, name + '.netMain.2', c1, c0, 3)
     t = p.conv(a, w1, b1, pad=1, act='prelu', slope=_prelu(ws, name + '.netMain.3', c1))
     w2, b2 = conv_plain(ws, name + '.netMain.4', c2, c1, 3)

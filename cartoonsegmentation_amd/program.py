@@ -269,11 +269,19 @@ class Program:
             out = self.buffer(x.n, osz(x.h), osz(x.w), x.c)
         return self._emit(OP_MAXPOOL, x, None, out, kh=k, kw=k, stride=stride, pad=pad)
 
-    def bilinear(self, x, size, align_corners=False, out=None):
+    def bilinear(self, x, size, align_corners=False, out=None, act=None, slope=None):
+        """F.interpolate(mode='bilinear') [followed by an activation applied to the interpolated value in the same kernel: the
+        Upsample blocks of the Ken Burns GridNets are Upsample -> PReLU -> conv and nothing else reads the un-activated map]"""
         if out is None:
             out = self.buffer(x.n, size[0], size[1], x.c)
         assert (out.h, out.w) == tuple(size)
-        return self._emit(OP_BILINEAR, x, None, out, flags=1 if align_corners else 0)
+        a_h = a_n = -1
+        if slope is not None:
+            slope = np.asarray(slope, np.float32)
+            if slope.size < x.c:                       # zero-padded channels keep slope 0
+                slope = np.concatenate([slope, np.zeros(x.c - slope.size, np.float32)])
+            a_h, a_n = self._w(slope, slope)
+        return self._emit(OP_BILINEAR, x, None, out, flags=1 if align_corners else 0, act=ACT[act], aux_off=a_h, nat=dict(aux_off=a_n))
 
     def nearest(self, x, factor, out=None):
         if out is None:

@@ -296,7 +296,7 @@ static void src_index(int dst, int in_size, int out_size, float scale, int align
     *l0 = 1.0f - *l1;
 }
 
-static void orc_bilinear(const csm_op *op, view_t in, view_t out)
+static void orc_bilinear(const csm_op *op, view_t in, view_t out, const float *slope)
 {
     int align = op->flags & 1;
     float sh, sw;
@@ -315,7 +315,7 @@ static void orc_bilinear(const csm_op *op, view_t in, view_t out)
         for (int c = 0; c < out.c; ++c) {
             float p00 = P[((int64_t)y0 * in.w + x0) * in.ld + c], p01 = P[((int64_t)y0 * in.w + x1) * in.ld + c];
             float p10 = P[((int64_t)y1 * in.w + x0) * in.ld + c], p11 = P[((int64_t)y1 * in.w + x1) * in.ld + c];
-            out.p[m * out.ld + c] = hl0 * (wl0 * p00 + wl1 * p01) + hl1 * (wl0 * p10 + wl1 * p11);
+            out.p[m * out.ld + c] = orc_act(hl0 * (wl0 * p00 + wl1 * p01) + hl1 * (wl0 * p10 + wl1 * p11), op->act, slope ? slope[c] : 0.0f);
         }
     }
 }
@@ -444,7 +444,7 @@ int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
             }
             case CSM_OP_DWCONV: orc_dwconv(op, in, out, W, B, S); break;
             case CSM_OP_MAXPOOL: orc_maxpool(op, in, out); break;
-            case CSM_OP_BILINEAR: orc_bilinear(op, in, out); break;
+            case CSM_OP_BILINEAR: orc_bilinear(op, in, out, S); break;
             case CSM_OP_NEAREST: orc_nearest(in, out); break;
             case CSM_OP_ADD: orc_eltwise(in, in1, out, op->act, 1, NULL); break;
             case CSM_OP_SCALE: orc_eltwise(in, in1, out, op->act, 2, NULL); break;

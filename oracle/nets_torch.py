@@ -106,7 +106,8 @@ def run_program(prog, ext_arrays, want_views=(), threads=None):
                 assert tuple(y.shape[2:]) == (vo.h, vo.w)
                 wr(o['out'], y)
             elif kind == P.OP_BILINEAR:
-                wr(o['out'], F.interpolate(x, size=(vo.h, vo.w), mode='bilinear', align_corners=bool(o['flags'] & 1)))
+                slope = wt(nat['aux_off'], (vo.c,)) if nat and nat.get('aux_off', -1) >= 0 else None
+                wr(o['out'], _act(F.interpolate(x, size=(vo.h, vo.w), mode='bilinear', align_corners=bool(o['flags'] & 1)), o['act'], slope))
             elif kind == P.OP_NEAREST:
                 wr(o['out'], F.interpolate(x, size=(vo.h, vo.w), mode='nearest'))
             elif kind == P.OP_ADD:
