@@ -1522,8 +1522,7 @@ enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CF
        // three LDS stages (loads two chunks ahead) and 256 x 64 tiles (N = 64 layers: the B tile is shared by four 64 x 64 wave tiles)
        CFG_D64x64_s3 = 28, CFG_D128x64_s3 = 29, CFG_D64x128_s3 = 30, CFG_D128x128_s3 = 31, CFG_D128x128_8w_s3 = 32,
        CFG_D256x128_8w_s3 = 33, CFG_D256x64 = 34, CFG_D256x64_s3 = 35, CFG_P256x64 = 36, CFG_D64x64_s4 = 37,
-       CFG_D448x128_8w = 38, CFG_D416x128 = 39,   // one-round tiles (experiment)
-       CFG_COUNT = 40 };
+       CFG_COUNT = 38 };
 static int g_force_cfg = -1;
 static int g_force_serial = -1;    // tests: -1 = rule / tuned, 0 = parallel split-K, 1 = serial split-K
 static int g_tune_split = 1;       // tuner: consider mixed-tile launches (csm_debug_conv_tuner_options)
@@ -1588,8 +1587,6 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_D256x64_s3: return launch_conv_dma<4, 1, 2, 2, 3>(a, st);
         case CFG_P256x64: return launch_conv_patch<4, 1, 2, 2, 16>(a, st);
         case CFG_D64x64_s4: return launch_conv_dma<2, 2, 1, 1, 4>(a, st);
-        case CFG_D448x128_8w: return launch_conv_dma<2, 4, 7, 1>(a, st);
-        case CFG_D416x128: return launch_conv_dma<1, 4, 13, 1>(a, st);
         default: return launch_conv<32, 2, 2, 1>(a, st);
     }
 }

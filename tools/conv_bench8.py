@@ -20,6 +20,9 @@ LAYERS = [
     (9, 8, 80, 80, 256, 256, 3, 1, 1, 1), (16, 8, 40, 40, 256, 256, 3, 1, 1, 1), (9, 8, 80, 80, 128, 128, 3, 1, 1, 1),
     (6, 8, 20, 20, 512, 512, 3, 1, 1, 1), (12, 8, 40, 40, 256, 256, 1, 1, 1, 1), (9, 8, 80, 80, 128, 128, 1, 1, 1, 1),
     (3, 8, 160, 160, 64, 64, 3, 1, 1, 1),
+    # 26..: the GridNet of the point-cloud inpainting at 1024^2 (per pass)
+    (11, 1, 1024, 1024, 32, 32, 3, 1, 1, 1), (2, 1, 1024, 1024, 64, 32, 3, 1, 1, 1), (10, 1, 512, 512, 64, 64, 3, 1, 1, 1),
+    (1, 16, 360, 360, 64, 32, 3, 1, 1, 1),
 ]
 CFGS = [int(c) for c in os.environ.get('CFGS', '').split()]
 DBG = int(os.environ.get('DBG', '0'))
