@@ -348,6 +348,146 @@ __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict_
     }
 }
 
+// ---- render_pointcloud for ANY channel count on the tile path (Inpaint.forward splats 68 feature channels, pointcloud_inpainting.py:135) ----
+// Same binning, same z-buffer / degrid / z-test as k_tile_render; the channels are splatted in GROUPS of kGroup through 64-bit fixed-point
+// LDS accumulators (2^-32 units: |value x weight| < 2^31; the weight plane keeps 2^-40 so that a positive weight never becomes 0 and
+// `existing > 0` is the reference's decision), each group normalised by the weight plane and written as whole row segments.  The
+// per-entry geometry (corner pixels, weights, z-test) of the first kReg x 256 entries of a tile is computed once and kept in registers
+// for all groups.  Integer sums: deterministic (the L2 float-atomic path k_update_output<.., 0> is not) and ~4x faster at C = 68
+// (276 L2 atomics per point there).
+constexpr int kGroup = 8;
+constexpr float kScaleF = 4294967296.0f;             // 2^32
+struct EntryGeom { unsigned short li[4]; float w[4]; unsigned mask; };       // corner pixel in the tile, weight, z-test bits
+
+__global__ __launch_bounds__(kBlock) void k_tile_render_c(const Entry *__restrict__ entries, int cap, const float *__restrict__ data, int C,
+                                                           int64_t N, int H, int W, TileGeom g, int *__restrict__ totals,
+                                                           const Entry *__restrict__ spill, const int *__restrict__ spill_tile,
+                                                           const int *__restrict__ spill_count, float *__restrict__ render,
+                                                           float *__restrict__ existing) {
+    __shared__ float zee[ZH * ZW];
+    __shared__ float zd[TPIX];
+    __shared__ float den[TPIX];
+    __shared__ unsigned long long wacc[TPIX];
+    __shared__ unsigned long long acc[kGroup * TPIX];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int tx0 = (t % g.ntx) * TW, ty0 = (t / g.ntx) * TH;
+    for (int i = tid; i < ZH * ZW; i += kBlock) zee[i] = 1000000.0f;        // models/utils.py:59
+    for (int i = tid; i < TPIX; i += kBlock) wacc[i] = 0ull;
+    __syncthreads();
+    const int total = totals[(int64_t)t * kTotalStride];
+    const int e1 = total < cap ? total : cap;
+    entries += (int64_t)t * cap;
+    const int nspill = total > cap ? *spill_count : 0;
+    auto zee_entry = [&](const Entry &en) {                                 // updateZee, models/utils.py:101-147
+        int x0, y0, cx, cy; float w[4];
+        corner_weights(en.fx, en.fy, x0, y0, w);
+        if (!argmax_corner(w, x0, y0, cx, cy)) return;
+        if (cx < 0 || cx >= W || cy < 0 || cy >= H) return;
+        const int lx = cx - (tx0 - 1), ly = cy - (ty0 - 1);
+        if (lx < 0 || lx >= ZW || ly < 0 || ly >= ZH) return;
+        lds_min_f32(&zee[ly * ZW + lx], en.err);
+    };
+    constexpr int kReg = 4;
+    Entry en[kReg]; bool has[kReg];
+#pragma unroll
+    for (int k = 0; k < kReg; ++k) {
+        const int e = tid + k * kBlock;
+        has[k] = e < e1;
+        en[k] = has[k] ? entries[e] : Entry{0.0f, 0.0f, 0.0f, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < kReg; ++k) if (has[k]) zee_entry(en[k]);
+    for (int e = tid + kReg * kBlock; e < e1; e += kBlock) zee_entry(entries[e]);
+    for (int e = tid; e < nspill; e += kBlock) if (spill_tile[e] == t) zee_entry(spill[e]);
+    __syncthreads();
+    for (int i = tid; i < TPIX; i += kBlock) {                              // updateDegrid (models/utils.py:152-212), Jacobi form
+        const int lx = i % TW, ly = i / TW;
+        const int x = tx0 + lx, y = ty0 + ly;
+        const float c = zee[(ly + 1) * ZW + lx + 1];
+        float r = c;
+        if (x < W && y < H) {
+            int cnt = 0; float sum = 0.0f;
+            const int ox[4] = {1, 0, 1, 1}, oy[4] = {0, 1, 1, -1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x1 = x + ox[k], y1 = y + oy[k], x2 = x - ox[k], y2 = y - oy[k];
+                if (x1 < 0 || x1 >= W || y1 < 0 || y1 >= H) continue;
+                if (x2 < 0 || x2 >= W || y2 < 0 || y2 >= H) continue;
+                const float a = zee[(ly + 1 + oy[k]) * ZW + lx + 1 + ox[k]], d = zee[(ly + 1 - oy[k]) * ZW + lx + 1 - ox[k]];
+                if ((double)c >= (double)a + 1.0 && (double)c >= (double)d + 1.0) { cnt += 2; sum += a; sum += d; }
+            }
+            if (cnt > 0) r = fminf(c, sum / (float)cnt);
+        }
+        zd[i] = r;
+    }
+    __syncthreads();
+    auto geom_of = [&](const Entry &e) {                                    // updateOutput's z-test + bilinear weights (models/utils.py:215-313)
+        EntryGeom q; int x0, y0;
+        corner_weights(e.fx, e.fy, x0, y0, q.w);
+        q.mask = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+            const int lx = cx - tx0, ly = cy - ty0;
+            const bool in = lx >= 0 && lx < TW && ly >= 0 && ly < TH && cx < W && cy < H;
+            q.li[k] = (unsigned short)(in ? ly * TW + lx : 0);
+            if (in && ((double)e.err <= (double)zd[q.li[k]] + 1.0)) q.mask |= 1u << k;
+        }
+        return q;
+    };
+    EntryGeom gq[kReg];
+#pragma unroll
+    for (int k = 0; k < kReg; ++k) { gq[k] = geom_of(en[k]); if (!has[k]) gq[k].mask = 0u; }
+    // the ones channel (tenOutput[:, -1]): weights only
+    auto splat_w = [&](const EntryGeom &q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (q.mask & (1u << k)) atomicAdd(&wacc[q.li[k]], to_fixed(1.0f * q.w[k], kScaleC));
+    };
+#pragma unroll
+    for (int k = 0; k < kReg; ++k) splat_w(gq[k]);
+    for (int e = tid + kReg * kBlock; e < e1; e += kBlock) splat_w(geom_of(entries[e]));
+    for (int e = tid; e < nspill; e += kBlock) if (spill_tile[e] == t) splat_w(geom_of(spill[e]));
+    __syncthreads();
+    const int64_t plane = (int64_t)H * W;
+    for (int i = tid; i < TPIX; i += kBlock) {
+        const float e = from_fixed(wacc[i], 1.0 / 1099511627776.0);
+        den[i] = e + 0.0000001f;                                            // models/utils.py:315
+        const int x = tx0 + i % TW, y = ty0 + i / TW;
+        if (x < W && y < H) existing[(int64_t)y * W + x] = e;
+    }
+    for (int g0 = 0; g0 < C; g0 += kGroup) {
+        const int ng = C - g0 < kGroup ? C - g0 : kGroup;
+        for (int i = tid; i < kGroup * TPIX; i += kBlock) acc[i] = 0ull;
+        __syncthreads();                                                    // (also orders den[] before its first use)
+        const float *dg = data + (int64_t)g0 * N;
+        auto splat_g = [&](const EntryGeom &q, int idx) {
+            if (!q.mask) return;
+            float v[kGroup];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) v[j] = j < ng ? dg[(int64_t)j * N + idx] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(q.mask & (1u << k))) continue;
+                const float wk = q.w[k];
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) if (j < ng) atomicAdd(&acc[j * TPIX + q.li[k]], to_fixed(v[j] * wk, kScaleF));
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < kReg; ++k) splat_g(gq[k], en[k].idx);
+        for (int e = tid + kReg * kBlock; e < e1; e += kBlock) { const Entry x = entries[e]; splat_g(geom_of(x), x.idx); }
+        for (int e = tid; e < nspill; e += kBlock) if (spill_tile[e] == t) { const Entry x = spill[e]; splat_g(geom_of(x), x.idx); }
+        __syncthreads();
+        for (int i = tid; i < ng * TPIX; i += kBlock) {                     // a wave = two 32-px rows of one channel
+            const int j = i / TPIX, px = i - j * TPIX;
+            const int x = tx0 + px % TW, y = ty0 + px / TW;
+            if (x < W && y < H) render[(int64_t)(g0 + j) * plane + (int64_t)y * W + x] = from_fixed(acc[i], 1.0 / 4294967296.0) / den[px];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) totals[(int64_t)t * kTotalStride] = 0;                    // the bin counter is re-armed for the next call
+}
+
 __constant__ float kDirX[16] = {-1, 0, 1, 1, -1, 1, 2, 2, -2, -1, 1, 2, 3, 3, 3, 3};   // common.py:168
 __constant__ float kDirY[16] = {1, 1, 1, 0, 2, 2, 1, -1, 3, 3, 3, 3, 2, 1, -1, -2};    // common.py:169
 
@@ -561,4 +701,30 @@ extern "C" int csm_warp_frame_tiled(const float *pts, const float *rgb, const fl
     rc = csm::check_launch("k_tile_render"); if (rc) return rc;
     k_tile_holes<<<1024, kBlock, 0, st>>>(H, W, g, out);
     return csm::check_launch("k_tile_holes");
+}
+
+// render_pointcloud (models/utils.py:56-315) for one cloud and any channel count through the tile path: bin -> per-tile z-buffer /
+// degrid / splat in channel groups.  scratch: csm_warp_tile_scratch_bytes(H, W, N) bytes whose first csm_warp_tile_header_bytes are zero
+// between calls (zeroed once by the caller; every call leaves them zero) -- a csm_warp_frame_tiled scratch of the same size serves.
+extern "C" int csm_render_pointcloud_tiled(const float *pts, const float *data, int C, int64_t N, int W, int H, double focal,
+                                           double baseline, void *scratch, float *render, float *existing, void *stream) {
+    CSM_REQUIRE(scratch && render && existing && C > 0 && N >= 0 && H > 0 && W > 0 && N < (1ll << 29));
+    CSM_REQUIRE(N == 0 || (pts && data));
+    CSM_REQUIRE((((uintptr_t)scratch) & 15) == 0);
+    if (!csm_warp_tile_supported(H, W)) return csm::fail_arg("frame too large for the tiled path (more than 8192 tiles): use csm_render_pointcloud");
+    hipStream_t st = (hipStream_t)stream;
+    const TileGeom g = tile_geom(H, W);
+    const TileScratch ts = carve(scratch, H, W, g.nt, N);
+    int rc;
+    if (N > 0) {
+        k_tile_bin<false><<<(unsigned)bin_blocks(N), kBlock, 2 * sizeof(int) * (size_t)g.nt, st>>>(pts, N, make_proj(H, W, focal, baseline),
+                                                                                                   Shift{0, 0, 0}, g, ts.cap, make_point_map(H, W, N), ts.totals,
+                                                                                                   ts.entries, ts.spill, ts.spill_tile, ts.spill_count, ts.hole_count);
+        rc = csm::check_launch("k_tile_bin"); if (rc) return rc;
+    }
+    k_tile_render_c<<<g.nt, kBlock, 0, st>>>(ts.entries, ts.cap, data, C, N, H, W, g, ts.totals, ts.spill, ts.spill_tile, ts.spill_count,
+                                             render, existing);
+    rc = csm::check_launch("k_tile_render_c"); if (rc) return rc;
+    CSM_HIP(hipMemsetAsync(ts.spill_count, 0, sizeof(int), st));            // (the frame path's k_tile_holes re-arms it; here nothing runs after the reader)
+    return CSM_OK;
 }

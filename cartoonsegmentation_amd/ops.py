@@ -51,20 +51,48 @@ def pointrender_update_output(tenInput, tenData, tenZee, fltFocal, fltBaseline):
     return acc
 
 
-def render_pointcloud(tenInput, tenData, intWidth, intHeight, fltFocal, fltBaseline):
+_RENDER_SCRATCH = {}
+
+
+def _render_tile_scratch(dev, H, W, N):
+    """scratch of the tiled render_pointcloud, one per (device, stream, frame size), grown with the cloud; header zeroed once"""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, H, W)
+    have = _RENDER_SCRATCH.get(key)
+    if have is None or have[1] < N:
+        L = _lib.load()
+        cap = int(N * 1.25) + 1024
+        buf = torch.empty((L.csm_warp_tile_scratch_bytes(i32(H), i32(W), i64(cap)) + 3) // 4, dtype=torch.float32, device=dev)
+        buf[:(L.csm_warp_tile_header_bytes(i32(H), i32(W)) + 3) // 4].zero_()
+        _RENDER_SCRATCH[key] = have = (buf, cap)
+    return have[0]
+
+
+def render_pointcloud(tenInput, tenData, intWidth, intHeight, fltFocal, fltBaseline, path=None):
     """render_pointcloud -- anime_3dkenburns/models/utils.py:56-315
-    tenInput [B,3,N], tenData [B,C,N] -> (tenRender [B,C,H,W], tenExisting [B,1,H,W])"""
+    tenInput [B,3,N], tenData [B,C,N] -> (tenRender [B,C,H,W], tenExisting [B,1,H,W]).
+    path 'tiled' (default for one cloud on frames of at most 8192 tiles): destination-tile binning + LDS splat in channel groups
+    (csm_render_pointcloud_tiled, deterministic); 'atomics': the global-atomic chain (csm_render_pointcloud; CSM_RENDER_PATH selects)."""
+    import os
     tenInput, tenData = _dev(tenInput, "tenInput"), _dev(tenData, "tenData")
     B, C, N = tenData.shape
     if tenInput.shape[0] != B or tenInput.shape[1] != 3 or tenInput.shape[2] != N:
         raise _lib.CsmError("render_pointcloud: tenInput must be [B,3,N] matching tenData [B,C,N]")
-    zee = tenInput.new_empty([2, B, intHeight, intWidth])
-    acc = tenInput.new_empty([B, C + 1, intHeight, intWidth])
+    L = _lib.load()
+    path = path or os.environ.get('CSM_RENDER_PATH', 'tiled')
+    assert path in ('tiled', 'atomics')
     render = tenInput.new_empty([B, C, intHeight, intWidth])
     existing = tenInput.new_empty([B, 1, intHeight, intWidth])
-    check(_lib.load().csm_render_pointcloud(ptr(tenInput), ptr(tenData), i32(B), i32(C), i64(N), i32(intWidth),
-                                            i32(intHeight), f64(fltFocal), f64(fltBaseline), ptr(zee), ptr(acc),
-                                            ptr(render), ptr(existing), stream_ptr()), "render_pointcloud")
+    if path == 'tiled' and B == 1 and L.csm_warp_tile_supported(i32(intHeight), i32(intWidth)):
+        tenInput, tenData = tenInput.contiguous(), tenData.contiguous()
+        check(L.csm_render_pointcloud_tiled(ptr(tenInput), ptr(tenData), i32(C), i64(N), i32(intWidth), i32(intHeight), f64(fltFocal),
+                                            f64(fltBaseline), ptr(_render_tile_scratch(tenInput.device, intHeight, intWidth, N)),
+                                            ptr(render), ptr(existing), stream_ptr()), "render_pointcloud_tiled")
+        return render, existing
+    zee = tenInput.new_empty([2, B, intHeight, intWidth])
+    acc = tenInput.new_empty([B, C + 1, intHeight, intWidth])
+    check(L.csm_render_pointcloud(ptr(tenInput), ptr(tenData), i32(B), i32(C), i64(N), i32(intWidth),
+                                  i32(intHeight), f64(fltFocal), f64(fltBaseline), ptr(zee), ptr(acc),
+                                  ptr(render), ptr(existing), stream_ptr()), "render_pointcloud")
     return render, existing
 
 

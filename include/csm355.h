@@ -61,6 +61,14 @@ int csm_render_pointcloud(const float *pts, const float *data, int B, int C, int
                           double focal, double baseline, float *zee_scratch, float *accum_scratch,
                           float *render, float *existing, void *stream);
 
+/* The same operator for ONE cloud (B = 1) and any channel count on the destination-tile path (warptile.hip): binning, per-tile
+ * z-buffer / degrid / z-test in LDS, the channels splatted in groups of 8 through 64-bit fixed-point LDS accumulators (|data| < 2^30):
+ * deterministic sums, ~4x faster than the L2 float atomics at the 68 channels Inpaint.forward splats (pointcloud_inpainting.py:135).
+ * scratch: csm_warp_tile_scratch_bytes(H, W, N) bytes (a csm_warp_frame_tiled scratch serves) whose first csm_warp_tile_header_bytes(H, W)
+ * are zeroed once by the caller. */
+int csm_render_pointcloud_tiled(const float *pts, const float *data, int C, int64_t N, int W, int H, double focal, double baseline,
+                                void *scratch, float *render, float *existing, void *stream);
+
 /* fill_disocclusion   anime_3dkenburns/common.py:145-248
  * in [B,C,H,W], depth [B,1,H,W] -> out [B,C,H,W] (out is fully written; no pre-clone needed).
  * scratch: csm_fill_disocclusion_scratch_bytes(B,H,W) bytes of device memory (hole list + valid map). */

@@ -62,12 +62,14 @@ def test_stages_vs_golden_and_oracle(ops, path):
         assert close_frac(acc, g['accum'], 1e-4, 1e-5) == 1.0
 
 
+@pytest.mark.parametrize("how", ["tiled", "atomics"])
 @pytest.mark.parametrize("path", RENDER_CASES, ids=IDS)
-def test_render_pointcloud(ops, path):
+def test_render_pointcloud(ops, path, how):
+    """both executions of the operator (destination tiles + LDS fixed point / global float atomics; batches always take the latter)"""
     g = dict(np.load(path))
     H, W = int(g['H']), int(g['W'])
     focal, baseline = float(g['focal']), float(g['baseline'])
-    render, existing = ops.render_pointcloud(dev(g['pts_shift']), dev(g['data']), W, H, focal, baseline)
+    render, existing = ops.render_pointcloud(dev(g['pts_shift']), dev(g['data']), W, H, focal, baseline, path=how)
     render, existing = render.cpu().numpy(), existing.cpu().numpy()
     r1, e1 = orc.render_pointcloud(g['pts_shift'], g['data'], W, H, focal, baseline, degrid_mode=1)
     assert np.array_equal(existing > 0, e1 > 0)
@@ -258,3 +260,24 @@ def test_frame_inside_fma_bracket(ops, path):
     r1, e1 = orc.render_pointcloud(g['pts_shift'], g['data'], W, H, focal, baseline, degrid_mode=1)
     agree = same & np.all(np.abs(r0 - r1) <= 1e-6, axis=1)[0] & (g['fill_depth'][0, 0] > 0)
     assert near[agree].mean() >= 0.999
+
+
+
+def test_render_pointcloud_68_channels_tiled_vs_atomics_and_oracle(ops):
+    """the splat of Inpaint.forward (68 feature channels, pointcloud_inpainting.py:135) on the tile path: same coverage, values
+    within float-atomic noise of the global-atomic path and of the oracle, deterministic, scratch re-usable; ragged sizes"""
+    rng = np.random.default_rng(5)
+    for (H, W, C) in ((96, 130, 68), (41, 57, 13)):
+        sc, pts, rgb, dep, _ = _frame_case(ops, H, W, 99 + H)
+        ps = ops.shift_points(dev(pts), [3.0, -2.0, -1.5])
+        data = dev(rng.normal(0, 3, (1, C, pts.shape[2])).astype(np.float32))
+        rt, et = ops.render_pointcloud(ps, data, W, H, sc['focal'], sc['baseline'], path='tiled')
+        ra, ea = ops.render_pointcloud(ps, data, W, H, sc['focal'], sc['baseline'], path='atomics')
+        assert torch.equal(et > 0, ea > 0)
+        assert torch.allclose(et, ea, rtol=1e-5, atol=1e-6)
+        assert float(((rt - ra).abs() <= 1e-5 + 1e-4 * ra.abs()).float().mean()) >= 0.9999
+        ro, eo = orc.render_pointcloud(ps.cpu().numpy(), data.cpu().numpy(), W, H, sc['focal'], sc['baseline'], degrid_mode=1)
+        assert np.array_equal(et.cpu().numpy() > 0, eo > 0)
+        assert close_frac(rt.cpu().numpy(), ro) >= 0.999
+        rt2, et2 = ops.render_pointcloud(ps, data, W, H, sc['focal'], sc['baseline'], path='tiled')      # same scratch again
+        assert torch.equal(rt, rt2) and torch.equal(et, et2)
