@@ -589,16 +589,37 @@ __global__ __launch_bounds__(256) void k_bokeh_pass_tile(const float *__restrict
         const int im_size = min(H, W), off = nsamples / 2;
         const float ddx = dx * ctr.w, ddy = dy * ctr.w;
         float weight = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-        for (int s = 0; s < nsamples; ++s) {
-            const int sp = (s - off) * im_size;
-            const int x_ = x + (int)roundf(ddx * (float)sp), y_ = y + (int)roundf(ddy * (float)sp);
-            if (x_ >= W || y_ >= H || x_ < 0 || y_ < 0) continue;
-            const int wx = x_ - x0, wy = y_ - y0;
-            float4 t;
-            if (wx >= 0 && wx < WW && wy >= 0 && wy < WH) t = win[wy * WW + wx];
-            else { const int64_t o = (int64_t)y_ * W + x_; t = float4{img[o * 3], img[o * 3 + 1], img[o * 3 + 2], depth[o]}; }
-            weight += t.w;
-            c0 += t.x * t.w; c1 += t.y * t.w; c2 += t.z * t.w;
+        // a block whose staged window lies inside the image (all but the border tiles) needs no image-bounds test for a sample that
+        // falls inside the window: one unsigned compare per axis instead of four signed ones and two branches
+        const bool interior = x0 >= 0 && y0 >= 0 && x0 + WW <= W && y0 + WH <= H;        // block-uniform
+        if (interior) {
+            const int wx0 = lx + R, wy0 = ly + R;
+            for (int s = 0; s < nsamples; ++s) {
+                const int sp = (s - off) * im_size;
+                const int ox = (int)roundf(ddx * (float)sp), oy = (int)roundf(ddy * (float)sp);
+                const int wx = wx0 + ox, wy = wy0 + oy;
+                float4 t;
+                if ((unsigned)wx < (unsigned)WW && (unsigned)wy < (unsigned)WH) t = win[wy * WW + wx];
+                else {
+                    const int x_ = x + ox, y_ = y + oy;
+                    if (x_ >= W || y_ >= H || x_ < 0 || y_ < 0) continue;
+                    const int64_t o = (int64_t)y_ * W + x_; t = float4{img[o * 3], img[o * 3 + 1], img[o * 3 + 2], depth[o]};
+                }
+                weight += t.w;
+                c0 += t.x * t.w; c1 += t.y * t.w; c2 += t.z * t.w;
+            }
+        } else {
+            for (int s = 0; s < nsamples; ++s) {
+                const int sp = (s - off) * im_size;
+                const int x_ = x + (int)roundf(ddx * (float)sp), y_ = y + (int)roundf(ddy * (float)sp);
+                if (x_ >= W || y_ >= H || x_ < 0 || y_ < 0) continue;
+                const int wx = x_ - x0, wy = y_ - y0;
+                float4 t;
+                if (wx >= 0 && wx < WW && wy >= 0 && wy < WH) t = win[wy * WW + wx];
+                else { const int64_t o = (int64_t)y_ * W + x_; t = float4{img[o * 3], img[o * 3 + 1], img[o * 3 + 2], depth[o]}; }
+                weight += t.w;
+                c0 += t.x * t.w; c1 += t.y * t.w; c2 += t.z * t.w;
+            }
         }
         r0 = weight != 0.0f ? c0 / weight : ctr.x;
         r1 = weight != 0.0f ? c1 / weight : ctr.y;
