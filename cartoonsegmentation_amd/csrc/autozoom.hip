@@ -381,21 +381,23 @@ __global__ __launch_bounds__(kBandThreads) void k_band_cover(ProjConst pc, const
             int cnt2 = 0; float sum = 0.0f;
             // The reference tests `(double)cz >= (double)a + 1.0` per neighbour.  For |a| >= 2^-28 (or a == 0) the sum a + 1.0 is
             // exact in double, and so is cz - 1.0 for |cz| >= 2^-28 (or 0), hence the test equals (double)a <= (double)cz - 1.0
-            // = a <= thr with thr the largest float <= cz - 1.0: one threshold per pixel, fp32 compares per neighbour.  Tiny
-            // non-zero neighbours (a + 1.0 rounds in double; unreachable for real depth ranges, where z-buffer entries are ~1e6)
-            // take the reference's own expression.
+            // = a <= thr with thr the largest float <= cz - 1.0: one threshold per pixel, fp32 compares per neighbour.
             const float thr = round_down_f32((double)cz - 1.0);
-            const bool cz_exact = fabsf(cz) >= 3.7252903e-9f || cz == 0.0f;     // 2^-28: cz - 1.0 is an exact double
-            auto below = [&](float a) {
-                return (cz_exact && (fabsf(a) >= 3.7252903e-9f || a == 0.0f)) ? a <= thr : (double)cz >= (double)a + 1.0;
+            // a value for which the threshold form is not exact: non-zero and below 2^-28 (0x31800000).  Such pixels (none in a real
+            // cloud) are recomputed with the reference's expression below; the common path carries three integer ops per value read.
+            // (Selecting per neighbour between the fp32 compare and the double expression cost 0.95 ms per 256-candidate search.)
+            auto tiny = [](float v) { return ((__float_as_uint(v) & 0x7FFFFFFFu) - 1u) < 0x317FFFFFu; };
+            bool slow = tiny(cz);
+            auto line = [&](float a, float d, auto below) { if (below(a) && below(d)) { cnt2 += 2; sum += a; sum += d; } };
+            auto degrid = [&](auto below) {
+                // loop order of the reference: (1,0) (0,1) (1,1) (1,-1), the +offset end first; a line counts only if both ends are inside
+                cnt2 = 0; sum = 0.0f;
+                if (lf && rt) line(Zc[1], Zc[-1], below);
+                if (up && dn) line(Zc[W], Zc[-W], below);
+                if (lf && rt && up && dn) { line(Zc[W + 1], Zc[-W - 1], below); line(Zc[-W + 1], Zc[W - 1], below); }
             };
-            // loop order of the reference: (1,0) (0,1) (1,1) (1,-1), the +offset end first; a line counts only if both ends are inside
-            if (lf && rt) { const float a = Zc[1], d = Zc[-1]; if (below(a) && below(d)) { cnt2 += 2; sum += a; sum += d; } }
-            if (up && dn) { const float a = Zc[W], d = Zc[-W]; if (below(a) && below(d)) { cnt2 += 2; sum += a; sum += d; } }
-            if (lf && rt && up && dn) {
-                { const float a = Zc[W + 1], d = Zc[-W - 1]; if (below(a) && below(d)) { cnt2 += 2; sum += a; sum += d; } }
-                { const float a = Zc[-W + 1], d = Zc[W - 1]; if (below(a) && below(d)) { cnt2 += 2; sum += a; sum += d; } }
-            }
+            degrid([&](float a) { slow = slow || tiny(a); return a <= thr; });
+            if (slow) degrid([&](float a) { return (double)cz >= (double)a + 1.0; });
             const float r = cnt2 > 0 ? fminf(cz, sum / (float)cnt2) : cz;
             // zd holds the z-test THRESHOLD of the pixel, not the degridded value: err passes  <=>  (double)err <= (double)r + 1.0
             zd[i] = round_down_f32((double)certain_or(cz, r, n) + 1.0);
