@@ -583,6 +583,184 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 }
 
 
+// ---- persistent form of k_conv_dma: a block walks SEVERAL tiles and the loader runs one chunk ahead ACROSS tile boundaries ----------
+// In k_conv_dma every tile pays its prologue (address set-up, the first chunk's DMA round trip: ~3 us) and its epilogue with the matrix
+// pipe idle, and because all tiles of a launch take the same time the blocks of a CU stay in lock-step: their prologues never run under
+// another block's MFMA phase.  For short-K layers (K = 288: nine chunks, ~15 us of MFMA per tile) that is a fifth of the kernel.  Here
+// the grid is one round of resident blocks; a block takes tiles i, i + stride, ... of its XCD's run (the same XCD-aware order), and
+// behind the barrier of a tile's LAST chunk it sets the loader up for the NEXT tile and sends that tile's chunk 0 into the free stage:
+// the round trip runs under the last chunk's MFMAs and the epilogue's stores.  Same chunks, same chain per output: the bits of every
+// other tile configuration.  ksplit == 1 only (short-K layers do not split).
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n /* N tiles per group */, int total /* tiles */) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;
+    static_assert(GA * 8 * NW == BM && GB * 8 * NW == BN, "tile rows must split evenly over the waves");
+    constexpr int kStageF = (BM + BN) * 32;
+    constexpr unsigned kOob = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ho = a.out.h, wo = a.out.w;
+    const int Tall = a.kh * a.kw * a.ncb;
+    // this block's tiles: XCD x = blockIdx & 7 owns the run [start, start + len) of the (z, m-tile, n-tile) order, n fastest
+    const int per = (int)(gridDim.x >> 3), x = (int)(blockIdx.x & 7u), i0 = (int)(blockIdx.x >> 3);
+    const int q = total >> 3, r = total & 7;
+    const int start = x * q + (x < r ? x : r), len = q + (x < r ? 1 : 0);
+    if (i0 >= len) return;
+    const int per_z = a.m_tiles * n_n;
+
+    i32x4 ra, rb;
+    {
+        uint64_t pa = (uint64_t)a.in.p, pb = (uint64_t)a.w;
+        unsigned na = (unsigned)((((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4);
+        unsigned nb = (unsigned)((int64_t)a.groups * Tall * a.npad * 128);
+        ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
+        rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned ldsA = lds0 + (unsigned)(wave * GA * 8) * 128u, ldsB = lds0 + (unsigned)(BM + wave * GB * 8) * 128u;
+
+    // loader state of the tile being FETCHED (one chunk ahead of the tile being computed)
+    unsigned offA[GA], vmA[GA], offB[GB];
+    int l_cb = 0, l_tap = 0, l_kh = 0, l_kw = 0;
+    unsigned l_w = 0u;
+    auto loader_setup = [&](int k, bool live) {                 // tile k of the run (clamped by the caller); !live: every lane out of range
+        const int j = start + k;
+        const int g = j / per_z, rem = j - g * per_z;
+        const int mt = rem / n_n, nt = rem - mt * n_n;
+        const int m0 = mt * BM, n0 = nt * BN, cin_off = g * a.cin_g;
+#pragma unroll
+        for (int p = 0; p < GA; ++p) {
+            int row = 8 * (wave * GA + p) + (lane >> 3);
+            int slot = (lane & 7) ^ ((row >> 1) & 7);
+            int m = m0 + row;
+            bool rv = live && m < a.M;
+            int mm = rv ? m : 0;
+            int n = mm / (ho * wo), rem2 = mm - n * ho * wo;
+            int oy = rem2 / wo, ox = rem2 - oy * wo;
+            int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            offA[p] = (unsigned)(((n * a.in.h + iy0) * a.in.w + ix0) * a.in.ld + cin_off + slot * 4) * 4u;
+            unsigned vm = 0u;
+            if (rv)
+                for (int kh = 0; kh < a.kh; ++kh)
+                    for (int kw = 0; kw < a.kw; ++kw) {
+                        int iy = iy0 + kh * a.dil, ix = ix0 + kw * a.dil;
+                        if (iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w) vm |= 1u << (kh * a.kw + kw);
+                    }
+            vmA[p] = vm;
+        }
+#pragma unroll
+        for (int p = 0; p < GB; ++p) {
+            int row = 8 * (wave * GB + p) + (lane >> 3);
+            int slot = (lane & 7) ^ ((row >> 1) & 7);
+            offB[p] = (live && n0 + row < a.npad) ? (unsigned)((n0 + row) * 32 + slot * 4) * 4u : kOob;
+        }
+        l_cb = 0; l_tap = 0; l_kh = 0; l_kw = 0;
+        l_w = (unsigned)((int64_t)g * Tall * a.npad * 128);
+    };
+    auto issue = [&](int stage) {
+        const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
+        const unsigned sb = (unsigned)stage * (unsigned)(kStageF * 4);
+#pragma unroll
+        for (int p = 0; p < GA; ++p)
+            dma16(((vmA[p] >> l_tap) & 1u) ? offA[p] + coff : kOob, ra, ldsA + sb + (unsigned)p * 1024u);
+#pragma unroll
+        for (int p = 0; p < GB; ++p)
+            dma16(offB[p] == kOob ? kOob : offB[p] + l_w, rb, ldsB + sb + (unsigned)p * 1024u);
+        l_w += (unsigned)a.npad * 128u;
+        ++l_tap;
+        if (++l_kw == a.kw) { l_kw = 0; if (++l_kh == a.kh) { l_kh = 0; l_tap = 0; ++l_cb; } }
+    };
+
+    int sw[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) sw[kb] = ((2 * kb + lh) ^ ((li >> 1) & 7)) * 4;
+    const int rowA = (32 * TM * wm + li) * 32, rowB = (BM + 32 * TN * wn + li) * 32;
+    f32x16 acc[TM][TN];
+    auto compute = [&](int stage) {
+        const float *S = lds + stage * kStageF;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(S + rowA + i * 1024 + sw[kb]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(S + rowB + j * 1024 + sw[kb]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = t == 0 ? af[i].x : (t == 1 ? af[i].y : (t == 2 ? af[i].z : af[i].w));
+                        const float bv = t == 0 ? bf[j].x : (t == 1 ? bf[j].y : (t == 2 ? bf[j].z : bf[j].w));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+        }
+    };
+
+    loader_setup(i0, true);
+    issue(0);
+    int st = 0;
+    for (int k = i0; k < len; k += per) {
+        const int j = start + k;
+        const int g = j / per_z, rem = j - g * per_z;
+        const int mt = rem / n_n, nt = rem - mt * n_n;
+        const int m0 = mt * BM, n0 = nt * BN, cout_off = g * a.cout_g;
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {
+            int n = n0 + 32 * (TN * wn + jj) + li;
+            float b = (a.bias && n < a.cout_g) ? a.bias[cout_off + n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) acc[i][jj][rr] = b;
+        }
+        for (int chunk = 0; chunk + 1 < Tall; ++chunk, st ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(st ^ 1);
+            compute(st);
+        }
+        // the tile's last chunk: the NEXT tile's chunk 0 goes out behind the barrier (branch-free: past the end every lane is out
+        // of range and the DMA writes zeros into a stage nobody reads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int kn = k + per;
+            const bool more = kn < len;
+            loader_setup(more ? kn : k, more);
+            issue(st ^ 1);
+        }
+        compute(st);
+        st ^= 1;
+        // epilogue: lane holds column li of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {
+            int n = n0 + 32 * (TN * wn + jj) + li;
+            if (n >= a.cout_g) continue;
+            float slope = a.slope ? a.slope[cout_off + n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    int m = m0 + 32 * (TM * wm + i) + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                    if (m >= a.M) continue;
+                    float v = acc[i][jj][rr];
+                    if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
+                    v = apply_act(v, a.act, slope);
+                    if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
+                    a.out.p[(int64_t)m * a.out.ld + cout_off + n] = v;
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetch must land before the block's LDS is released
+}
+
 // ---- 3x3 (stride 1, dilation 1) convolution with input-patch re-use -------------------------------------------------------
 // k_conv_dma moves the A tile (BM pixels x 32 channels) once per (32-channel block, tap): nine times per block for a 3x3.
 // The micro-benchmark (tools/ubench/glds_loop.hip, "A/5") shows that LDS-DMA volume is what costs MFMA rate (64x64 tile:
@@ -775,6 +953,207 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
                 a.out.p[m * a.out.ld + cout_off + nn] = v;
             }
         }
+}
+
+// ---- persistent form of k_conv_patch: the NEXT tile's input patch is fetched during the current tile's taps -------------------------
+// With 32 or 64 input channels a tile has one or two channel blocks: k_conv_patch fetches the tile's only (first) patch in its
+// prologue, the one DMA round trip of the tile that nothing hides (all blocks of a CU run in lock-step), and the plain DMA kernel has
+// one chunk of MFMAs (1.7 us at four 128x32 blocks per CU) to hide every HBM miss behind.  Here a block walks several tiles and the
+// sequence of (tile, channel block) patches is double-buffered ACROSS tiles: at the first tap of a tile's last channel block the
+// loader switches to the next tile and sends its first patch -- nine taps of MFMAs ahead of its use; the weights of the next tile's
+// first tap go out behind the barrier of the last tap.  Same chunks, same chain per output.  ksplit == 1 only.
+template <int WM, int WN, int TM, int TN, int TW>
+__global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, int tiles_x, int tiles_y, int n_n, int total) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
+    constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+    constexpr int NPP = (NPIX + 7) / 8;
+    constexpr int QP = (NPP + NW - 1) / NW;
+    constexpr int GB = BN / 8 / NW;
+    static_assert(GB * 8 * NW == BN && TH * TW == BM && (TW == 16 || TW == 8), "tile shape");
+    constexpr int kPPT = (QP + 7) / 8, kPT = (QP + kPPT - 1) / kPPT;      // patch pieces per tap / taps that carry a slice (<= 8)
+    constexpr int kPatchF = QP * NW * 8 * 32, kBF = BN * 32;
+    constexpr unsigned kOob = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [patch 0][patch 1][B 0][B 1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ho = a.out.h, wo = a.out.w;
+    const int ncb = a.ncb, Tall = 9 * ncb;
+    const int per = (int)(gridDim.x >> 3), x = (int)(blockIdx.x & 7u), i0 = (int)(blockIdx.x >> 3);
+    const int q = total >> 3, r = total & 7;
+    const int start = x * q + (x < r ? x : r), len = q + (x < r ? 1 : 0);
+    if (i0 >= len) return;
+    const int per_z = a.m_tiles * n_n, per_img = tiles_x * tiles_y;
+
+    i32x4 ra, rb;
+    {
+        uint64_t pa = (uint64_t)a.in.p, pb = (uint64_t)a.w;
+        unsigned na = (unsigned)((((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4);
+        unsigned nb = (unsigned)((int64_t)a.groups * Tall * a.npad * 128);
+        ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
+        rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
+    }
+    auto tile_of = [&](int k, int &mt, int &nt, int &g) { const int j = start + k; g = j / per_z; const int rem = j - g * per_z; mt = rem / n_n; nt = rem - mt * n_n; };
+    // patch loader (tile being fetched): wave w owns pieces w, w+NW, ...; lane -> patch pixel 8*piece + lane/8, physical slot lane%8
+    unsigned offP[QP], offB[GB];
+    auto patch_setup = [&](int k, bool live) {
+        int mt, nt, g; tile_of(k, mt, nt, g);
+        const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, n = mt / per_img;
+        const int iy0 = ty * TH - a.pad, ix0 = tx * TW - a.pad, cin_off = g * a.cin_g;
+#pragma unroll
+        for (int qq = 0; qq < QP; ++qq) {
+            int pp = 8 * (wave + qq * NW) + (lane >> 3);
+            int slot = (lane & 7) ^ ((pp >> 1) & 7);
+            int py = pp / PW, px = pp - py * PW;
+            int iy = iy0 + py, ix = ix0 + px;
+            bool v = live && pp < NPIX && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+            offP[qq] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + cin_off + slot * 4) * 4u : kOob;
+        }
+    };
+    unsigned l_w = 0u;
+    auto b_setup = [&](int k, bool live) {
+        int mt, nt, g; tile_of(k, mt, nt, g);
+        const int n0 = nt * BN;
+#pragma unroll
+        for (int p = 0; p < GB; ++p) {
+            int row = 8 * (wave * GB + p) + (lane >> 3);
+            int slot = (lane & 7) ^ ((row >> 1) & 7);
+            offB[p] = (live && n0 + row < a.npad) ? (unsigned)((n0 + row) * 32 + slot * 4) * 4u : kOob;
+        }
+        l_w = (unsigned)((int64_t)g * Tall * a.npad * 128);
+    };
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned ldsB = lds0 + (unsigned)(2 * kPatchF * 4) + (unsigned)(wave * GB * 8) * 128u;
+    auto issue_patch = [&](int cb, int pstage) {               // all 32-channel rows of block cb of the tile offP describes
+        const unsigned sb = lds0 + (unsigned)pstage * (unsigned)(kPatchF * 4);
+#pragma unroll
+        for (int qq = 0; qq < QP; ++qq)
+            dma16(offP[qq] == kOob ? kOob : offP[qq] + (unsigned)cb * 128u, ra, sb + (unsigned)(wave + qq * NW) * 1024u);
+    };
+    auto issue_b = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < GB; ++p)
+            dma16(offB[p] == kOob ? kOob : offB[p] + l_w, rb, ldsB + (unsigned)stage * (unsigned)(kBF * 4) + (unsigned)p * 1024u);
+        l_w += (unsigned)a.npad * 128u;
+    };
+
+    int ppb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int rr = 32 * (TM * wm + i) + li;
+        ppb[i] = (rr / TW) * PW + (rr % TW);
+    }
+    int swb[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) swb[kb] = ((2 * kb + lh) ^ ((li >> 1) & 7)) * 4;
+    const int rowB = (32 * TN * wn + li) * 32;
+    f32x16 acc[TM][TN];
+    auto compute = [&](int pstage, int tap, int bstage) {
+        const float *SP = lds + pstage * kPatchF;
+        const float *SB = lds + 2 * kPatchF + bstage * kBF;
+        const int kh = tap / 3, toff = kh * PW + (tap - 3 * kh);
+        int arow[TM], asw[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { int pp = ppb[i] + toff; arow[i] = pp * 32; asw[i] = (pp >> 1) & 7; }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(SP + arow[i] + (((2 * kb + lh) ^ asw[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(SB + rowB + j * 1024 + swb[kb]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = t == 0 ? af[i].x : (t == 1 ? af[i].y : (t == 2 ? af[i].z : af[i].w));
+                        const float bv = t == 0 ? bf[j].x : (t == 1 ? bf[j].y : (t == 2 ? bf[j].z : bf[j].w));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+        }
+    };
+
+    patch_setup(i0, true);
+    b_setup(i0, true);
+    issue_patch(0, 0);
+    issue_b(0);
+    int ps = 0, st = 0;                                         // stage of the patch / of the weights about to be consumed
+    for (int k = i0; k < len; k += per) {
+        int mt, nt, g; tile_of(k, mt, nt, g);
+        const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, n = mt / per_img;
+        const int n0 = nt * BN, cout_off = g * a.cout_g;
+        const int kn = k + per;
+        const bool more = kn < len;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int nn = n0 + 32 * (TN * wn + j) + li;
+            float b = (a.bias && nn < a.cout_g) ? a.bias[cout_off + nn] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) acc[i][j][rr] = b;
+        }
+        for (int cb = 0; cb < ncb; ++cb, ps ^= 1) {
+            const bool last_cb = cb + 1 == ncb;
+            // The next patch of the sequence -- block cb + 1 of this tile or (last block) block 0 of the NEXT tile, for which the loader
+            // state is switched at tap 0 -- goes out in SLICES of kPPT pieces behind the weights of taps 0 .. kPT - 1.  vmcnt retires in
+            // order, so "at most kPPT outstanding" at the next barrier means the weights have landed and the slice may still fly:
+            // every slice has two taps of MFMAs to arrive in (HBM misses included) instead of one.  Branch-free: past the end every
+            // lane is out of range and the DMA writes zeros into a stage nobody reads.
+            auto chunk = [&](auto TAPC) {
+                constexpr int tap = decltype(TAPC)::value;
+                if constexpr (tap >= 1 && tap <= kPT) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPPT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if constexpr (tap == 0) { if (last_cb) patch_setup(more ? kn : k, more); }
+                if constexpr (tap == 8) { if (last_cb) b_setup(more ? kn : k, more); }      // the weights of the next tile's first tap
+                issue_b(st ^ 1);
+                if constexpr (tap < kPT) {
+                    const unsigned sb = lds0 + (unsigned)(ps ^ 1) * (unsigned)(kPatchF * 4);
+                    const unsigned cbo = (unsigned)(last_cb ? 0 : cb + 1) * 128u;
+#pragma unroll
+                    for (int qq = tap * kPPT; qq < (tap + 1) * kPPT && qq < QP; ++qq)
+                        dma16(offP[qq] == kOob ? kOob : offP[qq] + cbo, ra, sb + (unsigned)(wave + qq * NW) * 1024u);
+                }
+                compute(ps, tap, st);
+                st ^= 1;
+            };
+            chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{}); chunk(std::integral_constant<int, 2>{});
+            chunk(std::integral_constant<int, 3>{}); chunk(std::integral_constant<int, 4>{}); chunk(std::integral_constant<int, 5>{});
+            chunk(std::integral_constant<int, 6>{}); chunk(std::integral_constant<int, 7>{}); chunk(std::integral_constant<int, 8>{});
+        }
+        // epilogue
+        float slope[TN]; int ncol[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            ncol[j] = n0 + 32 * (TN * wn + j) + li;
+            slope[j] = (a.slope && ncol[j] < a.cout_g) ? a.slope[cout_off + ncol[j]] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int rrow = 32 * (TM * wm + i) + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                const int oy = ty * TH + rrow / TW, ox = tx * TW + rrow % TW;
+                if (oy >= ho || ox >= wo) continue;
+                const int64_t m = ((int64_t)n * ho + oy) * wo + ox;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nn = ncol[j];
+                    if (nn >= a.cout_g) continue;
+                    float v = acc[i][j][rr];
+                    if (a.res_mode == 1) v += a.res.p[m * a.res.ld + cout_off + nn];
+                    v = apply_act(v, a.act, slope[j]);
+                    if (a.res_mode == 2) v += a.res.p[m * a.res.ld + cout_off + nn];
+                    a.out.p[m * a.out.ld + cout_off + nn] = v;
+                }
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetches must land before the block's LDS is released
 }
 
 // ---- stem convolution (cin padded to 4: RTMDet / ISNet / LeReS first layers) -----------------------------------------------
@@ -1466,6 +1845,32 @@ int launch_conv_dma(const ConvArgs &a, hipStream_t st) {
     return launch_conv_dma_t<WM, WN, TM, TN, NS, false>(a, st);
 }
 
+// persistent launch: one round of resident blocks (a multiple of 8, at most one block per tile); layers that split K take the
+// one-tile-per-block kernel of the same shape
+template <int WM, int WN, int TM, int TN>
+int launch_conv_dma_p(const ConvArgs &a0, hipStream_t st) {
+    if (a0.ksplit > 1 || a0.m_begin != 0) return launch_conv_dma<WM, WN, TM, TN>(a0, st);
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    ConvArgs a = a0;
+    const size_t lds = (size_t)2 * (BM + BN) * 128;
+    static unsigned prepared = 0;
+    static int blocks_per_cu = 1;
+    if (first_use_on_device(prepared)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma_p<WM, WN, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_dma_p<WM, WN, TM, TN>), 64 * WM * WN, lds) == hipSuccess && nb > 0)
+            blocks_per_cu = nb;
+    }
+    a.m_tiles = (a.M + BM - 1) / BM;
+    const int n_n = (a.cout_g + BN - 1) / BN;
+    const int64_t total = (int64_t)a.m_tiles * n_n * a.groups;
+    if (total >= (1ll << 30)) return launch_conv_dma<WM, WN, TM, TN>(a0, st);
+    int64_t grid = 256ll * blocks_per_cu;
+    if (grid > ((total + 7) & ~7ll)) grid = (total + 7) & ~7ll;
+    k_conv_dma_p<WM, WN, TM, TN><<<(unsigned)grid, 64 * WM * WN, lds, st>>>(a, n_n, (int)total);
+    return csm::check_launch("k_conv_dma_p");
+}
+
 template <int WM, int WN, int TM, int TN, int TW, bool SER>
 int launch_conv_patch_t(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
@@ -1489,6 +1894,32 @@ template <int WM, int WN, int TM, int TN, int TW>
 int launch_conv_patch(const ConvArgs &a, hipStream_t st) {
     if (a.ksplit > 1 && a.serial) return launch_conv_patch_t<WM, WN, TM, TN, TW, true>(a, st);
     return launch_conv_patch_t<WM, WN, TM, TN, TW, false>(a, st);
+}
+
+template <int WM, int WN, int TM, int TN, int TW>
+int launch_conv_patch_p(const ConvArgs &a0, hipStream_t st) {
+    if (a0.ksplit > 1) return launch_conv_patch<WM, WN, TM, TN, TW>(a0, st);
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
+    constexpr int NW = WM * WN, NPP = ((((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW) * NW;
+    ConvArgs a = a0;
+    const int tiles_x = (a.out.w + TW - 1) / TW, tiles_y = (a.out.h + TH - 1) / TH;
+    a.m_tiles = tiles_x * tiles_y * a.out.n;
+    const size_t lds = ((size_t)2 * NPP * 8 * 32 + (size_t)2 * BN * 32) * 4;
+    static unsigned prepared = 0;
+    static int blocks_per_cu = 1;
+    if (first_use_on_device(prepared)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch_p<WM, WN, TM, TN, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_patch_p<WM, WN, TM, TN, TW>), 64 * WM * WN, lds) == hipSuccess && nb > 0)
+            blocks_per_cu = nb;
+    }
+    const int n_n = (a.cout_g + BN - 1) / BN;
+    const int64_t total = (int64_t)a.m_tiles * n_n * a.groups;
+    if (total >= (1ll << 30)) return launch_conv_patch<WM, WN, TM, TN, TW>(a0, st);
+    int64_t grid = 256ll * blocks_per_cu;
+    if (grid > ((total + 7) & ~7ll)) grid = (total + 7) & ~7ll;
+    k_conv_patch_p<WM, WN, TM, TN, TW><<<(unsigned)grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y, n_n, (int)total);
+    return csm::check_launch("k_conv_patch_p");
 }
 
 static bool narrow_eligible(const ConvArgs &a) {
@@ -1522,7 +1953,11 @@ enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CF
        // three LDS stages (loads two chunks ahead) and 256 x 64 tiles (N = 64 layers: the B tile is shared by four 64 x 64 wave tiles)
        CFG_D64x64_s3 = 28, CFG_D128x64_s3 = 29, CFG_D64x128_s3 = 30, CFG_D128x128_s3 = 31, CFG_D128x128_8w_s3 = 32,
        CFG_D256x128_8w_s3 = 33, CFG_D256x64 = 34, CFG_D256x64_s3 = 35, CFG_P256x64 = 36, CFG_D64x64_s4 = 37,
-       CFG_COUNT = 38 };
+       // persistent blocks, loader one chunk ahead across tile boundaries (k_conv_dma_p); ksplit == 1 layers
+       CFG_Q64x64 = 38, CFG_Q128x64 = 39, CFG_Q64x128 = 40, CFG_Q128x128_8w = 41, CFG_Q128x32 = 42,
+       // persistent patch kernel (k_conv_patch_p): the next tile's patch is fetched during the current tile's taps
+       CFG_R128x32 = 43, CFG_R64x64 = 44, CFG_R128x64 = 45, CFG_R128x32_w8 = 46,
+       CFG_COUNT = 47 };
 static int g_force_cfg = -1;
 static int g_force_serial = -1;    // tests: -1 = rule / tuned, 0 = parallel split-K, 1 = serial split-K
 static int g_tune_split = 1;       // tuner: consider mixed-tile launches (csm_debug_conv_tuner_options)
@@ -1587,6 +2022,15 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_D256x64_s3: return launch_conv_dma<4, 1, 2, 2, 3>(a, st);
         case CFG_P256x64: return launch_conv_patch<4, 1, 2, 2, 16>(a, st);
         case CFG_D64x64_s4: return launch_conv_dma<2, 2, 1, 1, 4>(a, st);
+        case CFG_Q64x64: return launch_conv_dma_p<2, 2, 1, 1>(a, st);
+        case CFG_Q128x64: return launch_conv_dma_p<2, 2, 2, 1>(a, st);
+        case CFG_Q64x128: return launch_conv_dma_p<2, 2, 1, 2>(a, st);
+        case CFG_Q128x128_8w: return launch_conv_dma_p<2, 4, 2, 1>(a, st);
+        case CFG_Q128x32: return launch_conv_dma_p<4, 1, 1, 1>(a, st);
+        case CFG_R128x32: return launch_conv_patch_p<4, 1, 1, 1, 16>(a, st);
+        case CFG_R64x64: return launch_conv_patch_p<2, 2, 1, 1, 16>(a, st);
+        case CFG_R128x64: return launch_conv_patch_p<2, 2, 2, 1, 16>(a, st);
+        case CFG_R128x32_w8: return launch_conv_patch_p<4, 1, 1, 1, 8>(a, st);
         default: return launch_conv<32, 2, 2, 1>(a, st);
     }
 }
@@ -1654,7 +2098,7 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 a.serial = a.ksplit > 1 && (g_force_serial >= 0 ? g_force_serial != 0 : tuned ? (op.tile & kTileSerial) != 0
                                             : (int64_t)((a.M + 63) / 64) * ((op.cout_g + 63) / 64) >= 512);
                 int cfg = tuned ? tcfg - 1 : choose_cfg(a, op.cout_g);
-                if (((cfg >= CFG_P64x64 && cfg <= CFG_P128x128_8w) || cfg == CFG_P256x64) && !patch_eligible(a)) cfg = CFG_D64x64;
+                if (((cfg >= CFG_P64x64 && cfg <= CFG_P128x128_8w) || cfg == CFG_P256x64 || cfg >= CFG_R128x32) && !patch_eligible(a)) cfg = CFG_D64x64;
                 if (cfg == CFG_NARROW && !narrow_eligible(a)) cfg = CFG_64x16;
                 if (cfg >= CFG_D64x64 && cfg != CFG_NARROW && !dma_eligible(a)) cfg = op.cout_g <= 16 ? CFG_64x16 : (op.cout_g <= 32 ? CFG_128x32 : CFG_64x64);
                 rc = launch_conv_cfg(cfg, a, st);
@@ -1816,9 +2260,13 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         static const int cand_all[] = {CFG_64x64, CFG_128x32, CFG_64x16, CFG_D64x64, CFG_D128x64, CFG_D64x128, CFG_D128x128,
                                        CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32, CFG_NARROW, CFG_D96x128, CFG_D160x128,
                                        CFG_D224x128, CFG_D192x128, CFG_P64x64, CFG_P128x64, CFG_P64x128, CFG_P128x128, CFG_P256x128,
-                                       CFG_P128x32, CFG_P64x64_w8, CFG_P128x128_w8, CFG_P128x32_w8, CFG_P128x128_8w};
+                                       CFG_P128x32, CFG_P64x64_w8, CFG_P128x128_w8, CFG_P128x32_w8, CFG_P128x128_8w,
+                                       CFG_Q64x64, CFG_Q128x64, CFG_Q64x128, CFG_Q128x128_8w, CFG_Q128x32,
+                                       CFG_R128x32, CFG_R64x64, CFG_R128x64, CFG_R128x32_w8};
         static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32, 4, 128, 128, 128, 128,
-                                      64, 64, 128, 128, 128, 32, 64, 128, 32, 128};
+                                      64, 64, 128, 128, 128, 32, 64, 128, 32, 128,
+                                      64, 64, 128, 128, 32,
+                                      32, 64, 64, 32};
         // identical layers (same shapes / strides / split) share one measurement, also across programs
         View vin{}, vout{};
         rc = make_view(tensors, n_tensors, op.in0, workspace, ext, n_ext, vin); if (rc) break;
@@ -1850,7 +2298,11 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         std::vector<std::pair<float, int>> timed;
         for (size_t c = 0; c < sizeof(cand_all) / sizeof(int); ++c) {
             if (cand_bn[c] >= 2 * npad && cand_bn[c] > 32) continue;      // tile much wider than the output: never wins
-            if (cand_all[c] >= CFG_P64x64 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
+            if (cand_all[c] >= CFG_Q64x64) {                                     // persistent blocks: layers that do not split K
+                if (op.ksplit > 1) continue;
+                if (cand_all[c] >= CFG_R128x32 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
+            }
+            else if (cand_all[c] >= CFG_P64x64 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
             if (cand_bn[c] == 4 && (op.cout_g > 4 || op.groups != 1 || op.ksplit > 1)) continue;
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
             if (cand_bn[c] == 32 && op.cout_g > 64 && (op.cout_g % 64) != 32) continue;   // (96, 160 ... outputs: 32-wide tiles waste no MFMA columns)

@@ -140,6 +140,8 @@ FULL_SIZE_LAYERS = [
     (2, 90, 90, 128, 256, 3, 1, 1, 1),       # ISNet
     (1, 45, 45, 256, 256, 3, 1, 4, 1),       # ISNet RSU4F dilated
     (1, 160, 160, 128, 256, 3, 2, 1, 1),     # CSPNeXt stride-2 stage conv
+    (1, 333, 517, 32, 32, 3, 1, 1, 1),       # GridNet-like 32 -> 32 on a ragged frame: several tiles per persistent block, M tail
+    (4, 80, 80, 32, 96, 1, 1, 1, 1),         # one-chunk 1x1 (every chunk is a tile's last), ragged N
 ]
 
 
@@ -170,7 +172,7 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
     L = _lib.load()
     ref, names = None, {}
     try:
-        for cfg in range(28):
+        for cfg in list(range(28)) + list(range(38, 47)):       # 38..46: the persistent-block kernels (fall back when K is split / not a 3x3)
             L.csm_debug_force_conv_cfg(cfg)
             cp.run()
             out = cp.read_view(y).cpu().numpy()
