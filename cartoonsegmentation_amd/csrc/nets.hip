@@ -1956,8 +1956,8 @@ enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CF
        // persistent blocks, loader one chunk ahead across tile boundaries (k_conv_dma_p); ksplit == 1 layers
        CFG_Q64x64 = 38, CFG_Q128x64 = 39, CFG_Q64x128 = 40, CFG_Q128x128_8w = 41, CFG_Q128x32 = 42,
        // persistent patch kernel (k_conv_patch_p): the next tile's patch is fetched during the current tile's taps
-       CFG_R128x32 = 43, CFG_R64x64 = 44, CFG_R128x64 = 45, CFG_R128x32_w8 = 46,
-       CFG_COUNT = 47 };
+       CFG_R128x32 = 43, CFG_R64x64 = 44, CFG_R128x64 = 45, CFG_R128x32_w8 = 46, CFG_R128x128_8w = 47, CFG_R64x128 = 48, CFG_R64x64_w8 = 49,
+       CFG_COUNT = 50 };
 static int g_force_cfg = -1;
 static int g_force_serial = -1;    // tests: -1 = rule / tuned, 0 = parallel split-K, 1 = serial split-K
 static int g_tune_split = 1;       // tuner: consider mixed-tile launches (csm_debug_conv_tuner_options)
@@ -2031,6 +2031,9 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_R64x64: return launch_conv_patch_p<2, 2, 1, 1, 16>(a, st);
         case CFG_R128x64: return launch_conv_patch_p<2, 2, 2, 1, 16>(a, st);
         case CFG_R128x32_w8: return launch_conv_patch_p<4, 1, 1, 1, 8>(a, st);
+        case CFG_R128x128_8w: return launch_conv_patch_p<2, 4, 2, 1, 16>(a, st);
+        case CFG_R64x128: return launch_conv_patch_p<2, 2, 1, 2, 16>(a, st);
+        case CFG_R64x64_w8: return launch_conv_patch_p<2, 2, 1, 1, 8>(a, st);
         default: return launch_conv<32, 2, 2, 1>(a, st);
     }
 }
@@ -2262,11 +2265,11 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
                                        CFG_D224x128, CFG_D192x128, CFG_P64x64, CFG_P128x64, CFG_P64x128, CFG_P128x128, CFG_P256x128,
                                        CFG_P128x32, CFG_P64x64_w8, CFG_P128x128_w8, CFG_P128x32_w8, CFG_P128x128_8w,
                                        CFG_Q64x64, CFG_Q128x64, CFG_Q64x128, CFG_Q128x128_8w, CFG_Q128x32,
-                                       CFG_R128x32, CFG_R64x64, CFG_R128x64, CFG_R128x32_w8};
+                                       CFG_R128x32, CFG_R64x64, CFG_R128x64, CFG_R128x32_w8, CFG_R128x128_8w, CFG_R64x128, CFG_R64x64_w8};
         static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32, 4, 128, 128, 128, 128,
                                       64, 64, 128, 128, 128, 32, 64, 128, 32, 128,
                                       64, 64, 128, 128, 32,
-                                      32, 64, 64, 32};
+                                      32, 64, 64, 32, 128, 128, 64};
         // identical layers (same shapes / strides / split) share one measurement, also across programs
         View vin{}, vout{};
         rc = make_view(tensors, n_tensors, op.in0, workspace, ext, n_ext, vin); if (rc) break;

@@ -172,7 +172,7 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
     L = _lib.load()
     ref, names = None, {}
     try:
-        for cfg in list(range(28)) + list(range(38, 47)):       # 38..46: the persistent-block kernels (fall back when K is split / not a 3x3)
+        for cfg in list(range(28)) + list(range(38, 50)):       # 38..49: the persistent-block kernels (fall back when K is split / not a 3x3)
             L.csm_debug_force_conv_cfg(cfg)
             cp.run()
             out = cp.read_view(y).cpu().numpy()
