@@ -529,6 +529,23 @@ extern "C" int csm_depth_range_stats(const float *minmax_raw_dev, float scale, c
     return csm::check_launch("k_crop_minmaxloc");
 }
 
+// uint8 HWC image -> float32 CHW in [0, 1]: `img.permute(2, 0, 1)[None].float() * (1.0 / 255.0)` (kenburns_effect.py:878-880 feeds every
+// net input from this tensor) -- one pass instead of torch's convert, multiply and contiguous copy; the same fp32 product
+namespace {
+__global__ __launch_bounds__(256) void k_u8_hwc_to_f32_chw(const uint8_t *__restrict__ src, int64_t plane, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= plane) return;
+    const float s = (float)(1.0 / 255.0);
+    out[i] = (float)src[i * 3] * s; out[plane + i] = (float)src[i * 3 + 1] * s; out[2 * plane + i] = (float)src[i * 3 + 2] * s;
+}
+}  // namespace
+extern "C" int csm_u8_hwc_to_f32_chw(const uint8_t *src_hwc, int H, int W, float *out_chw, void *stream) {
+    CSM_REQUIRE(src_hwc && out_chw && H > 0 && W > 0);
+    const int64_t plane = (int64_t)H * W;
+    k_u8_hwc_to_f32_chw<<<csm::cdiv(plane, 256), 256, 0, (hipStream_t)stream>>>(src_hwc, plane, out_chw);
+    return csm::check_launch("k_u8_hwc_to_f32_chw");
+}
+
 extern "C" int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream) {
     CSM_REQUIRE(src && out && h > 0 && w > 0 && H >= h && W >= w);
     k_resize_u8_to_f32<<<dim3(csm::cdiv(W, 256), H), 256, 0, (hipStream_t)stream>>>(src, h, w, H, W, out);

@@ -267,7 +267,7 @@ class KenBurnsPipeline:
         """kenburns_effect.py:812-818"""
         from .zoedepth import depth_to_disparity
         if img_tensor is None:
-            img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+            img_tensor = ops.image_tensor(img_d)                                    # permute(2, 0, 1)[None].float() * (1.0 / 255.0)
         depth = self.depth_zoe.infer(img_tensor, with_flip_aug=True, pad_input=True)
         return depth_to_disparity(depth, self.cfg.focal, self.cfg.baseline)
 
@@ -300,7 +300,7 @@ class KenBurnsPipeline:
         """disparity_estimation (anime_3dkenburns/models/__init__.py:43-52): bilinear resize to <= 512, VGG19-BN semantics, GridNet;
         returns the disparity at HALF that resolution (depth_adjustment / Refine bring it back, kenburns_effect.py:49-52, :619-622)"""
         if img_tensor is None:
-            img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+            img_tensor = ops.image_tensor(img_d)                                    # permute(2, 0, 1)[None].float() * (1.0 / 255.0)
         H, W = int(img_tensor.shape[2]), int(img_tensor.shape[3])
         ratio = float(W) / float(H)
         w, h = min(int(512 * ratio), 512), min(int(512 / ratio), 512)
@@ -507,7 +507,7 @@ class KenBurnsPipeline:
         if instances is None:
             instances, _ = self.run_instance_segmentation(img, scale_down_to_maxsize=False)
         if img_tensor is None:
-            img_tensor = (img_d.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+            img_tensor = ops.image_tensor(img_d)                                    # permute(2, 0, 1)[None].float() * (1.0 / 255.0)
         disparity = self._depth_est(img_tensor, img_d) if coarse is None else coarse
         verbose = kw.get('verbose', False) and kcfg is not None
         if verbose:
@@ -606,7 +606,7 @@ class KenBurnsPipeline:
         H, W = int(frame_dev.shape[0]), int(frame_dev.shape[1])
         instances.resize(H, W)
         self.cfg.int_height, self.cfg.int_width = H, W
-        img_tensor = (frame_dev.permute(2, 0, 1)[None].float() * (1.0 / 255.0)).contiguous()
+        img_tensor = ops.image_tensor(frame_dev)                                    # permute(2, 0, 1)[None].float() * (1.0 / 255.0)
         cfg = self.cfg.copy()
         disparity = self.infer_disparity(frame_dev, instances, img_tensor, kcfg=cfg, coarse=coarse, verbose=verbose)
         if tuple(frame_dev.shape) == tuple(img.shape):

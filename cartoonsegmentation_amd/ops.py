@@ -412,6 +412,18 @@ def _percentile_linear(sorted_vals, q):
 _TAIL_SCRATCH = {}
 
 
+def image_tensor(img_hwc_u8):
+    """uint8 HxWx3 device image -> float32 [1,3,H,W] in [0,1] (`img.permute(2, 0, 1)[None].float() * (1.0 / 255.0)`), one kernel"""
+    img = img_hwc_u8
+    if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.uint8 and img.dim() == 3 and img.shape[2] == 3):
+        raise _lib.CsmError("image_tensor: a uint8 HxWx3 device tensor is required; libcsm355 has no CPU path")
+    img = img.contiguous()
+    H, W = int(img.shape[0]), int(img.shape[1])
+    out = torch.empty((1, 3, H, W), dtype=torch.float32, device=img.device)
+    check(_lib.load().csm_u8_hwc_to_f32_chw(ptr(img), i32(H), i32(W), ptr(out), stream_ptr()), "u8_hwc_to_f32_chw")
+    return out
+
+
 def ctypes_ptr(t, offset_elems):
     """device pointer `offset_elems` elements into tensor t"""
     import ctypes

@@ -394,6 +394,8 @@ int csm_depth_range_stats(const float *minmax_raw_dev, float scale, const float 
 int csm_depth_adjust_instance(float *disp, const uint8_t *mask, int H, int W, float *scratch, void *stream);
 /* kenburns_effect.py:572-575: cv2.resize(u8 depth, (W,H), INTER_AREA) (enlarging) -> float32 */
 int csm_resize_u8_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream);
+/* uint8 [H,W,3] -> float32 [3,H,W] * (1/255): the image tensor of kenburns_effect.py:878-880 (`permute(2,0,1)[None].float() * (1.0 / 255.0)`) */
+int csm_u8_hwc_to_f32_chw(const uint8_t *src_hwc, int H, int W, float *out_chw, void *stream);
 /* the same line when the 32-aligned LeReS map is larger than the frame (k > 1): cv2.resize(..., INTER_LANCZOS4) -> float32 */
 int csm_resize_u8_lanczos4_to_f32(const uint8_t *src, int h, int w, int H, int W, float *out, void *stream);
 /* kenburns_effect.py:1069-1070: cv2.getRectSubPix(frame,(patch_w,patch_h),center) + cv2.resize(INTER_LINEAR) to (W,H) */
