@@ -56,14 +56,14 @@ _RENDER_SCRATCH = {}
 
 def _render_tile_scratch(dev, H, W, N):
     """scratch of the tiled render_pointcloud, one per (device, stream, frame size), grown with the cloud; header zeroed once"""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream, H, W)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)            # one set per stream: another frame size replaces it
     have = _RENDER_SCRATCH.get(key)
-    if have is None or have[1] < N:
+    if have is None or have[1] < N or have[2] != (H, W):
         L = _lib.load()
         cap = int(N * 1.25) + 1024
         buf = torch.empty((L.csm_warp_tile_scratch_bytes(i32(H), i32(W), i64(cap)) + 3) // 4, dtype=torch.float32, device=dev)
         buf[:(L.csm_warp_tile_header_bytes(i32(H), i32(W)) + 3) // 4].zero_()
-        _RENDER_SCRATCH[key] = have = (buf, cap)
+        _RENDER_SCRATCH[key] = have = (buf, cap, (H, W))
     return have[0]
 
 
