@@ -961,8 +961,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
 // one chunk of MFMAs (1.7 us at four 128x32 blocks per CU) to hide every HBM miss behind.  Here a block walks several tiles and the
 // sequence of (tile, channel block) patches is double-buffered ACROSS tiles: at the first tap of a tile's last channel block the
 // loader switches to the next tile and sends its first patch -- nine taps of MFMAs ahead of its use; the weights of the next tile's
-// first tap go out behind the barrier of the last tap.  Same chunks, same chain per output.  ksplit == 1 only.
-template <int WM, int WN, int TM, int TN, int TW>
+// first tap go out behind the barrier of the last tap.  Same chunks, same chain per output.  SER: the serial split-K walk of k_conv_patch
+// (runs combined in registers at the run boundaries); parallel split-K layers keep the one-tile-per-block kernel.
+template <int WM, int WN, int TM, int TN, int TW, bool SER = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, int tiles_x, int tiles_y, int n_n, int total) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
@@ -1050,6 +1051,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
     for (int kb = 0; kb < 4; ++kb) swb[kb] = ((2 * kb + lh) ^ ((li >> 1) & 7)) * 4;
     const int rowB = (32 * TN * wn + li) * 32;
     f32x16 acc[TM][TN];
+    f32x16 tot[SER ? TM : 1][SER ? TN : 1];
+    int run = 0, next_b = 0;                                    // SER: first chunk of the next run (reset per tile)
     auto compute = [&](int pstage, int tap, int bstage) {
         const float *SP = lds + pstage * kPatchF;
         const float *SB = lds + 2 * kPatchF + bstage * kBF;
@@ -1097,6 +1100,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) acc[i][j][rr] = b;
         }
+        if constexpr (SER) { run = 0; next_b = (int)((int64_t)Tall / a.ksplit); }
         for (int cb = 0; cb < ncb; ++cb, ps ^= 1) {
             const bool last_cb = cb + 1 == ncb;
             // The next patch of the sequence -- block cb + 1 of this tile or (last block) block 0 of the NEXT tile, for which the loader
@@ -1118,6 +1122,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
 #pragma unroll
                     for (int qq = tap * kPPT; qq < (tap + 1) * kPPT && qq < QP; ++qq)
                         dma16(offP[qq] == kOob ? kOob : offP[qq] + cbo, ra, sb + (unsigned)(wave + qq * NW) * 1024u);
+                }
+                if constexpr (SER) {
+                    if (9 * cb + tap == next_b) {                                  // block-uniform: S - 1 times per tile
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                                for (int rr = 0; rr < 16; ++rr) { tot[i][j][rr] = run == 0 ? acc[i][j][rr] : tot[i][j][rr] + acc[i][j][rr]; acc[i][j][rr] = 0.0f; }
+                        ++run; next_b = (int)(((int64_t)(run + 1) * Tall) / a.ksplit);
+                    }
                 }
                 compute(ps, tap, st);
                 st ^= 1;
@@ -1146,6 +1161,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
                     const int nn = ncol[j];
                     if (nn >= a.cout_g) continue;
                     float v = acc[i][j][rr];
+                    if constexpr (SER) v = tot[i][j][rr] + v;
                     if (a.res_mode == 1) v += a.res.p[m * a.res.ld + cout_off + nn];
                     v = apply_act(v, a.act, slope[j]);
                     if (a.res_mode == 2) v += a.res.p[m * a.res.ld + cout_off + nn];
@@ -1896,9 +1912,8 @@ int launch_conv_patch(const ConvArgs &a, hipStream_t st) {
     return launch_conv_patch_t<WM, WN, TM, TN, TW, false>(a, st);
 }
 
-template <int WM, int WN, int TM, int TN, int TW>
-int launch_conv_patch_p(const ConvArgs &a0, hipStream_t st) {
-    if (a0.ksplit > 1) return launch_conv_patch<WM, WN, TM, TN, TW>(a0, st);
+template <int WM, int WN, int TM, int TN, int TW, bool SER>
+int launch_conv_patch_p_t(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
     constexpr int NW = WM * WN, NPP = ((((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW) * NW;
     ConvArgs a = a0;
@@ -1908,9 +1923,9 @@ int launch_conv_patch_p(const ConvArgs &a0, hipStream_t st) {
     static unsigned prepared = 0;
     static int blocks_per_cu = 1;
     if (first_use_on_device(prepared)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch_p<WM, WN, TM, TN, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch_p<WM, WN, TM, TN, TW, SER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_patch_p<WM, WN, TM, TN, TW>), 64 * WM * WN, lds) == hipSuccess && nb > 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_patch_p<WM, WN, TM, TN, TW, SER>), 64 * WM * WN, lds) == hipSuccess && nb > 0)
             blocks_per_cu = nb;
     }
     const int n_n = (a.cout_g + BN - 1) / BN;
@@ -1918,8 +1933,16 @@ int launch_conv_patch_p(const ConvArgs &a0, hipStream_t st) {
     if (total >= (1ll << 30)) return launch_conv_patch<WM, WN, TM, TN, TW>(a0, st);
     int64_t grid = 256ll * blocks_per_cu;
     if (grid > ((total + 7) & ~7ll)) grid = (total + 7) & ~7ll;
-    k_conv_patch_p<WM, WN, TM, TN, TW><<<(unsigned)grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y, n_n, (int)total);
+    k_conv_patch_p<WM, WN, TM, TN, TW, SER><<<(unsigned)grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y, n_n, (int)total);
     return csm::check_launch("k_conv_patch_p");
+}
+template <int WM, int WN, int TM, int TN, int TW>
+int launch_conv_patch_p(const ConvArgs &a, hipStream_t st) {
+    if (a.ksplit > 1) {
+        if (a.serial && a.groups == 1) return launch_conv_patch_p_t<WM, WN, TM, TN, TW, true>(a, st);
+        return launch_conv_patch<WM, WN, TM, TN, TW>(a, st);                   // parallel split-K: one tile per block + reduce
+    }
+    return launch_conv_patch_p_t<WM, WN, TM, TN, TW, false>(a, st);
 }
 
 static bool narrow_eligible(const ConvArgs &a) {
@@ -2302,7 +2325,7 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         for (size_t c = 0; c < sizeof(cand_all) / sizeof(int); ++c) {
             if (cand_bn[c] >= 2 * npad && cand_bn[c] > 32) continue;      // tile much wider than the output: never wins
             if (cand_all[c] >= CFG_Q64x64) {                                     // persistent blocks: layers that do not split K
-                if (op.ksplit > 1) continue;
+                if (op.ksplit > 1 && cand_all[c] < CFG_R128x32) continue;         // k_conv_dma_p: ksplit == 1 only
                 if (cand_all[c] >= CFG_R128x32 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
             }
             else if (cand_all[c] >= CFG_P64x64 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
@@ -2310,6 +2333,7 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
             if (cand_bn[c] == 32 && op.cout_g > 64 && (op.cout_g % 64) != 32) continue;   // (96, 160 ... outputs: 32-wide tiles waste no MFMA columns)
             for (int ser = 0; ser <= (op.ksplit > 1 ? 1 : 0) && rc == CSM_OK; ++ser) {     // split-K layers: both executions
+                if (cand_all[c] >= CFG_R128x32 && op.ksplit > 1 && !ser) continue;             // (the persistent kernel walks split K serially only)
                 const bool dfam = cand_all[c] >= CFG_D64x64 && cand_all[c] <= CFG_D192x128 && cand_all[c] != CFG_NARROW && cand_all[c] != CFG_D64x64;
                 for (int sp = 0; sp <= ((dfam && g_tune_split && (op.ksplit <= 1 || ser)) ? 1 : 0) && rc == CSM_OK; ++sp) {   // mixed-tile launch
                     op.tile = cand_all[c] + 1 + (ser ? kTileSerial : 0) + (sp ? kTileSplit : 0);
