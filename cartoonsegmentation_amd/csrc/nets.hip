@@ -590,8 +590,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 // the grid is one round of resident blocks; a block takes tiles i, i + stride, ... of its XCD's run (the same XCD-aware order), and
 // behind the barrier of a tile's LAST chunk it sets the loader up for the NEXT tile and sends that tile's chunk 0 into the free stage:
 // the round trip runs under the last chunk's MFMAs and the epilogue's stores.  Same chunks, same chain per output: the bits of every
-// other tile configuration.  ksplit == 1 only (short-K layers do not split).
-template <int WM, int WN, int TM, int TN>
+// other tile configuration.  SER: the serial split-K walk of k_conv_dma (runs combined in registers at the run boundaries).
+template <int WM, int WN, int TM, int TN, bool SER = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n /* N tiles per group */, int total /* tiles */) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -681,6 +681,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n
     for (int kb = 0; kb < 4; ++kb) sw[kb] = ((2 * kb + lh) ^ ((li >> 1) & 7)) * 4;
     const int rowA = (32 * TM * wm + li) * 32, rowB = (BM + 32 * TN * wn + li) * 32;
     f32x16 acc[TM][TN];
+    f32x16 tot[SER ? TM : 1][SER ? TN : 1];
+    int run = 0, next_b = 0;                                    // SER: first chunk of the next run (reset per tile)
+    auto run_boundary = [&](int chunk) {                        // block-uniform: S - 1 times per tile
+        if constexpr (SER) {
+            if (chunk == next_b) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) { tot[i][j][rr] = run == 0 ? acc[i][j][rr] : tot[i][j][rr] + acc[i][j][rr]; acc[i][j][rr] = 0.0f; }
+                ++run; next_b = (int)(((int64_t)(run + 1) * Tall) / a.ksplit);
+            }
+        }
+    };
     auto compute = [&](int stage) {
         const float *S = lds + stage * kStageF;
 #pragma unroll
@@ -720,10 +735,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) acc[i][jj][rr] = b;
         }
+        if constexpr (SER) { run = 0; next_b = (int)((int64_t)Tall / a.ksplit); }
         for (int chunk = 0; chunk + 1 < Tall; ++chunk, st ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             issue(st ^ 1);
+            run_boundary(chunk);
             compute(st);
         }
         // the tile's last chunk: the NEXT tile's chunk 0 goes out behind the barrier (branch-free: past the end every lane is out
@@ -736,6 +753,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n
             loader_setup(more ? kn : k, more);
             issue(st ^ 1);
         }
+        run_boundary(Tall - 1);
         compute(st);
         st ^= 1;
         // epilogue: lane holds column li of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*lh
@@ -751,6 +769,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n
                     int m = m0 + 32 * (TM * wm + i) + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
                     if (m >= a.M) continue;
                     float v = acc[i][jj][rr];
+                    if constexpr (SER) v = tot[i][jj][rr] + v;
                     if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
                     v = apply_act(v, a.act, slope);
                     if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
@@ -1863,18 +1882,17 @@ int launch_conv_dma(const ConvArgs &a, hipStream_t st) {
 
 // persistent launch: one round of resident blocks (a multiple of 8, at most one block per tile); layers that split K take the
 // one-tile-per-block kernel of the same shape
-template <int WM, int WN, int TM, int TN>
-int launch_conv_dma_p(const ConvArgs &a0, hipStream_t st) {
-    if (a0.ksplit > 1 || a0.m_begin != 0) return launch_conv_dma<WM, WN, TM, TN>(a0, st);
+template <int WM, int WN, int TM, int TN, bool SER>
+int launch_conv_dma_p_t(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgs a = a0;
     const size_t lds = (size_t)2 * (BM + BN) * 128;
     static unsigned prepared = 0;
     static int blocks_per_cu = 1;
     if (first_use_on_device(prepared)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma_p<WM, WN, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma_p<WM, WN, TM, TN, SER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_dma_p<WM, WN, TM, TN>), 64 * WM * WN, lds) == hipSuccess && nb > 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_dma_p<WM, WN, TM, TN, SER>), 64 * WM * WN, lds) == hipSuccess && nb > 0)
             blocks_per_cu = nb;
     }
     a.m_tiles = (a.M + BM - 1) / BM;
@@ -1883,8 +1901,17 @@ int launch_conv_dma_p(const ConvArgs &a0, hipStream_t st) {
     if (total >= (1ll << 30)) return launch_conv_dma<WM, WN, TM, TN>(a0, st);
     int64_t grid = 256ll * blocks_per_cu;
     if (grid > ((total + 7) & ~7ll)) grid = (total + 7) & ~7ll;
-    k_conv_dma_p<WM, WN, TM, TN><<<(unsigned)grid, 64 * WM * WN, lds, st>>>(a, n_n, (int)total);
+    k_conv_dma_p<WM, WN, TM, TN, SER><<<(unsigned)grid, 64 * WM * WN, lds, st>>>(a, n_n, (int)total);
     return csm::check_launch("k_conv_dma_p");
+}
+template <int WM, int WN, int TM, int TN>
+int launch_conv_dma_p(const ConvArgs &a, hipStream_t st) {
+    if (a.m_begin != 0) return launch_conv_dma<WM, WN, TM, TN>(a, st);
+    if (a.ksplit > 1) {
+        if (a.serial && a.groups == 1) return launch_conv_dma_p_t<WM, WN, TM, TN, true>(a, st);
+        return launch_conv_dma<WM, WN, TM, TN>(a, st);                          // parallel split-K: one tile per block + reduce
+    }
+    return launch_conv_dma_p_t<WM, WN, TM, TN, false>(a, st);
 }
 
 template <int WM, int WN, int TM, int TN, int TW, bool SER>
@@ -2325,7 +2352,6 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
         for (size_t c = 0; c < sizeof(cand_all) / sizeof(int); ++c) {
             if (cand_bn[c] >= 2 * npad && cand_bn[c] > 32) continue;      // tile much wider than the output: never wins
             if (cand_all[c] >= CFG_Q64x64) {                                     // persistent blocks: layers that do not split K
-                if (op.ksplit > 1 && cand_all[c] < CFG_R128x32) continue;         // k_conv_dma_p: ksplit == 1 only
                 if (cand_all[c] >= CFG_R128x32 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
             }
             else if (cand_all[c] >= CFG_P64x64 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
@@ -2333,7 +2359,7 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
             if (cand_bn[c] == 32 && op.cout_g > 64 && (op.cout_g % 64) != 32) continue;   // (96, 160 ... outputs: 32-wide tiles waste no MFMA columns)
             for (int ser = 0; ser <= (op.ksplit > 1 ? 1 : 0) && rc == CSM_OK; ++ser) {     // split-K layers: both executions
-                if (cand_all[c] >= CFG_R128x32 && op.ksplit > 1 && !ser) continue;             // (the persistent kernel walks split K serially only)
+                if (cand_all[c] >= CFG_Q64x64 && op.ksplit > 1 && !ser) continue;              // (the persistent kernels walk split K serially only)
                 const bool dfam = cand_all[c] >= CFG_D64x64 && cand_all[c] <= CFG_D192x128 && cand_all[c] != CFG_NARROW && cand_all[c] != CFG_D64x64;
                 for (int sp = 0; sp <= ((dfam && g_tune_split && (op.ksplit <= 1 || ser)) ? 1 : 0) && rc == CSM_OK; ++sp) {   // mixed-tile launch
                     op.tile = cand_all[c] + 1 + (ser ? kTileSerial : 0) + (sp ? kTileSplit : 0);
