@@ -167,6 +167,21 @@ def test_torch_cpu_interpreter_agrees_with_the_c_oracle():
         assert rel_err(vb[t], va[t]) < 1e-4
 
 
+def test_gridnet_with_fused_upsample_prelu_in_both_interpreters():
+    """the Inpaint GridNet (Upsample + PReLU lowered to ONE bilinear op with an activation, residual epilogues, stand-alone PReLUs)
+    through the C oracle and through the torch-CPU interpreter -- two independent executions of the same program"""
+    from cartoonsegmentation_amd.nets.inpaint import build_inpaint_grid
+    from oracle import nets_torch
+    rng = np.random.default_rng(8)
+    p = build_inpaint_grid(SynthWeights('inpaint.'), 32, 48)
+    assert any(o['kind'] == 4 and o['act'] for o in p.ops), "the Upsample blocks are expected to carry their PReLU in the bilinear op"
+    x = rng.normal(0, 1, (1, 69, 32, 48)).astype(np.float32)
+    ia, da = np.zeros((1, 3, 32, 48), np.float32), np.zeros((1, 1, 32, 48), np.float32)
+    ib, db = np.zeros_like(ia), np.zeros_like(da)
+    onets.run_program(p, [x, ia, da]); nets_torch.run_program(p, [x, ib, db])
+    assert np.abs(ia).max() > 0 and rel_err(ib, ia) < 1e-4 and rel_err(db, da) < 1e-4
+
+
 def test_zoe_infer_chain_on_the_oracle_matches_the_reference_fixture():
     """CPU statement of `depth_est: 'zoe'` around the stand-in core (tests/golden/zoe_stub_core.py): reflect padding + flip +
     PrepForMidas in torch, the metric-bins head through the oracle interpreter, bicubic resize back + crop + flip average -- against
