@@ -1129,6 +1129,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
             // lane is out of range and the DMA writes zeros into a stage nobody reads.
             auto chunk = [&](auto TAPC) {
                 constexpr int tap = decltype(TAPC)::value;
+                // The nine taps are straight-line code: hipcc moves the barrier of tap t + 1 up between the last LDS reads of tap t and
+                // the MFMAs that consume them, so a wave could pass the barrier with fragment reads still in flight while the next
+                // DMA into that stage is issued behind it (a few wrong values in 10^7, seen once in the 8-wide 64 x 64 tile).  The
+                // fragment reads of the previous tap must have COMPLETED before this wave arrives at the barrier:
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if constexpr (tap >= 1 && tap <= kPT) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPPT) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -2083,8 +2088,8 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_R128x32_w8: return launch_conv_patch_p<4, 1, 1, 1, 16>(a, st);     // (the 8-wide persistent tiles were dropped, see CFG_R64x64_w8)
         case CFG_R128x128_8w: return launch_conv_patch_p<2, 4, 2, 1, 16>(a, st);
         case CFG_R64x128: return launch_conv_patch_p<2, 2, 1, 2, 16>(a, st);
-        // 8-wide 64 x 64 persistent tiles with serial split-K produced a few dozen wrong values per 13 M in repeated runs (a race that
-        // no other configuration shows and that vmcnt(0) at every tap does not remove; tools/check_persistent.py): not shipped
+        // (the 8-wide persistent tiles: where the LDS-read / barrier hazard of the unrolled taps showed; found by tools/check_persistent.py,
+        // fixed in k_conv_patch_p, the variants themselves stay out)
         case CFG_R64x64_w8: return launch_conv_patch_p<2, 2, 1, 1, 16>(a, st);
         default: return launch_conv<32, 2, 2, 1>(a, st);
     }
