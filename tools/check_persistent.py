@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """every distinct conv layer of a net (RTMDet n=8 by default; argv: rtmdet|leres|isnet [batch]) as a one-op program: the persistent tile
-configurations (38..49, serial split-K forced) against configuration 6 with parallel split-K, bit for bit"""
+configurations (38..49, serial split-K forced) against configuration 6 with parallel split-K, bit for bit.
+REPS=<n> repeats every configuration n times (rare races), ONLY3x3=1 keeps the stride-1 3x3 layers on maps of 40 px and more"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CSM_AUTOTUNE"] = "0"
