@@ -9,7 +9,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsm355.so")
+# CSM_LIB=<path> loads another build of the same library (development: A/B of two kernel builds; never a fallback -- a missing
+# file still raises)
+LIB_PATH = os.environ.get("CSM_LIB") or os.path.join(_HERE, "libcsm355.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "csm355.h")
 _lib = None
 

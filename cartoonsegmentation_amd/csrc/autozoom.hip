@@ -564,9 +564,9 @@ extern "C" int csm_autozoom_coverage_bands(const float *pts, int64_t N, int H, i
     std::vector<int> order(K);
     for (int i = 0; i < K; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return shifts_xy[2 * a + 1] < shifts_xy[2 * b + 1]; });
-    static bool attr_set = false;
     const size_t lds = (size_t)(2 * bg.br + 2) * W * 4 + (size_t)bg.ncache * 16;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_band_cover), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds); attr_set = true; }
+    // per device and per call (a search is one call: the microsecond does not matter, and no cross-thread / cross-device state is kept)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_band_cover), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds);
     int i = 0, batch = 0;
     while (i < K) {
         if (batch >= 64) return csm::fail_arg("autozoom band path: more than 64 launch batches (K too large): use csm_autozoom_coverage");

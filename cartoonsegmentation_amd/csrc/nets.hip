@@ -26,6 +26,11 @@
 #include <mutex>
 #include <vector>
 #include <algorithm>
+#include <utility>
+
+#ifndef CSM_ILV
+#define CSM_ILV 1        // persistent conv kernels: DMA pieces interleaved with the MFMA groups (0 = burst behind the barrier; A/B builds)
+#endif
 
 namespace {
 
@@ -87,14 +92,31 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     }
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember which devices a kernel has been prepared on
-static inline bool first_use_on_device(unsigned &mask) {
-    int d = 0;
-    (void)hipGetDevice(&d);
-    const unsigned bit = 1u << (d & 31);
-    if (mask & bit) return false;
-    mask |= bit;
-    return true;
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the occupancy query are per DEVICE, and FrameLanes drives run_ops from several host
+// threads: the check, the preparation and its publication happen under one mutex, so a launch can never see "prepared" before the
+// attribute has been set (a > 64 KB dynamic-LDS launch would fail), and the blocks-per-CU figure is kept per device.
+struct KernelPrep {
+    std::mutex m;
+    unsigned done = 0;                 // bit d: prepared on device d
+    int blocks_per_cu[32] = {};
+    template <class F> int ensure(F &&prepare /* () -> resident blocks per CU (<= 0: unknown) */) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        d &= 31;
+        std::lock_guard<std::mutex> lk(m);
+        if (!(done & (1u << d))) {
+            const int nb = prepare();
+            blocks_per_cu[d] = nb > 0 ? nb : 1;
+            done |= 1u << d;
+        }
+        return blocks_per_cu[d];
+    }
+};
+template <class K> static int prepare_kernel(K kernel, int threads, size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), threads, lds) != hipSuccess) nb = 0;
+    return nb;
 }
 
 struct View {           // NHWC view
@@ -401,7 +423,7 @@ __device__ __forceinline__ void dma16(unsigned voff, i32x4 rsrc, unsigned lds_by
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_byte_addr) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int NS, bool SER = false>
+template <int WM, int WN, int TM, int TN, int NS, bool SER = false, bool ILV = (CSM_ILV != 0)>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     static_assert(!SER || NS == 2, "the serial split-K walk is built for the two-stage pipeline");
     constexpr int NW = WM * WN;
@@ -472,18 +494,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     int l_cb = c_begin / ntaps, l_tap = c_begin - l_cb * ntaps;
     int l_kh = l_tap / a.kw, l_kw = l_tap - l_kh * a.kw;
     unsigned l_w = (unsigned)(((int64_t)g * Tall + c_begin) * a.npad * 128);     // byte offset of the chunk's weight tile
-    auto issue = [&](int stage) {
-        const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
+    // one DMA piece of the loader's current chunk (pieces 0 .. GA-1: activations, GA .. GA+GB-1: weights); !live: every lane out of range
+    auto piece = [&](auto PC, int stage, bool live) {
+        constexpr int p = decltype(PC)::value;
         const unsigned sb = (unsigned)stage * (unsigned)(kStageF * 4);
-#pragma unroll
-        for (int p = 0; p < GA; ++p)
-            dma16(((vmA[p] >> l_tap) & 1u) ? offA[p] + coff : kOob, ra, ldsA + sb + (unsigned)p * 1024u);
-#pragma unroll
-        for (int p = 0; p < GB; ++p)
-            dma16(offB[p] == kOob ? kOob : offB[p] + l_w, rb, ldsB + sb + (unsigned)p * 1024u);
+        if constexpr (p < GA) {
+            const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
+            dma16((live && ((vmA[p] >> l_tap) & 1u)) ? offA[p] + coff : kOob, ra, ldsA + sb + (unsigned)p * 1024u);
+        } else
+            dma16((!live || offB[p - GA] == kOob) ? kOob : offB[p - GA] + l_w, rb, ldsB + sb + (unsigned)(p - GA) * 1024u);
+    };
+    auto advance = [&]() {
         l_w += (unsigned)a.npad * 128u;
         ++l_tap;
         if (++l_kw == a.kw) { l_kw = 0; if (++l_kh == a.kh) { l_kh = 0; l_tap = 0; ++l_cb; } }
+    };
+    auto issue = [&](int stage) {
+        [&]<int... P>(std::integer_sequence<int, P...>) { (piece(std::integral_constant<int, P>{}, stage, true), ...); }(std::make_integer_sequence<int, GA + GB>{});
+        advance();
     };
 
     f32x16 acc[TM][TN];
@@ -536,10 +564,61 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         }
     };
 
-    if constexpr (NS == 2) {
+    // ILV (two-stage pipeline): the DMA pieces of the next chunk go out BETWEEN the MFMA groups of this one instead of in a burst behind
+    // the barrier (see k_conv_dma_p); branch-free -- behind the last chunk the lanes are out of range and the DMA writes zeros into the
+    // stage nobody reads any more
+    auto compute_ilv = [&](int stage, int chunk, bool live) {
+        if constexpr (SER) {
+            if (chunk == next_b) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { tot[i][j][r] = run == 0 ? acc[i][j][r] : tot[i][j][r] + acc[i][j][r]; acc[i][j][r] = 0.0f; }
+                ++run; next_b = (int)(((int64_t)(run + 1) * Tall) / a.ksplit);
+            }
+        }
+        const float *S = lds + stage * kStageF;
+        float4 af[2][TM], bf[2][TN];
+        auto rd = [&](int kb, int buf) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[buf][i] = *reinterpret_cast<const float4 *>(S + rowA + i * 1024 + sw[kb]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[buf][j] = *reinterpret_cast<const float4 *>(S + rowB + j * 1024 + sw[kb]);
+        };
+        rd(0, 0);
+        [&]<int... G>(std::integer_sequence<int, G...>) {
+            ([&] {
+                constexpr int kb = G / 4, t = G % 4, buf = kb & 1;
+                if constexpr (G < GA + GB) { piece(std::integral_constant<int, G>{}, stage ^ 1, live); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (t == 1 && kb < 3) { rd(kb + 1, buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = t == 0 ? af[buf][i].x : (t == 1 ? af[buf][i].y : (t == 2 ? af[buf][i].z : af[buf][i].w));
+                        const float bv = t == 0 ? bf[buf][j].x : (t == 1 ? bf[buf][j].y : (t == 2 ? bf[buf][j].z : bf[buf][j].w));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, 16>{});
+        advance();
+    };
+
+    if constexpr (NS == 2 && ILV && GA + GB <= 16) {
         issue(0);
         for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of `chunk` have landed ...
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            compute_ilv(st, chunk, chunk + 1 < T);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetch must land before the block's LDS is released
+    } else if constexpr (NS == 2) {
+        issue(0);
+        for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of `chunk` have landed, its fragment reads of stage st^1 have completed ...
             __builtin_amdgcn_s_barrier();                          // ... everybody's have, and everybody is done reading stage st^1
             if (chunk + 1 < T) issue(st ^ 1);
             compute(st, chunk);
@@ -553,6 +632,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st = (st + 1 == NS ? 0 : st + 1)) {
             if (chunk + NS - 2 < T) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * (GA + GB)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (in the barrier's own block: tools/check_isa_barriers.py)
             __builtin_amdgcn_s_barrier();                          // everybody is done reading the stage refilled next
             if (chunk + NS - 1 < T) issue(st == 0 ? NS - 1 : st - 1);
             compute(st, chunk);
@@ -591,7 +671,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
 // behind the barrier of a tile's LAST chunk it sets the loader up for the NEXT tile and sends that tile's chunk 0 into the free stage:
 // the round trip runs under the last chunk's MFMAs and the epilogue's stores.  Same chunks, same chain per output: the bits of every
 // other tile configuration.  SER: the serial split-K walk of k_conv_dma (runs combined in registers at the run boundaries).
-template <int WM, int WN, int TM, int TN, bool SER = false>
+template <int WM, int WN, int TM, int TN, bool SER = false, bool ILV = (CSM_ILV != 0)>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n /* N tiles per group */, int total /* tiles */) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -662,18 +742,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n
         l_cb = 0; l_tap = 0; l_kh = 0; l_kw = 0;
         l_w = (unsigned)((int64_t)g * Tall * a.npad * 128);
     };
-    auto issue = [&](int stage) {
-        const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
+    // one DMA piece of the loader's current chunk (pieces 0 .. GA-1: activations, GA .. GA+GB-1: weights), then the step to the next chunk
+    auto piece = [&](auto PC, int stage) {
+        constexpr int p = decltype(PC)::value;
         const unsigned sb = (unsigned)stage * (unsigned)(kStageF * 4);
-#pragma unroll
-        for (int p = 0; p < GA; ++p)
+        if constexpr (p < GA) {
+            const unsigned coff = (unsigned)(((l_kh * a.dil * a.in.w + l_kw * a.dil) * a.in.ld + l_cb * 32) * 4);
             dma16(((vmA[p] >> l_tap) & 1u) ? offA[p] + coff : kOob, ra, ldsA + sb + (unsigned)p * 1024u);
-#pragma unroll
-        for (int p = 0; p < GB; ++p)
-            dma16(offB[p] == kOob ? kOob : offB[p] + l_w, rb, ldsB + sb + (unsigned)p * 1024u);
+        } else
+            dma16(offB[p - GA] == kOob ? kOob : offB[p - GA] + l_w, rb, ldsB + sb + (unsigned)(p - GA) * 1024u);
+    };
+    auto advance = [&]() {
         l_w += (unsigned)a.npad * 128u;
         ++l_tap;
         if (++l_kw == a.kw) { l_kw = 0; if (++l_kh == a.kh) { l_kh = 0; l_tap = 0; ++l_cb; } }
+    };
+    auto issue = [&](int stage) {
+        [&]<int... P>(std::integer_sequence<int, P...>) { (piece(std::integral_constant<int, P>{}, stage), ...); }(std::make_integer_sequence<int, GA + GB>{});
+        advance();
     };
 
     int sw[4];
@@ -683,6 +769,40 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n
     f32x16 acc[TM][TN];
     f32x16 tot[SER ? TM : 1][SER ? TN : 1];
     int run = 0, next_b = 0;                                    // SER: first chunk of the next run (reset per tile)
+    // ILV: the chunk's MFMAs with the DMA pieces of the NEXT chunk spread between them -- piece g goes out behind MFMA group g (a group =
+    // one k step of all TM x TN accumulators), so the pieces leave in the first half of the chunk and the matrix pipe never waits for a
+    // burst of GA + GB address computations and DMA issues behind the barrier (each costs the wave 60-180 cycles of issue time, which an
+    // MFMA in flight covers).  The fragments of k-block kb + 1 are requested behind the second group of kb.  The order is pinned with
+    // sched_barrier: hipcc otherwise regroups the asm statements in front of the MFMAs.
+    auto compute_ilv = [&](int stage, int fill) {
+        const float *S = lds + stage * kStageF;
+        float4 af[2][TM], bf[2][TN];
+        auto rd = [&](int kb, int buf) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[buf][i] = *reinterpret_cast<const float4 *>(S + rowA + i * 1024 + sw[kb]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[buf][j] = *reinterpret_cast<const float4 *>(S + rowB + j * 1024 + sw[kb]);
+        };
+        rd(0, 0);
+        [&]<int... G>(std::integer_sequence<int, G...>) {
+            ([&] {
+                constexpr int kb = G / 4, t = G % 4, buf = kb & 1;
+                if constexpr (G < GA + GB) { piece(std::integral_constant<int, G>{}, fill); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (t == 1 && kb < 3) { rd(kb + 1, buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = t == 0 ? af[buf][i].x : (t == 1 ? af[buf][i].y : (t == 2 ? af[buf][i].z : af[buf][i].w));
+                        const float bv = t == 0 ? bf[buf][j].x : (t == 1 ? bf[buf][j].y : (t == 2 ? bf[buf][j].z : bf[buf][j].w));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, 16>{});
+        static_assert(GA + GB <= 16, "one DMA piece per MFMA group");
+        advance();
+    };
     auto run_boundary = [&](int chunk) {                        // block-uniform: S - 1 times per tile
         if constexpr (SER) {
             if (chunk == next_b) {
@@ -737,24 +857,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n
         }
         if constexpr (SER) { run = 0; next_b = (int)((int64_t)Tall / a.ksplit); }
         for (int chunk = 0; chunk + 1 < Tall; ++chunk, st ^= 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (lgkmcnt: this wave's fragment reads of the stage refilled next must have COMPLETED before it arrives -- hipcc may sink
+            // the last MFMAs of the previous chunk, and with them the wait for their operands, below the barrier)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            issue(st ^ 1);
-            run_boundary(chunk);
-            compute(st);
+            if constexpr (ILV) { run_boundary(chunk); compute_ilv(st, st ^ 1); }
+            else { issue(st ^ 1); run_boundary(chunk); compute(st); }
         }
         // the tile's last chunk: the NEXT tile's chunk 0 goes out behind the barrier (branch-free: past the end every lane is out
         // of range and the DMA writes zeros into a stage nobody reads)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         {
             const int kn = k + per;
             const bool more = kn < len;
             loader_setup(more ? kn : k, more);
-            issue(st ^ 1);
+            if constexpr (!ILV) issue(st ^ 1);
         }
         run_boundary(Tall - 1);
-        compute(st);
+        if constexpr (ILV) compute_ilv(st, st ^ 1); else compute(st);
         st ^= 1;
         // epilogue: lane holds column li of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*lh
 #pragma unroll
@@ -928,14 +1049,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
         const int tap_end = min(9, tap + (T - chunk));
         // first chunk of this channel block: the weights of the next chunk AND the next block's patch go out behind the barrier
         // (the weight fetch is unconditional: past the end of this K run it lands in a stage nobody reads)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (lgkmcnt: see k_conv_dma_p)
         __builtin_amdgcn_s_barrier();
         issue_b(st ^ 1);
         issue_patch(cb + 1, (cb + 1) * 9 < T);
         compute(cb, tap, st);
         ++chunk; st ^= 1;
         for (++tap; tap < tap_end; ++tap, ++chunk, st ^= 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             issue_b(st ^ 1);
             compute(cb, tap, st);
@@ -982,7 +1103,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
 // loader switches to the next tile and sends its first patch -- nine taps of MFMAs ahead of its use; the weights of the next tile's
 // first tap go out behind the barrier of the last tap.  Same chunks, same chain per output.  SER: the serial split-K walk of k_conv_patch
 // (runs combined in registers at the run boundaries); parallel split-K layers keep the one-tile-per-block kernel.
-template <int WM, int WN, int TM, int TN, int TW, bool SER = false>
+template <int WM, int WN, int TM, int TN, int TW, bool SER = false, bool ILV = (CSM_ILV != 0)>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, int tiles_x, int tiles_y, int n_n, int total) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
@@ -992,6 +1113,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
     constexpr int GB = BN / 8 / NW;
     static_assert(GB * 8 * NW == BN && TH * TW == BM && (TW == 16 || TW == 8), "tile shape");
     constexpr int kPPT = (QP + 7) / 8, kPT = (QP + kPPT - 1) / kPPT;      // patch pieces per tap / taps that carry a slice (<= 8)
+    // the counted wait `vmcnt(kPPT)` at the tap after a slice assumes that the slice had exactly kPPT pieces behind the weights: a shorter
+    // last slice would let a weight DMA be in flight at the barrier
+    static_assert(QP % kPPT == 0, "every patch slice must carry kPPT pieces (counted vmcnt)");
     constexpr int kPatchF = QP * NW * 8 * 32, kBF = BN * 32;
     constexpr unsigned kOob = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [patch 0][patch 1][B 0][B 1]
@@ -1139,13 +1263,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
                 __builtin_amdgcn_s_barrier();
                 if constexpr (tap == 0) { if (last_cb) patch_setup(more ? kn : k, more); }
                 if constexpr (tap == 8) { if (last_cb) b_setup(more ? kn : k, more); }      // the weights of the next tile's first tap
-                issue_b(st ^ 1);
-                if constexpr (tap < kPT) {
-                    const unsigned sb = lds0 + (unsigned)(ps ^ 1) * (unsigned)(kPatchF * 4);
-                    const unsigned cbo = (unsigned)(last_cb ? 0 : cb + 1) * 128u;
+                const unsigned psb = lds0 + (unsigned)(ps ^ 1) * (unsigned)(kPatchF * 4);
+                const unsigned cbo = (unsigned)(last_cb ? 0 : cb + 1) * 128u;
+                if constexpr (!ILV) {
+                    issue_b(st ^ 1);
+                    if constexpr (tap < kPT) {
 #pragma unroll
-                    for (int qq = tap * kPPT; qq < (tap + 1) * kPPT && qq < QP; ++qq)
-                        dma16(offP[qq] == kOob ? kOob : offP[qq] + cbo, ra, sb + (unsigned)(wave + qq * NW) * 1024u);
+                        for (int qq = tap * kPPT; qq < (tap + 1) * kPPT && qq < QP; ++qq)
+                            dma16(offP[qq] == kOob ? kOob : offP[qq] + cbo, ra, psb + (unsigned)(wave + qq * NW) * 1024u);
+                    }
                 }
                 if constexpr (SER) {
                     if (9 * cb + tap == next_b) {                                  // block-uniform: S - 1 times per tile
@@ -1158,7 +1284,51 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
                         ++run; next_b = (int)(((int64_t)(run + 1) * Tall) / a.ksplit);
                     }
                 }
-                compute(ps, tap, st);
+                if constexpr (!ILV) compute(ps, tap, st);
+                else {
+                    // the tap's MFMAs with this tap's DMA pieces between the groups (same order as the burst: the weights of the next tap
+                    // first, then the patch slice -- the counted vmcnt at the next barrier relies on it); see k_conv_dma_p
+                    constexpr int NSL = tap < kPT ? ((tap + 1) * kPPT <= QP ? kPPT : QP - tap * kPPT) : 0;
+                    static_assert(GB + kPPT <= 16, "one DMA piece per MFMA group");
+                    const float *SP = lds + ps * kPatchF;
+                    const float *SB = lds + 2 * kPatchF + st * kBF;
+                    constexpr int kh = tap / 3, toff = kh * PW + (tap - 3 * kh);
+                    int arow[TM], asw[TM];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) { int pp = ppb[i] + toff; arow[i] = pp * 32; asw[i] = (pp >> 1) & 7; }
+                    float4 af[2][TM], bf[2][TN];
+                    auto rd = [&](int kb, int buf) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) af[buf][i] = *reinterpret_cast<const float4 *>(SP + arow[i] + (((2 * kb + lh) ^ asw[i]) << 2));
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) bf[buf][j] = *reinterpret_cast<const float4 *>(SB + rowB + j * 1024 + swb[kb]);
+                    };
+                    rd(0, 0);
+                    [&]<int... G>(std::integer_sequence<int, G...>) {
+                        ([&] {
+                            constexpr int kb = G / 4, t = G % 4, buf = kb & 1;
+                            if constexpr (G < GB) {
+                                dma16(offB[G] == kOob ? kOob : offB[G] + l_w, rb, ldsB + (unsigned)(st ^ 1) * (unsigned)(kBF * 4) + (unsigned)G * 1024u);
+                                __builtin_amdgcn_sched_barrier(0);
+                            } else if constexpr (G < GB + NSL) {
+                                constexpr int qq = tap * kPPT + (G - GB);
+                                dma16(offP[qq] == kOob ? kOob : offP[qq] + cbo, ra, psb + (unsigned)(wave + qq * NW) * 1024u);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if constexpr (t == 1 && kb < 3) { rd(kb + 1, buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) {
+                                    const float av = t == 0 ? af[buf][i].x : (t == 1 ? af[buf][i].y : (t == 2 ? af[buf][i].z : af[buf][i].w));
+                                    const float bv = t == 0 ? bf[buf][j].x : (t == 1 ? bf[buf][j].y : (t == 2 ? bf[buf][j].z : bf[buf][j].w));
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                                }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }(), ...);
+                    }(std::make_integer_sequence<int, 16>{});
+                    l_w += (unsigned)a.npad * 128u;
+                }
                 st ^= 1;
             };
             chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{}); chunk(std::integral_constant<int, 2>{});
@@ -1386,9 +1556,8 @@ static size_t narrow_lds(const ConvArgs &a, int TH, int *rh_out, int *rw_out) {
 
 template <int NOUT, int TH>
 static int launch_narrow_t(const ConvArgs &a, size_t lds, int rh, int rw, hipStream_t st) {
-    static unsigned prepared = 0;
-    if (first_use_on_device(prepared))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_narrow<NOUT, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    static KernelPrep prep;
+    (void)prep.ensure([&] { return prepare_kernel(&k_conv_narrow<NOUT, TH>, 32 * TH, (size_t)150 * 1024); });
     int tiles_x = (a.out.w + 31) / 32, tiles_y = (a.out.h + TH - 1) / TH;
     k_conv_narrow<NOUT, TH><<<(unsigned)(tiles_x * tiles_y * a.out.n), 32 * TH, lds, st>>>(a, tiles_x, tiles_y, rh, rw);
     return csm::check_launch("k_conv_narrow");
@@ -1810,10 +1979,8 @@ int launch_conv_k(const ConvArgs &a0, hipStream_t st) {
     ConvArgs a = a0;
     a.m_tiles = (a.M + BM - 1) / BM;
     size_t lds = (size_t)2 * (BM + BN) * kLdsLd * sizeof(float);
-    static unsigned prepared = 0;
-    if (first_use_on_device(prepared))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_mfma<MT, WM, WN, TN, FULLK, SER>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static KernelPrep prep;
+    (void)prep.ensure([&] { return prepare_kernel(&k_conv_mfma<MT, WM, WN, TN, FULLK, SER>, 64 * WM * WN, lds); });
     dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * (SER ? 1 : a.ksplit));
     k_conv_mfma<MT, WM, WN, TN, FULLK, SER><<<grid, 64 * WM * WN, lds, st>>>(a);
     int rc = csm::check_launch("k_conv_mfma");
@@ -1850,15 +2017,8 @@ int launch_conv_dma_t(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgs a = a0;
     size_t lds = (size_t)NS * (BM + BN) * 128;
-    static unsigned prepared = 0;
-    static int blocks_per_cu = 0;
-    if (first_use_on_device(prepared)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma<WM, WN, TM, TN, NS, SER>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_dma<WM, WN, TM, TN, NS, SER>),
-                                                         64 * WM * WN, lds) == hipSuccess && nb > 0) blocks_per_cu = nb;
-    }
+    static KernelPrep prep;
+    const int blocks_per_cu = prep.ensure([&] { return prepare_kernel(&k_conv_dma<WM, WN, TM, TN, NS, SER>, 64 * WM * WN, lds); });
     if (a.split && (BM > 64 || BN > 64) && (a.ksplit <= 1 || SER)) {
         const int rows = conv_split_rows(a, BM, BN, blocks_per_cu);
         if (rows > 0) {
@@ -1892,14 +2052,8 @@ int launch_conv_dma_p_t(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgs a = a0;
     const size_t lds = (size_t)2 * (BM + BN) * 128;
-    static unsigned prepared = 0;
-    static int blocks_per_cu = 1;
-    if (first_use_on_device(prepared)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_dma_p<WM, WN, TM, TN, SER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_dma_p<WM, WN, TM, TN, SER>), 64 * WM * WN, lds) == hipSuccess && nb > 0)
-            blocks_per_cu = nb;
-    }
+    static KernelPrep prep;
+    const int blocks_per_cu = prep.ensure([&] { return prepare_kernel(&k_conv_dma_p<WM, WN, TM, TN, SER>, 64 * WM * WN, lds); });
     a.m_tiles = (a.M + BM - 1) / BM;
     const int n_n = (a.cout_g + BN - 1) / BN;
     const int64_t total = (int64_t)a.m_tiles * n_n * a.groups;
@@ -1927,10 +2081,8 @@ int launch_conv_patch_t(const ConvArgs &a0, hipStream_t st) {
     const int tiles_x = (a.out.w + TW - 1) / TW, tiles_y = (a.out.h + TH - 1) / TH;
     a.m_tiles = tiles_x * tiles_y * a.out.n;
     size_t lds = ((size_t)2 * NPP * 8 * 32 + (size_t)2 * BN * 32) * 4;
-    static unsigned prepared = 0;
-    if (first_use_on_device(prepared))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch<WM, WN, TM, TN, TW, SER>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static KernelPrep prep;
+    (void)prep.ensure([&] { return prepare_kernel(&k_conv_patch<WM, WN, TM, TN, TW, SER>, 64 * WM * WN, lds); });
     dim3 grid(a.m_tiles, (a.cout_g + BN - 1) / BN, a.groups * (SER ? 1 : a.ksplit));
     k_conv_patch<WM, WN, TM, TN, TW, SER><<<grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y);
     int rc = csm::check_launch("k_conv_patch");
@@ -1952,14 +2104,8 @@ int launch_conv_patch_p_t(const ConvArgs &a0, hipStream_t st) {
     const int tiles_x = (a.out.w + TW - 1) / TW, tiles_y = (a.out.h + TH - 1) / TH;
     a.m_tiles = tiles_x * tiles_y * a.out.n;
     const size_t lds = ((size_t)2 * NPP * 8 * 32 + (size_t)2 * BN * 32) * 4;
-    static unsigned prepared = 0;
-    static int blocks_per_cu = 1;
-    if (first_use_on_device(prepared)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch_p<WM, WN, TM, TN, TW, SER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_conv_patch_p<WM, WN, TM, TN, TW, SER>), 64 * WM * WN, lds) == hipSuccess && nb > 0)
-            blocks_per_cu = nb;
-    }
+    static KernelPrep prep;
+    const int blocks_per_cu = prep.ensure([&] { return prepare_kernel(&k_conv_patch_p<WM, WN, TM, TN, TW, SER>, 64 * WM * WN, lds); });
     const int n_n = (a.cout_g + BN - 1) / BN;
     const int64_t total = (int64_t)a.m_tiles * n_n * a.groups;
     if (total >= (1ll << 30)) return launch_conv_patch<WM, WN, TM, TN, TW>(a0, st);
@@ -2040,6 +2186,7 @@ static int choose_cfg(const ConvArgs &a, int N) {
 
 static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
     switch (cfg) {
+#ifndef CSM_PROBE          // (development: -DCSM_PROBE compiles the persistent kernels only, for a quick look at their ISA)
         case CFG_128x128_4w: return launch_conv<32, 4, 1, 4>(a, st);
         case CFG_128x64: return launch_conv<32, 4, 1, 2>(a, st);
         case CFG_128x128_8w: return launch_conv<32, 4, 2, 2>(a, st);
@@ -2077,6 +2224,7 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_D256x64_s3: return launch_conv_dma<4, 1, 2, 2, 3>(a, st);
         case CFG_P256x64: return launch_conv_patch<4, 1, 2, 2, 16>(a, st);
         case CFG_D64x64_s4: return launch_conv_dma<2, 2, 1, 1, 4>(a, st);
+#endif
         case CFG_Q64x64: return launch_conv_dma_p<2, 2, 1, 1>(a, st);
         case CFG_Q128x64: return launch_conv_dma_p<2, 2, 2, 1>(a, st);
         case CFG_Q64x128: return launch_conv_dma_p<2, 2, 1, 2>(a, st);

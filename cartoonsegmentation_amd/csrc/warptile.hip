@@ -197,6 +197,16 @@ __device__ __forceinline__ unsigned long long to_fixed(float prod, float scale) 
     if (q == 0) q = prod > 0.0f ? 1 : (prod < 0.0f ? -1 : 0);
     return (unsigned long long)q;
 }
+// the operator path accumulates ARBITRARY feature channels (Inpaint.forward's 64 context channels) at 2^-32 units: a product beyond
+// +-2^31 would overflow the conversion (undefined behaviour) -- saturate instead (+-2^62 units, i.e. |v w| <= 2^30 is exact to 2^-32;
+// NaN contributions count as the negative bound).  Supported range stated in INTEGRATION.md; ops.render_pointcloud(path='atomics')
+// keeps IEEE semantics for non-finite inputs.
+__device__ __forceinline__ unsigned long long to_fixed_sat(float prod, float scale) {
+    const float f = fminf(fmaxf(prod * scale, -4.611686018427387904e18f), 4.611686018427387904e18f);
+    long long q = (long long)f;
+    if (q == 0) q = prod > 0.0f ? 1 : (prod < 0.0f ? -1 : 0);
+    return (unsigned long long)q;
+}
 __device__ __forceinline__ float from_fixed(unsigned long long q, double inv_scale) { return (float)((double)(long long)q * inv_scale); }
 
 __global__ __launch_bounds__(kBlock) void k_tile_render(const Entry *__restrict__ entries, int cap,
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_render_c(const Entry *__restric
                 if (!(q.mask & (1u << k))) continue;
                 const float wk = q.w[k];
 #pragma unroll
-                for (int j = 0; j < kGroup; ++j) if (j < ng) atomicAdd(&acc[j * TPIX + q.li[k]], to_fixed(v[j] * wk, kScaleF));
+                for (int j = 0; j < kGroup; ++j) if (j < ng) atomicAdd(&acc[j * TPIX + q.li[k]], to_fixed_sat(v[j] * wk, kScaleF));
             }
         };
 #pragma unroll

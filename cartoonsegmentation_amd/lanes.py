@@ -33,42 +33,66 @@ class FrameLanes:
             self._threads.append(t)
         self._ready.wait()
 
+    @staticmethod
+    def _record(res, stream):
+        """results are allocated on the lane's stream and consumed on the caller's: tell the caching allocator, so that a block the
+        caller drops is not handed back to the lane while the caller's stream still has kernels reading it"""
+        if isinstance(res, torch.Tensor):
+            if res.is_cuda:
+                res.record_stream(stream)
+        elif isinstance(res, dict):
+            for v in res.values():
+                FrameLanes._record(v, stream)
+        elif isinstance(res, (list, tuple)):
+            for v in res:
+                FrameLanes._record(v, stream)
+
     def _run(self, i):
         torch.cuda.set_device(self.device)
         with torch.cuda.stream(self._streams[i]):
             try:
                 fn = self._make(i)
-            except BaseException as e:                     # surface construction errors on the first map()
+            except BaseException as e:                     # surfaced by every later map()
                 fn, self._err = None, e
             self._ready.wait()
             while True:
                 job = self._in[i].get()
                 if job is None:
                     return
-                idx, item = job
+                gen, idx, item, consumer = job
                 try:
+                    if fn is None:
+                        raise RuntimeError("lane %d failed to build its worker: %r" % (i, self._err))
                     res = fn(item)
                     self._streams[i].synchronize()         # the result is complete when it is handed over
-                    self._out.put((idx, res, None))
+                    self._record(res, consumer)
+                    self._out.put((gen, idx, res, None))
                 except BaseException as e:
-                    self._out.put((idx, None, e))
+                    self._out.put((gen, idx, None, e))
 
     def map(self, items):
-        """process items (frame k on lane k mod L); returns the results in input order"""
+        """process items (frame k on lane k mod L); returns the results in input order.  If an item raises, ALL results of the call
+        are collected first (nothing of this call is left in the queue for the next one) and the first error is re-raised."""
         if getattr(self, '_err', None) is not None:
             raise self._err
         items = list(items)
         cur = torch.cuda.current_stream(self.device)
         for s in self._streams:
             s.wait_stream(cur)                             # inputs produced on the caller's stream are visible to the lanes
+        self._gen = getattr(self, '_gen', 0) + 1
         for k, it in enumerate(items):
-            self._in[k % self.n].put((k, it))
-        out = [None] * len(items)
-        for _ in items:
-            idx, res, err = self._out.get()
-            if err is not None:
-                raise err
+            self._in[k % self.n].put((self._gen, k, it, cur))
+        out, first_err, got = [None] * len(items), None, 0
+        while got < len(items):
+            gen, idx, res, err = self._out.get()
+            if gen != self._gen:                           # a straggler of an earlier call (cannot happen after a complete drain; belt and braces)
+                continue
+            got += 1
+            if err is not None and first_err is None:
+                first_err = err
             out[idx] = res
+        if first_err is not None:
+            raise first_err
         return out
 
     def close(self):

@@ -213,6 +213,57 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
             assert np.array_equal(tot, ref[0, oy, ox]), "fmaf chain mismatch at (%d,%d): %g" % (oy, ox, np.abs(tot - ref[0, oy, ox]).max())
 
 
+# LDS-DMA tile configurations (include/csm355.h `tile`): plain 6-12 / 14-17 / 28-37, 3x3 patch 18-27 / 36, persistent 38-49
+DMA_CFGS = [c for c in range(6, 50) if c != 13]
+
+
+def test_dma_kernels_repeated_runs_are_bitwise_stable():
+    """stress test for the barrier / LDS hazard class (a stage refilled by DMA while a fragment read of it is still in flight shows as a
+    few wrong values in 10^7, once in many runs): every LDS-DMA tile configuration x the eight BASELINE-size layers x both split-K
+    executions, 20 repetitions each, every repetition compared bitwise with the first run of configuration 6 ON THE DEVICE (one host
+    read per layer).  tools/check_isa_barriers.py is the static half of this check."""
+    from cartoonsegmentation_amd import _lib
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    L = _lib.load()
+    reps = int(os.environ.get("CSM_STRESS_REPS", "20"))
+    try:
+        for layer in FULL_SIZE_LAYERS:
+            n, h, w, cin, cout, k, stride, dil, groups = layer
+            p = Program("stress")
+            x = p.buffer(n, h, w, cin)
+            W = rnd('sw%s' % (layer,), (cout, cin // groups, k, k), 1.0 / np.sqrt(cin // groups * k * k))
+            y = p.conv(x, W, rnd('sb%s' % (layer,), (cout,), 0.1), stride=stride, pad=dil * (k // 2), dil=dil, groups=groups, act='relu')
+            y.buf.keep = True
+            x.buf.first = 0
+            p.plan()
+            os.environ["CSM_AUTOTUNE"] = "0"
+            try:
+                cp = CompiledProgram(p, 'cuda')
+            finally:
+                os.environ.pop("CSM_AUTOTUNE", None)
+            xin = torch.from_numpy(rnd('sx%s' % (layer,), (n, h, w, cin))).cuda()
+            cp.workspace[x.buf.offset:x.buf.offset + xin.numel()] = xin.reshape(-1)
+            L.csm_debug_force_conv_cfg(6)
+            L.csm_debug_force_splitk_serial(0)
+            cp.run()
+            ref = cp.read_view(y).clone()
+            bad = torch.zeros(len(DMA_CFGS) * 2, dtype=torch.int32, device='cuda')
+            modes = (0, 1) if p.ops[0]['ksplit'] > 1 else (0,)
+            for ci, cfg in enumerate(DMA_CFGS):
+                L.csm_debug_force_conv_cfg(cfg)
+                for ser in modes:
+                    L.csm_debug_force_splitk_serial(ser)
+                    for _ in range(reps):
+                        cp.run()
+                        bad[2 * ci + ser] += (cp.read_view(y) != ref).sum().to(torch.int32)
+            bad = bad.cpu().numpy()
+            wrong = {(DMA_CFGS[i // 2], i % 2): int(v) for i, v in enumerate(bad) if v}
+            assert not wrong, "layer %s: wrong values per (tile configuration, serial split-K) over %d runs: %s" % (layer, reps, wrong)
+    finally:
+        L.csm_debug_force_conv_cfg(-1)
+        L.csm_debug_force_splitk_serial(-1)
+
+
 def test_program_run_is_hipgraph_capturable():
     """CompiledProgram.run enqueues only kernels on torch's current stream (no allocation, no sync after the first, tuning, call):
     capture a small net into a hipGraph, replay it on new input, compare with the eager run bit for bit."""

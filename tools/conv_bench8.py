@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from cartoonsegmentation_amd.program import Program
+from cartoonsegmentation_amd.program import Program  # (CSM_LIB=<path> selects another build of the library)
 from cartoonsegmentation_amd.runtime import CompiledProgram
 
 # (mult per step, n, h, w, cin, cout, k, stride, dil, groups)
