@@ -36,6 +36,7 @@ def parse():
                                                         "(64 frames on 8 GPUs), and the same per-rank work at every N (weak scaling)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra single-GPU measurements (batch / instances / det size / video)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-iou", action="store_true", help="skip the one-frame mask IoU against the CPU oracle (about 20 s of host time, untimed)")
     ap.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the per-op HIP-event pass, so that the process executes "
                                                                "exactly 1 + warmup + steps steps (rocprofv3 totals divide cleanly)")
     ap.add_argument("--cpu-seconds", type=float, default=90.0, help="budget of the host-side oracle run (full-size nets; stages that "
@@ -286,10 +287,89 @@ class FrameWorkload(Workload):
                 "lanes": lanes, "what": "%d steps of %d frame(s) in flight on %d host threads / stream sets (FrameLanes); each frame "
                                         "computed as in the serial loop" % (lanes, batch, lanes)}
 
+    def _fps_host_fed(self, steps=6):
+        """the headline step with the host feed a real multi-rank run has: every step's input frames start in PINNED HOST
+        memory and are uploaded on a copy stream (two device buffers: the upload of step s + 1 runs under the compute of step s), and
+        the step's output records (uint8 frames + bit-packed masks) are copied back to pinned host memory the same way.  `value` of the
+        bench line keeps the inputs resident (the contract); this is the PCIe-inclusive rate beside it."""
+        B, dev = self.frames_per_step, self.device
+        host_in = [torch.stack([im.cpu() for im in self.all_imgs[(p * B) % len(self.all_imgs):][:B]]).pin_memory() for p in range(2)]
+        dev_in = [torch.empty_like(h, device=dev) for h in host_in]
+        host_out = [torch.empty((B, self.rb), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        copy, main = torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+        up = [torch.cuda.Event() for _ in range(2)]
+        done = [torch.cuda.Event() for _ in range(2)]
+        recs = [torch.zeros((B, self.rb), dtype=torch.uint8, device=dev) for _ in range(2)]
+
+        def upload(p):
+            with torch.cuda.stream(copy):
+                copy.wait_event(done[p])                           # the step that read this buffer two steps ago has finished
+                dev_in[p].copy_(host_in[p], non_blocking=True)
+                up[p].record(copy)
+
+        def run(n):
+            upload(0)
+            for s_ in range(n):
+                p = s_ & 1
+                if s_ + 1 < n:
+                    upload(p ^ 1)
+                main.wait_event(up[p])
+                self.run_frames(self.pipe, self.wf, list(dev_in[p]), recs[p])
+                done[p].record(main)
+                with torch.cuda.stream(copy):
+                    copy.wait_event(done[p])
+                    host_out[p].copy_(recs[p], non_blocking=True)
+            copy.synchronize(); main.synchronize()
+        for e in done:
+            e.record(main)
+        run(2); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"frames_per_s": round(steps * B / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "batch": B,
+                "h2d_bytes_per_step": int(host_in[0].numel()), "d2h_bytes_per_step": int(host_out[0].numel()),
+                "what": "headline step fed from pinned host memory (H2D of the %d input frames and D2H of their output records on a copy "
+                        "stream, double-buffered, inside the timed region)" % B}
+
+    def mask_iou_vs_oracle(self):
+        """BASELINE.json's `mask IoU vs ref`: ONE 1024 x 1024 frame through AnimeInsSeg.infer on the GPU and through the CPU oracle pipeline
+        (oracle/segment.py, the checker; outside every timed region) -- per-instance IoU of the refined masks, boxes and scores compared"""
+        from cartoonsegmentation_amd import synth
+        from cartoonsegmentation_amd.nets import build_isnet, build_rtmdet
+        from cartoonsegmentation_amd.weights import SynthWeights
+        from oracle import segment as oseg
+        t0 = time.perf_counter()
+        a = self.pipe.animeinsseg
+        S, T = a.default_det_size, a.refine_size
+        img = synth.image_u8(self.H, self.W, 5)
+        inst = a.infer(img, pred_score_thr=0.3, max_instances=self.INSTANCES, output_type='numpy')
+        rp, cfg = build_rtmdet(SynthWeights('rtmdet.'), 1, S, S)
+        cfg.max_per_img = self.INSTANCES
+        d = oseg.detect(img, rp, cfg, S, pred_score_thr=0.3)
+        progs = {}
+
+        def isnet_for(b):
+            if b not in progs:
+                progs[b] = build_isnet(SynthWeights('isnet.'), b, T, T)
+            return progs[b]
+        ref = oseg.refine(img, d['masks'], isnet_for, T, 0.3).astype(bool)
+        n = min(len(inst), d['n'])
+        ious = []
+        for k in range(n):
+            inter, union = np.logical_and(ref[k], inst.masks[k]).sum(), np.logical_or(ref[k], inst.masks[k]).sum()
+            ious.append(float(inter) / float(union) if union else 1.0)
+        return {"iou_min": min(ious) if ious else None, "iou_mean": float(np.mean(ious)) if ious else None,
+                "instances_gpu": len(inst), "instances_oracle": int(d['n']),
+                "masks_bit_identical": bool(n > 0 and len(inst) == d['n'] and np.array_equal(ref, inst.masks)),
+                "boxes_and_scores_identical": bool(len(inst) == d['n'] and np.array_equal(d['scores'], inst.scores) and np.array_equal(d['bboxes'], inst.bboxes)),
+                "frame": "%dx%d synthetic, det %d, refine %d" % (self.W, self.H, S, T), "seconds": round(time.perf_counter() - t0, 1),
+                "what": "AnimeInsSeg.infer (HIP) vs the CPU oracle pipeline on one frame, after threshold; target >= 0.999"}
+
     # ---- extra single-GPU measurements (SURVEY 8d: batch 1 = BASELINE configs[1..2], n instances in {1, 8}, det 1024, the video) ----
-    def _fps(self, batch=None, instances=None, det=None, steps=3, conv_roofline=False):
+    def _fps(self, batch=None, instances=None, det=None, depth=None, steps=3, conv_roofline=False):
         """frames/s of step() under a variant of the configuration (one untimed step builds + tunes whatever is new)"""
-        keep = (self.frames_per_step, self.imgs, self.pipe.max_instances, self.pipe.animeinsseg.default_det_size)
+        keep = (self.frames_per_step, self.imgs, self.pipe.max_instances, self.pipe.animeinsseg.default_det_size, self.pipe.cfg.depth_est_size)
         try:
             if batch is not None:
                 self.frames_per_step, self.imgs = batch, self.all_imgs[:batch]
@@ -297,6 +377,8 @@ class FrameWorkload(Workload):
                 self.pipe.max_instances = instances
             if det is not None:
                 self.pipe.animeinsseg.set_detect_size(det)
+            if depth is not None:
+                self.pipe.cfg.depth_est_size = depth
             self.step(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -304,7 +386,8 @@ class FrameWorkload(Workload):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             res = {"frames_per_s": round(steps * self.frames_per_step / dt, 2), "ms_per_frame": round(dt / (steps * self.frames_per_step) * 1e3, 3),
-                   "batch": self.frames_per_step, "instances_found": self.n_inst, "det_size": self.pipe.animeinsseg.default_det_size}
+                   "batch": self.frames_per_step, "instances_found": self.n_inst, "det_size": self.pipe.animeinsseg.default_det_size,
+                   "depth_size": self.pipe.cfg.depth_est_size}
             if conv_roofline:                                  # the same conv-population roofline as the headline, for this variant
                 r = self.roofline()
                 res.update(conv_tflops=r["achieved"], conv_frac_of_mfma_peak=r["frac"], conv_avg_launch_us=r["avg_launch_us"])
@@ -312,6 +395,7 @@ class FrameWorkload(Workload):
         finally:
             self.frames_per_step, self.imgs, self.pipe.max_instances = keep[0], keep[1], keep[2]
             self.pipe.animeinsseg.set_detect_size(keep[3])
+            self.pipe.cfg.depth_est_size = keep[4]
 
     def _video(self):
         """run_kenburns.py on one 1024x1024 image with the shipped yaml's switches (configs/3dkenburns.yaml: inpainting, 75 frames,
@@ -335,8 +419,10 @@ class FrameWorkload(Workload):
                               inpaint_and_75_frames_ms=round((t[3] - t[2]) * 1e3, 2), points_after_inpaint=int(kc['tenInpaPoints'].shape[2]))
             return len(frames)
         once(); torch.cuda.synchronize()                       # builds the Inpaint programs
+        once(); torch.cuda.synchronize()                       # second call: whatever is sized / allocated lazily per video has its steady-state shape now
         st = {}
-        once(st)
+        once(st)                                               # third call, staged (a synchronize between the stages: the sum is >= video_ms by the bubbles)
+        st["stages_sum_ms"] = round(st["config_ms"] + st["autozoom_ms"] + st["inpaint_and_75_frames_ms"], 2)
         t0 = time.perf_counter()
         n = 0
         for _ in range(2):
@@ -387,13 +473,34 @@ class FrameWorkload(Workload):
             out["tiled_%d_3streams" % size] = {"us_per_frame": round(ms * 1e3, 2), "GBps": round(alg / (ms * 1e-3) / 1e9, 1),
                                                "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                "what": "60 frames round-robin over 3 streams with their own scratch (the video loop's issue order)"}
+            if size == 2048:
+                # SURVEY 8(d)'s L3-spilling point: EIGHT DIFFERENT 2048^2 clouds in a batch (8 x 155 P = 5.2 GB of algorithmic traffic, far
+                # beyond the 256 MB Infinity Cache: no frame finds its inputs cached), one stream, one scratch
+                clouds = []
+                for q in range(8):
+                    scq = synth.warp_scene(size, size, 2000 + q)
+                    dq = torch.from_numpy(scq['disp']).to(self.device)
+                    dq = dq / dq.max() * scq['baseline']
+                    depq, _, ptq, _ = self.ops.disparity_to_points(dq, scq['focal'], scq['baseline'])
+                    clouds.append((ptq.view(1, 3, -1).contiguous(), torch.from_numpy(scq['rgb']).to(self.device), depq.view(1, 1, -1).contiguous()))
+                wf8 = self.ops.WarpFrame(size, size, self.device, path="tiled")
+
+                def batch8():
+                    for ptq, rgq, dpq in clouds:
+                        wf8(ptq, rgq, dpq, sc['focal'], sc['baseline'], shift)
+                ms8 = event_time_ms(batch8, 6, warm=2) / 8
+                out["tiled_2048_batch8"] = {"us_per_frame": round(ms8 * 1e3, 2), "GBps": round(alg / (ms8 * 1e-3) / 1e9, 1),
+                                            "frac_of_hbm_peak": round(alg / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "what": "8 different 2048x2048 clouds per batch, serial on one stream (inputs never cached: 5.2 GB per batch)"}
+                del clouds
         return out
 
     def variants(self):
         v = {"batch1": self._fps(batch=1, conv_roofline=True), "batch1_lanes3": self._fps_lanes(1, 3, steps=8), "batch1_lanes4": self._fps_lanes(1, 4, steps=8),
              "batch16": self._fps(batch=16, conv_roofline=True), "instances1": self._fps(instances=1),
              "instances8": self._fps(instances=8), "instances100_batch1": self._fps(batch=1, instances=100, steps=2),
-             "det1024_batch4": self._fps(batch=4, det=1024), "video": self._video(),
+             "det1024_batch4": self._fps(batch=4, det=1024), "leres1024_batch4": self._fps(batch=4, depth=1024, steps=2),
+             "host_fed": self._fps_host_fed(), "video": self._video(),
              "warp_chain": self._warp_points()}
         v["reference_shaped_ratio"] = "1 seg + 1 depth + 75 warps: see video (inpaint_and_75_frames_ms vs config_ms)"
         return v
@@ -544,9 +651,12 @@ def main():
         # multi-rank start-up: rank 0 builds the weights and tunes the conv tiles, the others wait, then build with the tile table
         # rank 0 saved (CSM_TUNE_CACHE: no tuning launches on 7 of 8 ranks) and with PLACEHOLDER weights (zeros of the right shapes):
         # what they compute with arrives through the RCCL broadcast below, like a checkpoint read by rank 0 would
-        os.environ.setdefault("CSM_TUNE_CACHE", "/tmp/csm_tune_%s_%s.txt" % (os.environ.get("MASTER_PORT", "0"), a.size))
+        # (the table travels through the process group -- broadcast_object_list -- not through a shared file: every rank keeps a PRIVATE copy)
+        os.environ["CSM_TUNE_CACHE"] = "/tmp/csm_tune_%s_%s_rank%d.txt" % (os.environ.get("MASTER_PORT", "0"), a.size, rank)
         if rank != 0:
             os.environ["CSM_WEIGHTS_PLACEHOLDER"] = "1"
+            if os.path.exists(os.environ["CSM_TUNE_CACHE"]):
+                os.remove(os.environ["CSM_TUNE_CACHE"])
     wl = make_workload(a.workload, a.size, rank, device, world, dist, a.batch)
 
     weights_equal = None
@@ -556,6 +666,12 @@ def main():
     else:
         if rank == 0:
             wl.step(); torch.cuda.synchronize()       # builds + tunes + saves the tile table -- untimed
+        table = [open(os.environ["CSM_TUNE_CACHE"]).read() if rank == 0 and os.path.exists(os.environ["CSM_TUNE_CACHE"]) else None]
+        dist.broadcast_object_list(table, src=0)      # rank 0's tuned tiles: 7 of 8 ranks time nothing and all ranks run the same tiles
+        if rank != 0 and table[0]:
+            with open(os.environ["CSM_TUNE_CACHE"], "w") as f:
+                f.write(table[0])
+        tile_table_lines = len(table[0].splitlines()) if table[0] else 0
         dist.barrier()
         if rank != 0:
             wl.step(); torch.cuda.synchronize()       # same programs, tiles from the table, placeholder weights -- untimed
@@ -598,6 +714,8 @@ def main():
         out["roofline"] = None if a.no_roofline else wl.roofline()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline(a.cpu_seconds)
+        if world == 1 and not a.no_iou and hasattr(wl, "mask_iou_vs_oracle"):
+            out["mask_iou_vs_oracle"] = wl.mask_iou_vs_oracle()    # BASELINE.json's `mask IoU vs ref`; the oracle is the checker, untimed
         out.update(wl.extra())
         if world == 1 and not a.no_variants and hasattr(wl, "variants"):
             out["variants"] = wl.variants()
@@ -613,7 +731,7 @@ def main():
             out["gather"] = wl.check_gathered()
             out["weights_broadcast_bytes"] = bcast_bytes
             out["weights_equal_after_broadcast"] = weights_equal
-            out["tile_table"] = os.environ.get("CSM_TUNE_CACHE")
+            out["tile_table"] = {"entries": tile_table_lines, "how": "tuned by rank 0, broadcast_object_list to the other ranks"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

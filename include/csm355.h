@@ -241,7 +241,8 @@ int csm_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
 int csm_debug_force_conv_cfg(int cfg);
 /* Test aid (not stable ABI): how ksplit > 1 layers are executed: -1 = tuned / built-in rule, 0 = parallel, 1 = serial. */
 int csm_debug_force_splitk_serial(int mode);
-/* Measurement aid (not stable ABI): launch forms the autotuner may choose from; bit 0 = mixed-tile launches (default on). */
+/* Measurement aid (not stable ABI): bit 0 = the autotuner may choose mixed-tile launches (default on); bit 1 = N-grouped tile order
+ * (layers whose weights exceed an XCD's L2) OFF (default on).  Speed only. */
 int csm_debug_conv_tuner_options(int options);
 /* Measurement aid: same execution, each op bracketed by HIP events on `stream`; synchronises and returns ms per op. */
 int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,

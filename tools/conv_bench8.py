@@ -32,6 +32,8 @@ ONLY = [int(c) for c in os.environ.get('ONLY', '').split()]
 def main():
     from cartoonsegmentation_amd import _lib
     L = _lib.load()
+    if os.environ.get('TUNER_OPTIONS'):
+        L.csm_debug_conv_tuner_options(int(os.environ['TUNER_OPTIONS']))
     tot = best = 0.0
     print("cfgs:", CFGS, "dbg:", DBG)
     for li, (mult, n, h, w, cin, cout, k, s, d, g) in enumerate(LAYERS):
