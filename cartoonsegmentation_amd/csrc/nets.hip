@@ -19,9 +19,11 @@
 //     that the 3x3 halo re-reads of neighbouring tiles hit the same 4 MiB L2.
 // Numerical contract: see include/csm355.h (one fmaf chain per output, fixed K order).
 #include "csm_common.h"
+#include "csm_tokens.h"
 #include <array>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -2444,6 +2446,37 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 else
                     k_nhwc_to_nchw<<<blocks_for((int64_t)in.n * in.h * in.w * in.c), 256, 0, st>>>(in, out.p);
                 break;
+            case CSM_OP_LAYERNORM: {
+                if (op.w_off < 0 || op.b_off < 0 || op.aux_off < 0 || in.c != out.c) { csm::set_error("op %d: layernorm operands", i); return CSM_ERR_ARG; }
+                rc = csm::launch_layernorm(in.p, in.ld, out.p, out.ld, (int64_t)in.n * in.h * in.w, in.c, weights + op.w_off, weights + op.b_off,
+                                           weights + op.aux_off /* {eps}, read on the device */, st);
+                if (rc) return rc;
+                break;
+            }
+            case CSM_OP_ATTENTION: {
+                const int heads = op.groups, d = op.cin_g;
+                if (heads < 1 || in.c != 3 * heads * d || out.c != heads * d || in.w != 1 || out.h != in.h) { csm::set_error("op %d: attention operands", i); return CSM_ERR_ARG; }
+                rc = csm::launch_attention(in.p, in.ld, out.p, out.ld, in.n, in.h, heads, d, op.aux_off >= 0 ? weights + op.aux_off : nullptr, op.kh, op.kw, st);
+                if (rc) return rc;
+                break;
+            }
+            case CSM_OP_TOKENS: {
+                const int mode = op.flags;
+                const int np = mode == 0 ? in.h * in.w : out.h * out.w;
+                const bool ok = mode == 0 ? (out.h == np + 1 && out.w == 1 && out.c == in.c && op.aux_off >= 0)
+                                          : (in.h == np + 1 && in.w == 1 && out.c == (mode == 1 ? 2 : 1) * in.c);
+                if (!ok || in.n != out.n) { csm::set_error("op %d: tokens operands (mode %d)", i, mode); return CSM_ERR_ARG; }
+                rc = csm::launch_tokens(mode, in.p, in.ld, out.p, out.ld, in.n, np, in.c, op.aux_off >= 0 ? weights + op.aux_off : nullptr, st);
+                if (rc) return rc;
+                break;
+            }
+            case CSM_OP_DEPTH_TO_SPACE: {
+                const int k = op.stride;
+                if (k < 1 || out.h != in.h * k || out.w != in.w * k || in.c != k * k * out.c) { csm::set_error("op %d: depth_to_space operands", i); return CSM_ERR_ARG; }
+                rc = csm::launch_depth_to_space(in.p, in.ld, out.p, out.ld, in.n, in.h, in.w, k, out.c, st);
+                if (rc) return rc;
+                break;
+            }
             default:
                 csm::set_error("op %d: unknown kind %d", i, op.kind);
                 return CSM_ERR_ARG;

@@ -14,6 +14,7 @@ import numpy as np
 # ---- C structs (must match include/csm355.h) -------------------------------------------------
 OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_BILINEAR, OP_NEAREST, OP_ADD, OP_GAVGPOOL, OP_SCALE = 1, 2, 3, 4, 5, 6, 7, 8
 OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_ACT, OP_COPY, OP_ATTRACTOR, OP_LOGBINOM = 9, 10, 11, 12, 13, 14
+OP_LAYERNORM, OP_ATTENTION, OP_TOKENS, OP_DEPTH_TO_SPACE = 15, 16, 17, 18
 ACT = {None: 0, 'none': 0, 'relu': 1, 'silu': 2, 'prelu': 3, 'hsigmoid': 4, 'sigmoid': 5, 'softplus': 6, 'gelu': 7}
 
 
@@ -328,6 +329,64 @@ class Program:
         par = np.concatenate([np.array([p_eps, min_temp, max_temp], np.float32), np.asarray(log_binom_table, np.float32)])
         a_h, a_n = self._w(par, par)
         return self._emit(OP_LOGBINOM, pt, centers, out, aux_off=a_h, nat=dict(aux_off=a_n))
+
+    # ---- transformer ops (MiDaS DPT-BEiT core; a token sequence [B, N, C] is the tensor n = B, h = N, w = 1, c = C) ---------------
+    def linear(self, x, w, b=None, act=None, res=None, out=None):
+        """nn.Linear over the channels of every pixel / token: w [cout, cin] -> a 1x1 convolution on the MFMA engine"""
+        w = np.asarray(w, np.float32)
+        return self.conv(x, w.reshape(w.shape[0], w.shape[1], 1, 1), b, act=act, res=res, res_mode=1 if res is not None else 0, out=out)
+
+    def layernorm(self, x, gamma, beta, eps, out=None):
+        if out is None:
+            out = self.buffer(x.n, x.h, x.w, x.c)
+        assert x.c % 4 == 0 and gamma.size == x.c and beta.size == x.c
+        w_h, w_n = self._w(gamma, gamma)
+        b_h, b_n = self._w(beta, beta)
+        a_h, a_n = self._w(np.array([eps, 0, 0, 0], np.float32), np.array([eps, 0, 0, 0], np.float32))
+        return self._emit(OP_LAYERNORM, x, None, out, w_off=w_h, b_off=b_h, aux_off=a_h, nat=dict(w_off=w_n, b_off=b_n, aux_off=a_n))
+
+    def attention(self, qkv, heads, grid=None, rel_table=None):
+        """softmax(q k^T + bias) v per head; qkv [n, N, 1, 3 * heads * d] with q pre-scaled; rel_table [(2gh-1)(2gw-1)+3, heads] (BEiT) with
+        grid = (gh, gw) and N == gh * gw + 1 (token 0 = class token), or None"""
+        d = qkv.c // (3 * heads)
+        assert qkv.w == 1 and qkv.c == 3 * heads * d and d in (32, 64, 128), (qkv.shape, heads)
+        out = self.buffer(qkv.n, qkv.h, 1, heads * d)
+        a_h = a_n = -1
+        gh, gw = grid if grid is not None else (0, 0)
+        if rel_table is not None:
+            rel_table = np.asarray(rel_table, np.float32)
+            assert rel_table.shape == ((2 * gh - 1) * (2 * gw - 1) + 3, heads) and qkv.h == gh * gw + 1, (rel_table.shape, grid, qkv.h)
+            a_h, a_n = self._w(rel_table, rel_table)
+        self.flops += 4 * qkv.n * heads * qkv.h * qkv.h * d
+        return self._emit(OP_ATTENTION, qkv, None, out, groups=heads, cin_g=d, kh=gh, kw=gw, aux_off=a_h, nat=dict(aux_off=a_n))
+
+    def tokens_assemble(self, patches, cls):
+        """[n, gh, gw, c] patch embedding -> [n, gh*gw + 1, 1, c] with the class token in row 0"""
+        out = self.buffer(patches.n, patches.h * patches.w + 1, 1, patches.c)
+        a_h, a_n = self._w(cls, cls)
+        return self._emit(OP_TOKENS, patches, None, out, flags=0, aux_off=a_h, nat=dict(aux_off=a_n))
+
+    def tokens_readout(self, tokens, grid, project=True):
+        """MiDaS readout: drop the class token (Slice) or concatenate it to every patch token (ProjectReadout's input) -> [n, gh, gw, c or 2c]"""
+        gh, gw = grid
+        assert tokens.w == 1 and tokens.h == gh * gw + 1
+        out = self.buffer(tokens.n, gh, gw, tokens.c * (2 if project else 1))
+        return self._emit(OP_TOKENS, tokens, None, out, flags=1 if project else 2, kh=gh, kw=gw)
+
+    def depth_to_space(self, x, k):
+        assert x.c % (k * k) == 0 and (x.c // (k * k)) % 4 == 0
+        out = self.buffer(x.n, x.h * k, x.w * k, x.c // (k * k))
+        return self._emit(OP_DEPTH_TO_SPACE, x, None, out, stride=k)
+
+    def conv_transpose_nonoverlap(self, x, w, b, k):
+        """nn.ConvTranspose2d(cin, cout, kernel_size = stride = k): w [cin, cout, k, k].  Non-overlapping, so it is a 1x1 convolution to
+        k*k*cout channels (channel (ky*k + kx)*cout + co <- w[:, co, ky, kx]) followed by the depth-to-space scatter"""
+        w = np.asarray(w, np.float32)
+        cin, cout = w.shape[0], w.shape[1]
+        assert w.shape[2:] == (k, k) and cin == x.c
+        w1 = w.transpose(2, 3, 1, 0).reshape(k * k * cout, cin, 1, 1)
+        b1 = None if b is None else np.tile(np.asarray(b, np.float32), k * k)
+        return self.depth_to_space(self.conv(x, w1, b1), k)
 
     def crop_rows(self, x, h):
         """the first h rows of a single-image map as a VIEW (torch's negative bottom pad): same buffer, smaller height"""

@@ -48,6 +48,14 @@ def synth_tensor(name, shape, kind):
         v = 1.0 + 0.1 * u * u
     elif kind == 'prelu':
         v = 0.25 + 0.05 * u
+    elif kind == 'lin_w':        # transformer linears behind a LayerNorm: unit-variance outputs for unit-variance inputs
+        v = u * np.sqrt(3.0 / shape[-1])
+    elif kind == 'token':        # class token
+        v = 0.5 * u
+    elif kind == 'rel_bias':     # relative-position-bias table: logits of order one, so that the bias visibly shapes the softmax
+        v = 1.5 * u
+    elif kind == 'layer_scale':  # BEiT gamma_1 / gamma_2 (trained values are O(0.1 .. 1))
+        v = 0.3 + 0.2 * u
     else:
         raise KeyError(kind)
     return v.astype(np.float32).reshape(shape)

@@ -10,10 +10,12 @@ Built here, all on the device:
   * ZoeDepth.forward after `self.core(...)`: the metric-bins head as a layer program (nets/zoedepth_head.py);
   * the feature order MidasCore's hooks deliver: (out_conv, l4_rn, r4, r3, r2, r1) = layer_names of midas.py:189, with rel_depth.
 
-NOT built -- and not buildable from /root/reference: `self.core.core`, the MiDaS DPT-BEiT-L network (torch.hub "intel-isl/MiDaS" +
-timm; midas.py:341).  It is a plug: `core(x)` takes the prepared input [B, 3, h, w] and returns (rel_depth [B, h, w], [out_conv
-[B, 32, h, w], bottleneck [B, 256, h/32, w/32], r4 .. r1 [B, 256, h/16 .. h/2, ...]]) as device tensors.  Without one, infer() raises
--- there is no stand-in network and no CPU path.
+The core itself -- `self.core.core`, the MiDaS DPT-BEiT-L network the reference fetches with torch.hub "intel-isl/MiDaS" + timm
+(midas.py:341, not vendored) -- is built in (round 4): `DPTBeitCore` runs nets/dpt_beit.py's layer program (24 BEiT blocks on the fp32
+MFMA engine + CSM_OP_LAYERNORM / ATTENTION / TOKENS, the DPT reassemble / fusion / head), lowered from the published timm / MiDaS
+definitions with the checkpoint's parameter names [EXT: unpinned against MiDaS' own code, pinned against HuggingFace's DPT-BEiT
+implementation by tests/test_oracle_dpt_beit.py].  `core=` still accepts any callable with the same contract: core(x [B,3,h,w]) ->
+(rel_depth [B,h,w], [out_conv [B,32,h,w], bottleneck [B,256,h/32,w/32], r4 .. r1 [B,256,h/16 .. h/2, ...]]) as device tensors.
 """
 import math
 
@@ -26,10 +28,49 @@ from .nets import build_zoe_head
 from .runtime import CompiledProgram
 
 
-def _core_missing(x):
-    raise _lib.CsmError("ZoeDepth needs its MiDaS DPT-BEiT-L core, which the reference fetches with torch.hub (intel-isl/MiDaS + timm, "
-                        "depth_modules/zoedepth/models/base_models/midas.py:341) and does not vendor: pass core=<callable> "
-                        "(see cartoonsegmentation_amd/zoedepth.py) or use depth_est 'leres' / 'default'")
+class PrefixedWeights:
+    """a weight source seen through a name prefix (ZoeD_M12_N.pt keeps the MiDaS network under `core.core.`)"""
+
+    def __init__(self, ws, prefix):
+        self.ws, self.prefix = ws, prefix
+
+    def get(self, name, shape, kind):
+        return self.ws.get(self.prefix + name, shape, kind)
+
+
+class DPTBeitCore:
+    """the MiDaS DPT-BEiT core as a callable: one compiled layer program per (batch, height, width) of the prepared input"""
+
+    def __init__(self, ws, cfg=None, device=None):
+        from .nets import DPTBeitConfig
+        self.ws, self.cfg = ws, cfg or DPTBeitConfig()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device in (None, 'cuda') else torch.device(device)
+        self._progs, self._weights = {}, None
+
+    def program(self, n, h, w):
+        from .nets import build_dpt_beit
+        key = (n, h, w)
+        if key not in self._progs:
+            prog = build_dpt_beit(self.ws, n, h, w, self.cfg)
+            # every program of this core packs the same parameters except the re-sampled relative-position tables: they are small, the
+            # 1.2 GB of BEiT-L weights are not -- but the packed layout is position dependent, so each shape keeps its own buffer
+            self._progs[key] = CompiledProgram(prog, self.device)
+        return self._progs[key]
+
+    def __call__(self, xp):
+        if not xp.is_cuda or xp.dtype != torch.float32 or xp.dim() != 4 or xp.shape[1] != 3:
+            raise _lib.CsmError("DPTBeitCore: float32 device tensor [B,3,h,w] expected")
+        n, _, h, w = (int(v) for v in xp.shape)
+        if h % 32 or w % 32:
+            raise _lib.CsmError("DPTBeitCore: the prepared input must be a multiple of 32 (PrepForMidas), got %dx%d" % (h, w))
+        F, gh, gw = self.cfg.features, h // 16, w // 16
+        dev = self.device
+        rel = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev)
+        oc = torch.empty((n, self.cfg.head_features_2, h, w), dtype=torch.float32, device=dev)
+        l4 = torch.empty((n, F, gh // 2, gw // 2), dtype=torch.float32, device=dev)
+        rs = [torch.empty((n, F, gh << k, gw << k), dtype=torch.float32, device=dev) for k in range(4)]
+        self.program(n, h, w).run(xp.contiguous(), rel, oc, l4, *rs)
+        return rel.view(n, h, w), [oc, l4] + rs
 
 
 def midas_size(width, height, net_w, net_h, keep_aspect_ratio=True, multiple_of=32):
@@ -50,13 +91,22 @@ class ZoeDepth:
             raise _lib.CsmError("ZoeDepth needs an MI355X: libcsm355 has no CPU path")
         _lib.load()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device in (None, 'cuda') else torch.device(device)
-        self.ws, self.core, self.head_kw = ws, core or _core_missing, head_kw
+        self.ws, self.head_kw = ws, head_kw
+        self._builtin = None
+        self.core = core or self._builtin_core()
         self.net_h, self.net_w = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
         self.keep_aspect_ratio = keep_aspect_ratio
         self._heads = {}
 
+    def _builtin_core(self):
+        """the MiDaS network of the same checkpoint: ZoeDepth's state_dict keeps it under `core.core.` (ZoeDepth.core = MidasCore, .core = DPT)"""
+        if self._builtin is None:
+            self._builtin = DPTBeitCore(PrefixedWeights(self.ws, 'core.core.'), device=self.device)
+        return self._builtin
+
     def set_core(self, core):
-        self.core = core or _core_missing
+        """core = None restores the built-in DPT-BEiT-L program"""
+        self.core = core or self._builtin_core()
 
     # ---- ZoeDepth.forward (zoedepth_v1.py:124-202) on an already prepared input: core -> metric-bins head --------------------
     def _head(self, n, h, w, feat_sizes):

@@ -186,10 +186,30 @@ enum csm_op_kind {
     CSM_OP_ATTRACTOR = 13,  /* in0 = attractor points A [n,h,w,na], in1 = bin centers b [n,h,w,nb] -> out = b + agg_i dist(A_i - b):
                                dist = dx / (1 + alpha dx^2) (flags bit 0 = 0, "inv") or exp(-alpha dx^2) dx (bit 0 = 1, "exp");
                                agg = sum over i in order, / na when flags bit 1 (kind "mean"); aux_off -> {alpha}  (gamma = 2) */
-    CSM_OP_LOGBINOM = 14    /* in0 = pt [n,h,w,4] (softplus'ed p0,p1,t0,t1), in1 = bin centers [n,h,w,nb] -> out [n,h,w,1] =
+    CSM_OP_LOGBINOM = 14,   /* in0 = pt [n,h,w,4] (softplus'ed p0,p1,t0,t1), in1 = bin centers [n,h,w,nb] -> out [n,h,w,1] =
                                sum_k softmax_k(logbinomial_k(p) / t) * centers_k  (ConditionalLogBinomial.forward tail + the
                                weighted sum of zoedepth_v1.py:199); aux_off -> {p_eps, min_temp, max_temp, lb[0..nb)} with
                                lb[k] = log_binom(nb-1, k) tabulated by the host */
+    /* MiDaS DPT-BEiT core of ZoeDepth (timm 0.6.x beit_large_patch16_384 + MiDaS 3.1 dpt_depth.py / backbones/beit.py; the reference
+     * fetches it with torch.hub, depth_modules/zoedepth/models/base_models/midas.py:341).  A token sequence [B, N, C] is the NHWC tensor
+     * n = B, h = N, w = 1, c = C, so every nn.Linear is a 1x1 CSM_OP_CONV (exact fmaf chains, as above).  The ops below hold reductions
+     * over channels / keys: their order is implementation-defined and parity with the oracle is tolerance-level (1e-5 relative), not
+     * bit-exact. */
+    CSM_OP_LAYERNORM = 15,  /* out[p, :] = (in0[p, :] - mean) * rsqrt(var + eps) * gamma + beta over the c channels of every pixel p
+                               (biased variance); w_off -> gamma[c], b_off -> beta[c], aux_off -> {eps} */
+    CSM_OP_ATTENTION = 16,  /* multi-head self-attention core.  in0 = qkv [n, N, 1, 3 * heads * d] (channels: q | k | v, each head-major;
+                               q already carries the 1/sqrt(d) scale), out = [n, N, 1, heads * d]; groups = heads, cin_g = d.
+                               out[i, h, :] = sum_j softmax_j(q_i . k_j + bias_h(i, j)) v_j.  BEiT's relative position bias: token 0 is the
+                               class token, token 1 + y * kw + x the patch (y, x) of the kh x kw grid (N = kh * kw + 1); aux_off ->
+                               table [(2 kh - 1) * (2 kw - 1) + 3][heads]: bias_h(i, j) = table[(yi - yj + kh - 1) * (2 kw - 1) + (xi - xj +
+                               kw - 1)][h] between patches, rows T-3 / T-2 / T-1 for cls->patch / patch->cls / cls->cls (timm
+                               gen_relative_position_index); aux_off < 0: no bias (kh * kw + 1 == N still required when kh > 0) */
+    CSM_OP_TOKENS = 17,     /* token plumbing, mode = flags: 0 "assemble" in0 = patch embedding [n, gh, gw, c] -> out [n, gh*gw + 1, 1, c],
+                               row 0 = class token (aux_off -> c floats); 1 "readout project input" in0 = tokens [n, N, 1, c] ->
+                               out [n, kh, kw, 2c] = (token 1 + i | class token) (MiDaS ProjectReadout's concat); 2 "readout ignore"
+                               -> out [n, kh, kw, c] = token 1 + i (MiDaS Slice) */
+    CSM_OP_DEPTH_TO_SPACE = 18 /* out[n, y*k + ky, x*k + kx, c] = in0[n, y, x, (ky*k + kx) * out.c + c], k = stride: the scatter half of a
+                               ConvTranspose2d(kernel = stride = k) whose GEMM half is a 1x1 CSM_OP_CONV to k*k*cout channels */
 };
 enum csm_act { CSM_ACT_NONE = 0, CSM_ACT_RELU = 1, CSM_ACT_SILU = 2, CSM_ACT_PRELU = 3, CSM_ACT_HSIGMOID = 4,
                CSM_ACT_SIGMOID = 5, CSM_ACT_SOFTPLUS = 6 /* torch.nn.Softplus(): x > 20 ? x : log(1 + exp(x)) */,

@@ -188,7 +188,7 @@ static void orc_conv_fast(const csm_op *op, view_t in, view_t res, view_t out, c
         int n = (int)(m / ((int64_t)out.h * out.w));
         int rem = (int)(m - (int64_t)n * out.h * out.w);
         int oy = rem / out.w, ox = rem - oy * out.w;
-        const float *xp[64];                        /* kh * kw <= 49 in every net */
+        const float *xp[taps];                      /* (a VLA: the 16 x 16 patch embedding of the BEiT core has 256 taps) */
         for (int ky = 0; ky < kh; ++ky)
             for (int kx = 0; kx < kw; ++kx) {
                 int iy = oy * op->stride - op->pad + ky * op->dil, ix = ox * op->stride - op->pad + kx * op->dil;
@@ -423,6 +423,100 @@ static void orc_gavgpool(view_t in, view_t out)
         }
 }
 
+/* ---- transformer ops of the MiDaS DPT-BEiT core (timm 0.6.x models/beit.py Attention / Block, MiDaS 3.1 midas/backbones/beit.py and
+ * utils.py; restated from the published definitions -- the reference pulls them through torch.hub, base_models/midas.py:341).  Reductions
+ * in double: this is the high-precision side of a tolerance-level comparison. */
+static void orc_layernorm(view_t in, view_t out, const float *gamma, const float *beta, float eps)
+{
+    int64_t rows = (int64_t)in.n * in.h * in.w;
+#pragma omp parallel for
+    for (int64_t r = 0; r < rows; ++r) {
+        const float *x = in.p + r * in.ld;
+        double s = 0.0, q = 0.0;
+        for (int c = 0; c < in.c; ++c) s += x[c];
+        double mean = s / in.c;
+        for (int c = 0; c < in.c; ++c) { double d = x[c] - mean; q += d * d; }
+        double rstd = 1.0 / sqrt(q / in.c + (double)eps);
+        for (int c = 0; c < in.c; ++c) out.p[r * out.ld + c] = (float)((x[c] - mean) * rstd * gamma[c] + beta[c]);
+    }
+}
+
+/* timm Attention.forward after the qkv projection (q pre-scaled by the lowering): attn = q k^T + relative_position_bias -> softmax -> attn v.
+ * bias index = timm gen_relative_position_index for a (gh, gw) window with the class token first. */
+static void orc_attention(const csm_op *op, view_t in, view_t out, const float *table)
+{
+    const int heads = op->groups, d = op->cin_g, N = in.h, C = heads * d, gh = op->kh, gw = op->kw;
+    const int T = (2 * gh - 1) * (2 * gw - 1) + 3;
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < in.n; ++b)
+        for (int h = 0; h < heads; ++h) {
+            double *sc = (double *)malloc(sizeof(double) * (size_t)N);
+            for (int i = 0; i < N; ++i) {
+                const float *q = in.p + ((int64_t)b * N + i) * in.ld + h * d;
+                double mx = -1e300;
+                for (int j = 0; j < N; ++j) {
+                    const float *k = in.p + ((int64_t)b * N + j) * in.ld + C + h * d;
+                    double s = 0.0;
+                    for (int e = 0; e < d; ++e) s += (double)q[e] * (double)k[e];
+                    if (table) {
+                        int idx;
+                        if (i == 0) idx = j == 0 ? T - 1 : T - 3;
+                        else if (j == 0) idx = T - 2;
+                        else {
+                            int yi = (i - 1) / gw, xi = (i - 1) % gw, yj = (j - 1) / gw, xj = (j - 1) % gw;
+                            idx = (yi - yj + gh - 1) * (2 * gw - 1) + (xi - xj + gw - 1);
+                        }
+                        s += table[(int64_t)idx * heads + h];
+                    }
+                    sc[j] = s;
+                    if (s > mx) mx = s;
+                }
+                double sum = 0.0;
+                for (int j = 0; j < N; ++j) { sc[j] = exp(sc[j] - mx); sum += sc[j]; }
+                for (int e = 0; e < d; ++e) {
+                    double o = 0.0;
+                    for (int j = 0; j < N; ++j) o += sc[j] * (double)in.p[((int64_t)b * N + j) * in.ld + 2 * C + h * d + e];
+                    out.p[((int64_t)b * N + i) * out.ld + h * d + e] = (float)(o / sum);
+                }
+            }
+            free(sc);
+        }
+}
+
+static void orc_tokens(const csm_op *op, view_t in, view_t out, const float *cls)
+{
+    const int mode = op->flags;
+    if (mode == 0) {
+        int np = in.h * in.w;
+        for (int b = 0; b < in.n; ++b)
+            for (int t = 0; t <= np; ++t)
+                for (int c = 0; c < in.c; ++c)
+                    out.p[((int64_t)b * (np + 1) + t) * out.ld + c] = t == 0 ? cls[c] : in.p[((int64_t)b * np + t - 1) * in.ld + c];
+    } else {
+        int np = out.h * out.w;
+        for (int b = 0; b < in.n; ++b)
+            for (int i = 0; i < np; ++i) {
+                float *o = out.p + ((int64_t)b * np + i) * out.ld;
+                for (int c = 0; c < in.c; ++c) o[c] = in.p[((int64_t)b * (np + 1) + 1 + i) * in.ld + c];
+                if (mode == 1)
+                    for (int c = 0; c < in.c; ++c) o[in.c + c] = in.p[((int64_t)b * (np + 1)) * in.ld + c];
+            }
+    }
+}
+
+static void orc_depth_to_space(const csm_op *op, view_t in, view_t out)
+{
+    const int k = op->stride, C = out.c;
+    for (int b = 0; b < in.n; ++b)
+        for (int y = 0; y < in.h; ++y)
+            for (int x = 0; x < in.w; ++x)
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx)
+                        for (int c = 0; c < C; ++c)
+                            out.p[(((int64_t)b * out.h + y * k + ky) * out.w + x * k + kx) * out.ld + c] =
+                                in.p[(((int64_t)b * in.h + y) * in.w + x) * in.ld + (ky * k + kx) * C + c];
+}
+
 int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors, const float *weights,
                     float *workspace, void *const *ext, int n_ext)
 {
@@ -453,6 +547,10 @@ int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
             case CSM_OP_GAVGPOOL: orc_gavgpool(in, out); break;
             case CSM_OP_ATTRACTOR: orc_attractor(op, in, in1, out, S); break;
             case CSM_OP_LOGBINOM: orc_logbinom(in, in1, out, S); break;
+            case CSM_OP_LAYERNORM: orc_layernorm(in, out, W, B, S[0]); break;
+            case CSM_OP_ATTENTION: orc_attention(op, in, out, S); break;
+            case CSM_OP_TOKENS: orc_tokens(op, in, out, S); break;
+            case CSM_OP_DEPTH_TO_SPACE: orc_depth_to_space(op, in, out); break;
             case CSM_OP_NCHW_TO_NHWC: {
                 int64_t hw = (int64_t)out.h * out.w;
                 for (int64_t n = 0; n < out.n; ++n)

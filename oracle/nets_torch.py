@@ -38,6 +38,23 @@ def _act(x, act, slope=None):
     raise KeyError(name)
 
 
+def _rel_index(gh, gw):
+    """timm 0.6.x models/beit.py gen_relative_position_index for a (gh, gw) window (restated): [N, N] indices into the bias table,
+    class token first; built with meshgrid / broadcasting (the HIP kernel and the C oracle compute the same index arithmetically)"""
+    T = (2 * gh - 1) * (2 * gw - 1) + 3
+    coords = torch.stack(torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing='ij')).flatten(1)     # 2, gh*gw
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += gh - 1
+    rel[:, :, 1] += gw - 1
+    rel[:, :, 0] *= 2 * gw - 1
+    idx = torch.zeros((gh * gw + 1,) * 2, dtype=torch.long)
+    idx[1:, 1:] = rel.sum(-1)
+    idx[0, 0:] = T - 3
+    idx[0:, 0] = T - 2
+    idx[0, 0] = T - 1
+    return idx
+
+
 def run_program(prog, ext_arrays, want_views=(), threads=None):
     """ext_arrays: list of float32 numpy arrays NCHW (inputs read, outputs written in place).  Returns {view: ndarray [n,h,w,c]}."""
     if threads:
@@ -124,6 +141,37 @@ def run_program(prog, ext_arrays, want_views=(), threads=None):
             elif kind == P.OP_ACT:
                 slope = wt(nat['aux_off'], (vo.c,)) if nat.get('aux_off', -1) >= 0 else None
                 wr(o['out'], _act(x, o['act'], slope))
+            elif kind == P.OP_LAYERNORM:
+                c = vo.c
+                g, b = wt(nat['w_off'], (c,)), wt(nat['b_off'], (c,))
+                eps = float(w_nat[nat['aux_off']])
+                wr(o['out'], F.layer_norm(x.permute(0, 2, 3, 1), (c,), g, b, eps).permute(0, 3, 1, 2))
+            elif kind == P.OP_ATTENTION:
+                heads, d = o['groups'], o['cin_g']
+                n_, N = x.shape[0], x.shape[2]
+                qkv = x[:, :, :, 0].permute(0, 2, 1).reshape(n_, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+                attn = qkv[0] @ qkv[1].transpose(-2, -1)                       # q arrives pre-scaled
+                if nat.get('aux_off', -1) >= 0:
+                    gh, gw = o['kh'], o['kw']
+                    table = wt(nat['aux_off'], ((2 * gh - 1) * (2 * gw - 1) + 3, heads))
+                    attn = attn + table[_rel_index(gh, gw).view(-1)].view(N, N, heads).permute(2, 0, 1).unsqueeze(0)
+                y = (attn.softmax(dim=-1) @ qkv[2]).transpose(1, 2).reshape(n_, N, heads * d)
+                wr(o['out'], y.permute(0, 2, 1).unsqueeze(-1))
+            elif kind == P.OP_TOKENS:
+                mode = o['flags']
+                if mode == 0:
+                    c = vo.c
+                    cls = wt(nat['aux_off'], (c,)).view(1, c, 1, 1).expand(x.shape[0], c, 1, 1)
+                    wr(o['out'], torch.cat([cls, x.flatten(2).unsqueeze(-1)], 2))
+                else:
+                    tok = x[:, :, 1:, 0]                                       # [n, c, np]
+                    if mode == 1:
+                        tok = torch.cat([tok, x[:, :, :1, 0].expand_as(tok)], 1)
+                    wr(o['out'], tok.reshape(tok.shape[0], tok.shape[1], vo.h, vo.w))
+            elif kind == P.OP_DEPTH_TO_SPACE:
+                k, c = o['stride'], vo.c
+                n_, _, h_, w_ = x.shape
+                wr(o['out'], x.reshape(n_, k, k, c, h_, w_).permute(0, 3, 4, 1, 5, 2).reshape(n_, c, h_ * k, w_ * k))
             else:
                 raise NotImplementedError("op kind %d has no torch-CPU restatement here" % kind)
             for b, l in list(last_use.items()):            # release dead intermediates (LeReS @640 would otherwise hold ~6 GB)

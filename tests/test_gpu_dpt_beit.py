@@ -1,0 +1,84 @@
+"""GPU parity of the MiDaS DPT-BEiT core of ZoeDepth (nets/dpt_beit.py + csrc/tokens.hip) against the CPU oracle interpreter.
+The linear / conv layers are bit-exact fmaf chains on both sides; LayerNorm, softmax and the attention sums are reductions whose order
+differs (the oracle accumulates in double): tolerance 1e-4 relative at reduced size, 1e-3 (north_star's fp32 depth tolerance) for the
+full BEiT-L at 384 x 512.  The wiring itself is pinned on the CPU (tests/test_oracle_dpt_beit.py: independent modules + HuggingFace)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from cartoonsegmentation_amd.nets import DPTBeitConfig, build_dpt_beit  # noqa: E402
+from cartoonsegmentation_amd.weights import SynthWeights  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+
+
+def _outs(n, H, W, cfg, fill):
+    gh, gw, F = H // 16, W // 16, cfg.features
+    shapes = [(n, 1, H, W), (n, cfg.head_features_2, H, W), (n, F, gh // 2, gw // 2)] + [(n, F, gh << k, gw << k) for k in range(4)]
+    return [np.full(s, fill, np.float32) for s in shapes]
+
+
+def _compare(prog, x, cfg, tol):
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    n, _, H, W = x.shape
+    ref = _outs(n, H, W, cfg, 0.0)
+    onets.run_program(prog, [x] + ref)
+    cp = CompiledProgram(prog, 'cuda')
+    dev = [torch.from_numpy(a).cuda() for a in _outs(n, H, W, cfg, np.nan)]
+    cp.run(torch.from_numpy(x).cuda(), *dev)
+    torch.cuda.synchronize()
+    for name, r, d in zip(('rel', 'out_conv', 'l4_rn', 'r4', 'r3', 'r2', 'r1'), ref, dev):
+        d = d.cpu().numpy()
+        assert np.isfinite(d).all(), name
+        err = np.abs(d - r).max() / np.abs(r).max()
+        assert err < tol, (name, err)
+    return cp
+
+
+SMALL = dict(embed=64, depth=3, heads=2, base_grid=(4, 4), hooks=(0, 1, 2, 2), features=32, neck=(32, 32, 64, 64))
+
+
+@pytest.mark.parametrize("n,H,W,kw", [
+    (2, 64, 96, dict(SMALL, hooks=(0, 1, 2, 1))),                     # ragged token count (25 tokens), batch 2, a block hooked twice
+    (1, 160, 128, dict(SMALL, heads=1, readout='ignore')),            # head dimension 64, Slice readout
+    (1, 96, 96, dict(SMALL, embed=128, heads=1)),                     # head dimension 128 (no key-range split in the P V phase)
+    (1, 576, 576, dict(SMALL, depth=1, hooks=(0, 0, 0, 0))),          # 1297 tokens: the 16-row query tile of the attention kernel
+])
+def test_dpt_beit_small_hip_vs_oracle(n, H, W, kw):
+    cfg = DPTBeitConfig(**kw)
+    prog = build_dpt_beit(SynthWeights('dptbeit_small.'), n, H, W, cfg)
+    x = np.random.default_rng(n * H + W).normal(0, 1, (n, 3, H, W)).astype(np.float32)
+    _compare(prog, x, cfg, 1e-4)
+
+
+def test_dpt_beit_large_384x512_hip_vs_oracle():
+    """the network of BASELINE configs[2] itself: BEiT-L/16 (24 blocks, 1024 wide, 16 heads) + DPT decoder on a 384 x 512 prepared input
+    (24 x 32 + 1 = 769 tokens: the relative-position table is re-sampled from the 24 x 24 pre-training window)"""
+    cfg = DPTBeitConfig()
+    prog = build_dpt_beit(SynthWeights('zoe.core.core.'), 1, 384, 512, cfg)
+    assert 5.0e11 < prog.flops < 1.2e12
+    x = np.random.default_rng(11).normal(0, 1, (1, 3, 384, 512)).astype(np.float32)
+    _compare(prog, x, cfg, 1e-3)
+
+
+def test_zoedepth_runs_on_its_builtin_core():
+    """ZoeDepth.forward_prepared = built-in DPT-BEiT core -> metric-bins head, against the two programs on the oracle (reduced core width)"""
+    from cartoonsegmentation_amd.nets import build_zoe_head
+    from cartoonsegmentation_amd.zoedepth import DPTBeitCore, PrefixedWeights, ZoeDepth
+    ws = SynthWeights('zoe_small.')
+    cfg = DPTBeitConfig(embed=128, depth=4, heads=2, base_grid=(6, 6), hooks=(0, 1, 2, 3), features=256, neck=(64, 64, 128, 128))
+    core = DPTBeitCore(PrefixedWeights(ws, 'core.core.'), cfg)
+    z = ZoeDepth(ws, core=core, img_size=(96, 128), device='cuda')
+    xp = np.random.default_rng(5).normal(0, 1, (1, 3, 96, 128)).astype(np.float32)
+    got = z.forward_prepared(torch.from_numpy(xp).cuda()).cpu().numpy()
+    ref = _outs(1, 96, 128, cfg, 0.0)
+    onets.run_program(build_dpt_beit(PrefixedWeights(ws, 'core.core.'), 1, 96, 128, cfg), [xp] + ref)
+    sizes = [tuple(r.shape[2:]) for r in ref[2:]]
+    out = np.zeros((1, 1, 96, 128), np.float32)
+    onets.run_program(build_zoe_head(ws, 1, 96, 128, sizes), ref + [out])
+    assert np.isfinite(got).all() and np.abs(got - out).max() <= 1e-3 * np.abs(out).max()
+    # and DepthModel.infer (padding, flip TTA, resize back) runs end to end on it
+    img = torch.rand(1, 3, 70, 110, device='cuda')
+    d = z.infer(img)
+    assert d.shape == (1, 1, 70, 110) and torch.isfinite(d).all() and float(d.min()) > 0

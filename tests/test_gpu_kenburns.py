@@ -323,7 +323,7 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CSM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CSM_SYNTHETIC_WEIGHTS="1",
-               CSM_TUNE_CACHE=str(tmp_path / "tiles.txt"), CSM_BENCH_WATCHDOG="500")
+               CSM_BENCH_WATCHDOG="500")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "2", "--size", "320", "--steps", "1",
            "--warmup", "0"]
@@ -334,7 +334,8 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["frames_per_gpu_step"] == 2
     assert d["weights_broadcast_bytes"] > 1e8 and d["weights_equal_after_broadcast"] is True
     assert d["value"] > 0 and d["scaling"] == "weak" and "roofline" in d
-    assert os.path.getsize(tmp_path / "tiles.txt") > 0
+    # rank 0's tuned tile table reaches the other ranks through the process group (broadcast_object_list), not through a shared file
+    assert d["tile_table"]["entries"] > 0 and "broadcast_object_list" in d["tile_table"]["how"]
     # every rank's output records (uint8 frame + bit-packed instance masks + count) reach rank 0 and unpack
     g = d["gather"]
     assert g["records_ok"] is True and g["masks_in_first_frames"] >= 2 and g["record_bytes"] == 320 * 320 * 3 + 2 * (320 * 320 // 8) + 8

@@ -369,14 +369,14 @@ def test_zoedepth_infer_chain_vs_reference_classes():
     t = torch.tensor([[0.0, 2.0, float('nan'), float('inf'), -1e-5]], device=dev).view(1, 1, 1, 5)
     o = depth_to_disparity(t.clone(), 55.0, 40.0).view(-1).cpu().numpy()
     assert o[0] == o[1] and o[2] == 0.0 and o[3] == 0.0 and o[4] == 0.0 and abs(o[1] - 2200.0 / 2.00001) < 0.01
-    # without a core the estimator refuses loudly (the BEiT network is not vendored)
+    # set_core(None) restores the built-in MiDaS DPT-BEiT-L program (round 4; tests/test_gpu_dpt_beit.py runs it)
+    from cartoonsegmentation_amd.zoedepth import DPTBeitCore
     z.set_core(None)
-    with pytest.raises(_lib.CsmError):
-        z.infer(x)
+    assert isinstance(z.core, DPTBeitCore)
 
 
 def test_zoe_depth_estimation_is_wired_into_the_pipeline():
-    """set_depth_estimation('zoe') (kenburns_effect.py:541-544): needs a plugged core, then generate_kenburns_config runs end to end"""
+    """set_depth_estimation('zoe') (kenburns_effect.py:541-544) around a plugged stand-in core: generate_kenburns_config runs end to end"""
     import sys
     sys.path.insert(0, GOLDEN)
     import zoe_stub_core as stub
@@ -389,9 +389,7 @@ def test_zoe_depth_estimation_is_wired_into_the_pipeline():
     pipe.max_instances = 2
     pipe.animeinsseg.set_detect_size(96)
     img = synth.image_u8(320, 352, 91)
-    with pytest.raises(_lib.CsmError):
-        pipe.generate_kenburns_config(img)
-    pipe.set_zoe_core(stub.core)
+    pipe.set_zoe_core(stub.core)             # (without a plug the built-in DPT-BEiT-L core runs: tests/test_gpu_dpt_beit.py)
     kc = pipe.generate_kenburns_config(img)
     assert kc['tenRawDisparity'].shape == (1, 1, 320, 352) and torch.isfinite(kc['tenRawPoints']).all()
     frames = pipe.autozoom(kc, inpaint=False)
