@@ -332,6 +332,46 @@ class FrameWorkload(Workload):
                 "what": "headline step fed from pinned host memory (H2D of the %d input frames and D2H of their output records on a copy "
                         "stream, double-buffered, inside the timed region)" % B}
 
+    def _zoe_variant(self, frames=3):
+        """BASELINE configs[2] with its literal depth network: seg + ZoeDepth (built-in MiDaS DPT-BEiT-L core, 672 x 672, flip TTA: two
+        passes of 1765 tokens) + one warp per 1024 x 1024 frame, serial; and the core program's own conv population against the MFMA roof"""
+        from cartoonsegmentation_amd.kenburns import KenBurnsConfig, KenBurnsPipeline
+        size = self.H
+        cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='zoe', max_size=size, refine_crf=False, depth_field=False, focal=size / 2.0,
+                             mask_refine_kwargs={'refine_method': 'refinenet_isnet', 'refine_size': 720})
+        t_build = time.perf_counter()
+        pipe = KenBurnsPipeline(cfg, device=str(self.device))
+        pipe.max_instances = self.INSTANCES
+        records = torch.zeros((1, self.rb), dtype=torch.uint8, device=self.device)
+        self.run_frames(pipe, self.wf, self.all_imgs[:1], records); torch.cuda.synchronize()       # builds + tunes the core and head programs
+        t_build = time.perf_counter() - t_build
+        t0 = time.perf_counter()
+        for k in range(frames):
+            self.run_frames(pipe, self.wf, [self.all_imgs[(k + 1) % len(self.all_imgs)]], records)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / frames
+        res = {"frames_per_s": round(1.0 / dt, 2), "ms_per_frame": round(dt * 1e3, 2), "batch": 1, "build_and_tune_s": round(t_build, 1),
+               "what": "seg (RTMDet + ISNet) + ZoeDepth on the built-in DPT-BEiT-L core (img_size 672, pad + flip TTA) + 1 warp, 1024x1024, serial"}
+        core = getattr(pipe.depth_zoe, 'core', None)
+        for (n, h, w), cp in getattr(core, '_progs', {}).items():
+            ext = [torch.randn(b.n, b.c, b.h, b.w, device=self.device) for b in sorted((b for b in cp.prog.bufs if b.ext >= 0), key=lambda b: b.ext)]
+            cp.run(*ext)
+            ms = None
+            for _ in range(3):
+                m = cp.profile(*ext)
+                ms = m if ms is None else [min(a, b) for a, b in zip(ms, m)]
+            conv_ms = sum(t for t, o in zip(ms, cp.prog.ops) if o['kind'] == 1)
+            att_ms = sum(t for t, o in zip(ms, cp.prog.ops) if o['kind'] == 16)
+            conv_fl = sum(2 * cp.prog.views[o['out']].n * cp.prog.views[o['out']].h * cp.prog.views[o['out']].w * o['nat']['cout_g'] *
+                          o['nat']['groups'] * o['nat']['cin_g'] * o['kh'] * o['kw'] for o in cp.prog.ops if o['kind'] == 1)
+            res["core_%dx%d_n%d" % (h, w, n)] = {"all_ops_ms": round(sum(ms), 3), "conv_ms": round(conv_ms, 3), "attention_ms": round(att_ms, 3),
+                                                 "gflop": round(cp.prog.flops / 1e9, 1), "conv_tflops": round(conv_fl / conv_ms / 1e9, 1),
+                                                 "conv_frac_of_mfma_peak": round(conv_fl / conv_ms / 1e9 / MFMA_F32_PEAK_TF, 4),
+                                                 "tokens": (h // 16) * (w // 16) + 1}
+        del pipe
+        torch.cuda.empty_cache()
+        return res
+
     def mask_iou_vs_oracle(self):
         """BASELINE.json's `mask IoU vs ref`: ONE 1024 x 1024 frame through AnimeInsSeg.infer on the GPU and through the CPU oracle pipeline
         (oracle/segment.py, the checker; outside every timed region) -- per-instance IoU of the refined masks, boxes and scores compared"""
@@ -500,7 +540,7 @@ class FrameWorkload(Workload):
              "batch16": self._fps(batch=16, conv_roofline=True), "instances1": self._fps(instances=1),
              "instances8": self._fps(instances=8), "instances100_batch1": self._fps(batch=1, instances=100, steps=2),
              "det1024_batch4": self._fps(batch=4, det=1024), "leres1024_batch4": self._fps(batch=4, depth=1024, steps=2),
-             "host_fed": self._fps_host_fed(), "video": self._video(),
+             "host_fed": self._fps_host_fed(), "zoe_depth_batch1": self._zoe_variant(), "video": self._video(),
              "warp_chain": self._warp_points()}
         v["reference_shaped_ratio"] = "1 seg + 1 depth + 75 warps: see video (inpaint_and_75_frames_ms vs config_ms)"
         return v

@@ -3,17 +3,7 @@
 // network is a 1x1 convolution on that engine; this file holds the reductions (LayerNorm over channels, softmax over keys) and the
 // attention core  softmax(q k^T + relative position bias) v  on the exact-fp32 matrix pipe.
 //
-// Attention kernel, one block (4 waves) per (image, head, 32-query tile):
-//   1. scores: the tile's 32 x N score block is computed 32 keys at a time on v_mfma_f32_32x32x2_f32 (A = the wave's q fragments, kept in
-//      registers; B = k rows straight from global memory: a lane reads 16 B of one key row) -- key tiles round-robin over the waves -- and
-//      written to LDS with BEiT's relative position bias added (index computed arithmetically from the token grid: no N x N table);
-//   2. softmax over each row in LDS (a wave per 8 rows, shuffle reductions), padded keys get probability 0;
-//   3. out = P V on the matrix pipe: waves = (32-wide slice of the head dimension) x (a part of the key range), the parts summed in a
-//      fixed order through LDS.  P fragments come from LDS (row pitch N + 4 floats: conflict-free ds_read_b128), V rows from global.
-// LDS = QT x (N + 4) floats with QT = 32 query rows per block up to N = 1216 tokens and QT = 16 up to N = 2496 (ZoeDepth's 672 x 672
-// input: 42 x 42 + 1 = 1765 tokens; the 32-row MFMA then carries every query twice -- the attention core is a tenth of the network's
-// FLOPs); longer sequences are refused.
-// Reductions here are tolerance-level against the oracle (not bit-exact): see the header.
+// The attention kernel streams the keys with a running max / sum (no N x N matrix): see k_attention.
 #include "csm_common.h"
 #include "csm_tokens.h"
 
@@ -63,105 +53,158 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ in,
     }
 }
 
-// ---- attention core ------------------------------------------------------------------------------------------------------------------------
-// D = head dimension (32, 64 or 128).  qkv rows: [q (heads*D) | k (heads*D) | v (heads*D)], pitch ld floats.
-template <int D, int QT>
+// ---- attention core: softmax(q k^T + relative position bias) v, streamed over the keys with a running max / sum (no N x N matrix, no
+// limit on the sequence length) --------------------------------------------------------------------------------------------------------------
+// D = head dimension (32, 64 or 128).  qkv rows: [q (heads*D) | k (heads*D) | v (heads*D)], pitch ld floats; q carries the 1/sqrt(D) scale.
+// A block = 4 waves = (2 tiles of 32 queries) x (2 halves of the key range); the two halves of a query tile are merged at the end
+// (m = max, l and o rescaled -- the usual split-softmax identity).  Per iteration the block stages one 32-key tile of K and of V for EACH
+// half into LDS with coalesced 256-B row loads (row pitch D + 4 floats: conflict-free fragment reads), then every wave runs, for its 32
+// queries x 32 keys:
+//   s^T = K q^T   on v_mfma_f32_32x32x2_f32 with A = K rows, B = q (kept in registers): a lane holds ONE query (its column) and 16 of the 32
+//                 keys (rows (r & 3) + 8 (r >> 2) + 4 lh), lane ^ 32 the other 16 -- row statistics need one cross-lane exchange, not a tree;
+//   + bias        BEiT's relative position bias, index = C(query) - K(key) computed from the token grid (the keys' part staged per tile);
+//   p = exp(s - m_new), l and o rescaled by exp(m_old - m_new): per-lane scalars, because a lane's o registers belong to its own query;
+//   o^T += V^T p^T with A = V (staged tile, a lane reads V[key][its dimension]) and B = p STRAIGHT FROM THE SCORE REGISTERS (MFMA step r
+//                 pairs the keys of register r in the two lane halves): P never goes through LDS.
+// 64 MFMAs per wave and tile, none wasted.  Reductions are tolerance-level against the oracle (see the header).
+template <int D>
 __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv, int ld, float *__restrict__ out, int out_ld, int N, int heads,
-                                                   const float *__restrict__ table, int gh, int gw) {
-    constexpr int NCOL = D / 32, KPARTS = 4 / NCOL;                    // PV: column tiles of the head dimension x parts of the key range
-    extern __shared__ __attribute__((aligned(16))) float S[];          // [QT][pitch]
-    const int Npad = (N + 31) & ~31, pitch = Npad + 4;
+                                                   const float *__restrict__ table /* [heads][T] or null */, int gh, int gw) {
+    constexpr int NCT = D / 32, PITCH = D + 4, TILE = 32 * PITCH;       // floats of one staged K or V tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [half][K tile | V tile] then [half][32] key terms of the bias index
+    // half h: K tile at lds + 2 h TILE, V tile behind it
+    int *kterm = reinterpret_cast<int *>(lds + 4 * TILE);               // [2][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int q0 = blockIdx.x * QT, head = blockIdx.y, b = blockIdx.z;
-    const int qrow = li & (QT - 1);                                     // QT = 16: MFMA rows 16 .. 31 repeat rows 0 .. 15 (results discarded)
-    const int C = heads * D;
+    const int qt = wave & 1, kh = wave >> 1;
+    const int head = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int q0 = (blockIdx.x * 2 + qt) * 32, qi = q0 + li;
     const float *base = qkv + (int64_t)b * N * ld;
     const float *Q = base + head * D, *K = base + C + head * D, *V = base + 2 * C + head * D;
+    const int T = (2 * gh - 1) * (2 * gw - 1) + 3;
+    const float *tab = table ? table + (int64_t)head * T : nullptr;
+    // the query's part of the bias index: idx(i, j) = Ci - Kj for patch tokens, Kj = yj (2 gw - 1) + xj
+    int Ci = 0;
+    if (tab && qi >= 1) { const int yi = (qi - 1) / gw, xi = (qi - 1) - yi * gw; Ci = yi * (2 * gw - 1) + xi + (gh - 1) * (2 * gw - 1) + gw - 1; }
 
-    // ---- 1. scores ------------------------------------------------------------------------------------------------------------------
     float4 qf[D / 8];
     {
-        const int qi = min(q0 + qrow, N - 1);
+        const float *qrow = Q + (int64_t)min(qi, N - 1) * ld;
 #pragma unroll
-        for (int kb = 0; kb < D / 8; ++kb) qf[kb] = *reinterpret_cast<const float4 *>(Q + (int64_t)qi * ld + 8 * kb + 4 * lh);
+        for (int kb = 0; kb < D / 8; ++kb) qf[kb] = *reinterpret_cast<const float4 *>(qrow + 8 * kb + 4 * lh);
     }
-    const int T = (2 * gh - 1) * (2 * gw - 1) + 3;
-    for (int kt = wave; kt * 32 < Npad; kt += 4) {
-        const int kj = min(kt * 32 + li, N - 1);
-        f32x16 acc;
+    f32x16 o[NCT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
+    float m_run = -3.0e38f, l_run = 0.0f;
+
+    const int NT = (N + 31) >> 5, half = (NT + 1) >> 1;
+    for (int it = 0; it < half; ++it) {
+        // ---- stage the two halves' K and V tiles (rows beyond N repeat row N - 1: finite values, their probabilities are forced to 0)
+        __syncthreads();                                                // everybody is done with the previous tiles
+        for (int e = tid; e < 2 * 32 * (D / 4); e += 256) {
+            const int hsel = e / (32 * (D / 4)), rem = e - hsel * (32 * (D / 4)), row = rem / (D / 4), c4 = rem - row * (D / 4);
+            const int key = min((hsel * half + it) * 32 + row, N - 1);
+            *reinterpret_cast<float4 *>(lds + 2 * hsel * TILE + row * PITCH + 4 * c4) = *reinterpret_cast<const float4 *>(K + (int64_t)key * ld + 4 * c4);
+            *reinterpret_cast<float4 *>(lds + (2 * hsel + 1) * TILE + row * PITCH + 4 * c4) = *reinterpret_cast<const float4 *>(V + (int64_t)key * ld + 4 * c4);
+        }
+        if (tid < 64) {
+            const int j = ((tid >> 5) * half + it) * 32 + (tid & 31);
+            int kt = 0;
+            if (j >= 1) { const int yj = (j - 1) / gw, xj = (j - 1) - yj * gw; kt = yj * (2 * gw - 1) + xj; }
+            kterm[tid] = kt;
+        }
+        __syncthreads();
+        const int tile = kh * half + it;
+        if (tile >= NT || (kh == 1 && tile < half)) continue;           // (odd tile counts: the second half has one tile fewer)
+        const float *Kt = lds + 2 * kh * TILE, *Vt = Kt + TILE;
+        // ---- s^T = K q^T
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
 #pragma unroll
         for (int kb = 0; kb < D / 8; ++kb) {
-            const float4 kf = *reinterpret_cast<const float4 *>(K + (int64_t)kj * ld + 8 * kb + 4 * lh);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kb].x, kf.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kb].y, kf.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kb].z, kf.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kb].w, kf.w, acc, 0, 0, 0);
+            const float4 kf = *reinterpret_cast<const float4 *>(Kt + li * PITCH + 8 * kb + 4 * lh);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kb].x, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kb].y, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kb].z, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kb].w, sacc, 0, 0, 0);
         }
-        // lane holds key column li of the tile, query rows (r & 3) + 8 (r >> 2) + 4 lh
-        const int j = kt * 32 + li;
-        const int yj = j > 0 ? (j - 1) / gw : 0, xj = j > 0 ? (j - 1) - yj * gw : 0;
+        // ---- bias, padded keys, running max
+        float mt = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh, i = q0 + row;
-            if (row >= QT) continue;
-            float v = acc[r];
-            if (j >= N) v = -3.0e38f;                                   // padded key: probability 0
-            else if (table && i < N) {
+            const int krow = (r & 3) + 8 * (r >> 2) + 4 * lh, j = tile * 32 + krow;
+            float v = sacc[r];
+            if (tab) {
                 int idx;
-                if (i == 0) idx = j == 0 ? T - 1 : T - 3;
+                if (qi == 0) idx = j == 0 ? T - 1 : T - 3;
                 else if (j == 0) idx = T - 2;
-                else { const int yi = (i - 1) / gw, xi = (i - 1) - yi * gw; idx = (yi - yj + gh - 1) * (2 * gw - 1) + (xi - xj + gw - 1); }
-                v += table[(int64_t)idx * heads + head];
+                else idx = Ci - kterm[kh * 32 + krow];
+                v += tab[min(max(idx, 0), T - 1)];                      // (clamped: padded queries / keys carry meaningless indices)
             }
-            S[row * pitch + j] = v;
+            if (j >= N) v = -3.0e38f;
+            sacc[r] = v;
+            mt = fmaxf(mt, v);
         }
-    }
-    __syncthreads();
-    // ---- 2. softmax over the keys: wave w owns rows (QT/4) w .. (QT/4) w + QT/4 - 1 ---------------------------------------------------
-    for (int rr = 0; rr < QT / 4; ++rr) {
-        float *row = S + ((QT / 4) * wave + rr) * pitch;
-        float m = -3.0e38f;
-        for (int j = lane; j < Npad; j += 64) m = fmaxf(m, row[j]);
-        m = wave_max(m);
-        float s = 0.0f;
-        for (int j = lane; j < Npad; j += 64) { const float e = j < N ? expf(row[j] - m) : 0.0f; row[j] = e; s += e; }
-        const float inv = 1.0f / wave_sum(s);
-        for (int j = lane; j < Npad; j += 64) row[j] *= inv;
-    }
-    __syncthreads();
-    // ---- 3. out = P V: wave -> (column tile ct of the head dimension, part kp of the key range); parts are added in order through LDS
-    const int ct = wave % NCOL, kp = wave / NCOL;
-    const int nkb = Npad / 8, kb0 = (int)((int64_t)kp * nkb / KPARTS), kb1 = (int)((int64_t)(kp + 1) * nkb / KPARTS);
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-    const float *Vc = V + 32 * ct + li;
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const float4 pf = *reinterpret_cast<const float4 *>(S + qrow * pitch + 8 * kb + 4 * lh);
-        const int k0 = 8 * kb + 4 * lh;
-        const float v0 = Vc[(int64_t)min(k0, N - 1) * ld], v1 = Vc[(int64_t)min(k0 + 1, N - 1) * ld];
-        const float v2 = Vc[(int64_t)min(k0 + 2, N - 1) * ld], v3 = Vc[(int64_t)min(k0 + 3, N - 1) * ld];
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.x, v0, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.y, v1, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.z, v2, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.w, v3, o, 0, 0, 0);
-    }
-    __syncthreads();                                                    // everybody is done reading P: the score buffer becomes the exchange area
-    float *X = S;                                                       // [KPARTS - 1][NCOL][32 rows][33]  (fits: QT * pitch >= 16 * 36 ... checked by the launcher)
-    if (kp > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) X[(((kp - 1) * NCOL + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = o[r];
-    }
-    __syncthreads();
-    if (kp == 0) {
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f((m_run - m_new) * 1.44269504088896341f);
+        float lt = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh, i = q0 + row;
-            float v = o[r];
-            for (int p = 1; p < KPARTS; ++p) v += X[(((p - 1) * NCOL + ct) * 32 + row) * 33 + li];
-            if (row < QT && i < N) out[((int64_t)b * N + i) * out_ld + head * D + 32 * ct + li] = v;
+            const int j = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float pv = j < N ? exp2f((sacc[r] - m_new) * 1.44269504088896341f) : 0.0f;
+            sacc[r] = pv;
+            lt += pv;
+        }
+        lt += __shfl_xor(lt, 32, 64);
+        l_run = l_run * alpha + lt;
+        m_run = m_new;
+        // ---- o^T = o^T alpha + V^T p^T
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[krow * PITCH + 32 * ct + li], sacc[r], o[ct], 0, 0, 0);
+            }
+        }
+    }
+    // ---- merge the two key halves of each query tile (the second half hands (m, l, o) over through LDS), normalise, store ----------------
+    __syncthreads();
+    float *X = lds + qt * (64 * (16 * NCT + 2));                        // per query tile: [lane][16 NCT + 2]
+    if (kh == 1) {
+        float *x = X + lane * (16 * NCT + 2);
+        x[0] = m_run; x[1] = l_run;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[2 + 16 * ct + r] = o[ct][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const float *x = X + lane * (16 * NCT + 2);
+        const float m1 = x[0], l1 = x[1];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = exp2f((m_run - m) * 1.44269504088896341f), a1 = exp2f((m1 - m) * 1.44269504088896341f);
+        const float inv = 1.0f / (l_run * a0 + l1 * a1);
+        if (qi < N) {
+            float *orow = out + ((int64_t)b * N + qi) * out_ld + head * D;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                          // registers 4g .. 4g + 3 = dimensions 32 ct + 8 g + 4 lh + {0, 1, 2, 3}
+                    float4 v;
+                    v.x = (o[ct][4 * g + 0] * a0 + x[2 + 16 * ct + 4 * g + 0] * a1) * inv;
+                    v.y = (o[ct][4 * g + 1] * a0 + x[2 + 16 * ct + 4 * g + 1] * a1) * inv;
+                    v.z = (o[ct][4 * g + 2] * a0 + x[2 + 16 * ct + 4 * g + 2] * a1) * inv;
+                    v.w = (o[ct][4 * g + 3] * a0 + x[2 + 16 * ct + 4 * g + 3] * a1) * inv;
+                    *reinterpret_cast<float4 *>(orow + 32 * ct + 8 * g + 4 * lh) = v;
+                }
         }
     }
 }
@@ -216,29 +259,24 @@ int launch_layernorm(const float *in, int in_ld, float *out, int out_ld, int64_t
     return check_launch("k_layernorm");
 }
 
-template <int D, int QT> static int launch_attention_t(const float *qkv, int ld, float *out, int out_ld, int n, int N, int heads, const float *table,
-                                                       int gh, int gw, hipStream_t st) {
-    constexpr int kExchange = (4 / (D / 32) - 1) * (D / 32) * 32 * 33;        // floats of the partial-sum exchange area of phase 3
-    size_t lds = (size_t)QT * (((N + 31) & ~31) + 4) * sizeof(float);
-    if (lds < kExchange * sizeof(float)) lds = kExchange * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attention<D, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k_attention<D, QT><<<dim3((unsigned)((N + QT - 1) / QT), (unsigned)heads, (unsigned)n), 256, lds, st>>>(qkv, ld, out, out_ld, N, heads, table, gh, gw);
+template <int D> static int launch_attention_t(const float *qkv, int ld, float *out, int out_ld, int n, int N, int heads, const float *table, int gh,
+                                               int gw, hipStream_t st) {
+    constexpr int kTiles = 4 * 32 * (D + 4) + 64, kExchange = 2 * 64 * (16 * (D / 32) + 2);
+    const size_t lds = sizeof(float) * (size_t)(kTiles > kExchange ? kTiles : kExchange);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attention<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_attention<D><<<dim3((unsigned)((N + 63) / 64), (unsigned)heads, (unsigned)n), 256, lds, st>>>(qkv, ld, out, out_ld, N, heads, table, gh, gw);
     return check_launch("k_attention");
 }
 
 int launch_attention(const float *qkv, int ld, float *out, int out_ld, int n, int N, int heads, int d, const float *table, int gh, int gw,
                      hipStream_t st) {
-    if (N < 1 || N > 2496) { set_error("attention: 1 <= tokens <= 2496 (the score tile of a block lives in LDS), got %d", N); return CSM_ERR_ARG; }
-    if ((ld & 3) || (((uintptr_t)qkv) & 15)) { set_error("attention: qkv must be 16-byte aligned"); return CSM_ERR_ARG; }
+    if (N < 1) { set_error("attention: empty sequence"); return CSM_ERR_ARG; }
+    if ((ld & 3) || (out_ld & 3) || (((uintptr_t)qkv | (uintptr_t)out) & 15)) { set_error("attention: qkv / out must be 16-byte aligned"); return CSM_ERR_ARG; }
     if (table && gh * gw + 1 != N) { set_error("attention: relative position bias needs N == gh * gw + 1 (%d x %d vs %d)", gh, gw, N); return CSM_ERR_ARG; }
-    const bool wide = N <= 1216;
     switch (d) {
-        case 32: return wide ? launch_attention_t<32, 32>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st)
-                             : launch_attention_t<32, 16>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st);
-        case 64: return wide ? launch_attention_t<64, 32>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st)
-                             : launch_attention_t<64, 16>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st);
-        case 128: return wide ? launch_attention_t<128, 32>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st)
-                              : launch_attention_t<128, 16>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st);
+        case 32: return launch_attention_t<32>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st);
+        case 64: return launch_attention_t<64>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st);
+        case 128: return launch_attention_t<128>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st);
         default: set_error("attention: head dimension %d not built (32, 64, 128)", d); return CSM_ERR_ARG;
     }
 }

@@ -356,7 +356,7 @@ class Program:
         if rel_table is not None:
             rel_table = np.asarray(rel_table, np.float32)
             assert rel_table.shape == ((2 * gh - 1) * (2 * gw - 1) + 3, heads) and qkv.h == gh * gw + 1, (rel_table.shape, grid, qkv.h)
-            a_h, a_n = self._w(rel_table, rel_table)
+            a_h, a_n = self._w(np.ascontiguousarray(rel_table.T), rel_table)     # device: [heads][T] (a block reads one head's row)
         self.flops += 4 * qkv.n * heads * qkv.h * qkv.h * d
         return self._emit(OP_ATTENTION, qkv, None, out, groups=heads, cin_g=d, kh=gh, kw=gw, aux_off=a_h, nat=dict(aux_off=a_n))
 

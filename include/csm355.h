@@ -203,7 +203,8 @@ enum csm_op_kind {
                                class token, token 1 + y * kw + x the patch (y, x) of the kh x kw grid (N = kh * kw + 1); aux_off ->
                                table [(2 kh - 1) * (2 kw - 1) + 3][heads]: bias_h(i, j) = table[(yi - yj + kh - 1) * (2 kw - 1) + (xi - xj +
                                kw - 1)][h] between patches, rows T-3 / T-2 / T-1 for cls->patch / patch->cls / cls->cls (timm
-                               gen_relative_position_index); aux_off < 0: no bias (kh * kw + 1 == N still required when kh > 0) */
+                               gen_relative_position_index), stored HEAD-MAJOR ([heads][T]) in the device weight buffer; aux_off < 0:
+                               no bias.  Keys are streamed with a running max / sum: any sequence length */
     CSM_OP_TOKENS = 17,     /* token plumbing, mode = flags: 0 "assemble" in0 = patch embedding [n, gh, gw, c] -> out [n, gh*gw + 1, 1, c],
                                row 0 = class token (aux_off -> c floats); 1 "readout project input" in0 = tokens [n, N, 1, c] ->
                                out [n, kh, kw, 2c] = (token 1 + i | class token) (MiDaS ProjectReadout's concat); 2 "readout ignore"
