@@ -442,7 +442,6 @@ __device__ __forceinline__ void dma16(unsigned voff, i32x4 rsrc, unsigned lds_by
 
 template <int WM, int WN, int TM, int TN, int NS, bool SER = false, bool ILV = (CSM_ILV != 0)>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
-    static_assert(!SER || NS == 2, "the serial split-K walk is built for the two-stage pipeline");
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;          // DMA pieces (8 rows) per wave per chunk
@@ -584,7 +583,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
     // ILV (two-stage pipeline): the DMA pieces of the next chunk go out BETWEEN the MFMA groups of this one instead of in a burst behind
     // the barrier (see k_conv_dma_p); branch-free -- behind the last chunk the lanes are out of range and the DMA writes zeros into the
     // stage nobody reads any more
-    auto compute_ilv = [&](int stage, int chunk, bool live) {
+    auto compute_ilv = [&](int stage, int fill, int chunk, bool live) {
         if constexpr (SER) {
             if (chunk == next_b) {
 #pragma unroll
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         [&]<int... G>(std::integer_sequence<int, G...>) {
             ([&] {
                 constexpr int kb = G / 4, t = G % 4, buf = kb & 1;
-                if constexpr (G < GA + GB) { piece(std::integral_constant<int, G>{}, stage ^ 1, live); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (G < GA + GB) { piece(std::integral_constant<int, G>{}, fill, live); __builtin_amdgcn_sched_barrier(0); }
                 if constexpr (t == 1 && kb < 3) { rd(kb + 1, buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -624,14 +623,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         advance();
     };
 
-    if constexpr (NS == 2 && ILV && GA + GB <= 16) {
-        issue(0);
-        for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            compute_ilv(st, chunk, chunk + 1 < T);
+    if constexpr (ILV && GA + GB <= 16) {
+        // NS stages: while chunk c is multiplied, the pieces of chunk c + NS - 1 go out between its MFMA groups (into the stage chunk c - 1
+        // was read from), so a piece has NS - 2 further chunks to land in before it is waited for -- HBM / Infinity-Cache misses
+        // included.  Every step issues exactly GA + GB pieces (dead ones past the end), so the counted wait "at most (NS - 2)(GA + GB)
+        // outstanding" always means "the pieces of this chunk have landed" (loads retire in order).
+        for (int s0 = 0; s0 < NS - 1; ++s0) {
+            const bool live = c_begin + s0 < T;
+            [&]<int... P>(std::integer_sequence<int, P...>) { (piece(std::integral_constant<int, P>{}, s0, live), ...); }(std::make_integer_sequence<int, GA + GB>{});
+            advance();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetch must land before the block's LDS is released
+        for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st = (st + 1 == NS ? 0 : st + 1)) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((NS - 2) * (GA + GB)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            compute_ilv(st, st == 0 ? NS - 1 : st - 1, chunk, chunk + NS - 1 < T);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetches must land before the block's LDS is released
     } else if constexpr (NS == 2) {
         issue(0);
         for (int chunk = c_begin, st = 0; chunk < T; ++chunk, st ^= 1) {
@@ -2091,7 +2098,7 @@ int launch_conv_dma_t(const ConvArgs &a0, hipStream_t st) {
 
 template <int WM, int WN, int TM, int TN, int NS = 2>
 int launch_conv_dma(const ConvArgs &a, hipStream_t st) {
-    if constexpr (NS == 2)
+    if constexpr (NS == 2)        // (three- / four-stage tiles measured slower than two stages on every layer, also with interleaved issue: r04g)
         if (a.ksplit > 1 && a.serial) return launch_conv_dma_t<WM, WN, TM, TN, 2, true>(a, st);
     return launch_conv_dma_t<WM, WN, TM, TN, NS, false>(a, st);
 }
@@ -2602,7 +2609,8 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
             if (cand_all[c] >= CFG_Q64x64) {                                     // persistent blocks: layers that do not split K
                 if (cand_all[c] >= CFG_R128x32 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
             }
-            else if (cand_all[c] >= CFG_P64x64 && !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
+            else if (((cand_all[c] >= CFG_P64x64 && cand_all[c] <= CFG_P128x128_8w) || cand_all[c] == CFG_P256x64) &&
+                     !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
             if (cand_bn[c] == 4 && (op.cout_g > 4 || op.groups != 1 || op.ksplit > 1)) continue;
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
             if (cand_bn[c] == 32 && op.cout_g > 64 && (op.cout_g % 64) != 32) continue;   // (96, 160 ... outputs: 32-wide tiles waste no MFMA columns)
