@@ -1141,8 +1141,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
 // loader switches to the next tile and sends its first patch -- nine taps of MFMAs ahead of its use; the weights of the next tile's
 // first tap go out behind the barrier of the last tap.  Same chunks, same chain per output.  SER: the serial split-K walk of k_conv_patch
 // (runs combined in registers at the run boundaries); parallel split-K layers keep the one-tile-per-block kernel.
-template <int WM, int WN, int TM, int TN, int TW, bool SER = false, bool ILV = (CSM_ILV != 0)>
-__global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, int tiles_x, int tiles_y, int n_n, int total) {
+// MINW = waves per SIMD the register allocation must allow (launch bound): 4 caps the 8-wave 128 x 128 tile at 128 VGPRs, so that TWO
+// blocks (2 x 80 KB of LDS) share a CU instead of one
+template <int WM, int WN, int TM, int TN, int TW, bool SER = false, int MINW = 2, bool ILV = (CSM_ILV != 0)>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_patch_p(ConvArgs a, int tiles_x, int tiles_y, int n_n, int total) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
     constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
@@ -1225,10 +1227,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
     };
 
     int ppb[TM];
+    int abase[TM][3][4];                                        // (patch pixel of MFMA row li) * 32 + swizzled 16-B slot, per tap column kw and k-block
+    static_assert(TW == 16, "abase: the swizzle key of a 16-wide tile depends on the patch column only");
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         int rr = 32 * (TM * wm + i) + li;
         ppb[i] = (rr / TW) * PW + (rr % TW);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) abase[i][kw][kb] = ppb[i] * 32 + (((2 * kb + lh) ^ ((((rr % TW) + kw) >> 1) & 7)) << 2);
     }
     int swb[4];
 #pragma unroll
@@ -1331,16 +1339,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
                     // first, then the patch slice -- the counted vmcnt at the next barrier relies on it); see k_conv_dma_p
                     constexpr int NSL = tap < kPT ? ((tap + 1) * kPPT <= QP ? kPPT : QP - tap * kPPT) : 0;
                     static_assert(GB + kPPT <= 16, "one DMA piece per MFMA group");
-                    const float *SP = lds + ps * kPatchF;
+                    // fragment addresses = per-lane bases that do not depend on the tile (abase: 12 per accumulator row) + a tap constant + the
+                    // stage: the nine unrolled taps used to keep 72 precomputed addresses per accumulator row alive (187 - 233 VGPRs)
+                    constexpr int kh = tap / 3, kw = tap - 3 * kh, toff = kh * PW + kw;
+                    const float *SP = lds + ps * kPatchF + toff * 32;
                     const float *SB = lds + 2 * kPatchF + st * kBF;
-                    constexpr int kh = tap / 3, toff = kh * PW + (tap - 3 * kh);
-                    int arow[TM], asw[TM];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) { int pp = ppb[i] + toff; arow[i] = pp * 32; asw[i] = patch_key<PW, TW>(pp); }
                     float4 af[2][TM], bf[2][TN];
                     auto rd = [&](int kb, int buf) {
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) af[buf][i] = *reinterpret_cast<const float4 *>(SP + arow[i] + (((2 * kb + lh) ^ asw[i]) << 2));
+                        for (int i = 0; i < TM; ++i) af[buf][i] = *reinterpret_cast<const float4 *>(SP + abase[i][kw][kb]);
 #pragma unroll
                         for (int j = 0; j < TN; ++j) bf[buf][j] = *reinterpret_cast<const float4 *>(SB + rowB + j * 1024 + swb[kb]);
                     };
@@ -1403,6 +1410,175 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch_p(ConvArgs a, in
                     a.out.p[m * a.out.ld + cout_off + nn] = v;
                 }
             }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetches must land before the block's LDS is released
+}
+
+// ---- weights-stationary 3x3 convolution (stride 1, dilation 1, one K run): the block's WEIGHT PANEL stays in LDS --------------------------
+// k_conv_patch(_p) stream a weight tile per tap: one barrier and GB DMA pieces every tap, although a layer with few input channels has
+// very little weight data -- all nine taps x all channel blocks of a 32-wide column tile are 36.9 KB at 32 input channels and 73.7 KB at 64
+// (ISNet / RTMDet 32- and 64-channel stages, the 32-channel groups of ResNeXt, the Ken Burns GridNets).  Here a persistent block of eight
+// waves loads its column tile's panel ONCE, then walks 16 x 16 output tiles: only the (18 x 18 x 32-channel) input patch of the next
+// (tile, channel block) streams, double-buffered, its DMA pieces interleaved with the MFMAs of taps 0 .. 2, and the only barrier left is the
+// one per (tile, channel block) that publishes a patch -- 144 MFMAs per wave between barriers instead of 16, a quarter of the DMA volume.
+// Wave w owns output rows 2w, 2w + 1 of the tile (32 pixels) x all 32 TN columns.  Same chunks, same chain per output as every other
+// configuration (block-major: channel block outer, taps row-major inner).  Column tile = (group, N tile): grouped convolutions with
+// 32-channel groups are the case "one channel block, one N tile per group".  Blocks of one XCD with consecutive ids work on the same M tiles
+// for different column tiles, so the second reader of a patch finds it in that XCD's L2.
+template <int TN>
+__global__ __launch_bounds__(512, 2) void k_conv_ws(ConvArgs a, int tiles_x, int tiles_y, int n_n, int n_ct) {
+    constexpr int NW = 8, TW = 16, TH = 16, BN = 32 * TN;
+    constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NPP = (NPIX + 7) / 8, QP = (NPP + NW - 1) / NW;
+    constexpr int kPatchF = (NPP + 1) * 8 * 32;                 // floats per patch stage: NPP pieces + one dump slot for the surplus pieces of the last round
+    constexpr unsigned kOob = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [patch 0][patch 1][weight panel: chunk][BN rows][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int ho = a.out.h, wo = a.out.w, ncb = a.ncb, Tall = 9 * ncb;
+    // block -> (XCD x, column tile ct, position i0 among the `per` blocks of that column tile on this XCD)
+    const int x = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
+    const int ct = slot % n_ct, i0 = slot / n_ct, per = (int)(gridDim.x >> 3) / n_ct;
+    const int total = a.m_tiles, q = total >> 3, r = total & 7;
+    const int start = x * q + (x < r ? x : r), len = q + (x < r ? 1 : 0);
+    const int g = ct / n_n, n0 = (ct - g * n_n) * BN, cin_off = g * a.cin_g, cout_off = g * a.cout_g, per_img = tiles_x * tiles_y;
+    if (i0 >= len) return;
+
+    i32x4 ra, rb;
+    {
+        uint64_t pa = (uint64_t)a.in.p, pb = (uint64_t)a.w;
+        unsigned na = (unsigned)((((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4);
+        unsigned nb = (unsigned)((int64_t)a.groups * Tall * a.npad * 128);
+        ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
+        rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned ldsW = lds0 + (unsigned)(2 * kPatchF * 4);
+    // ---- the weight panel, once: piece p = 8 rows of chunk p / (BN / 8); rows beyond the layer's padded width come in as zeros
+    {
+        const int npieces = Tall * (BN / 8);
+        const unsigned wbase = (unsigned)((int64_t)g * Tall * a.npad * 128);
+        for (int p = wave; p < npieces; p += NW) {
+            const int c = p / (BN / 8), row = 8 * (p - c * (BN / 8)) + (lane >> 3);
+            const int sl = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned off = n0 + row < a.npad ? wbase + (unsigned)(((c * a.npad + n0 + row) * 32 + sl * 4) * 4) : kOob;
+            dma16(off, rb, ldsW + (unsigned)p * 1024u);
+        }
+    }
+    // ---- patch loader (tile being fetched): wave w owns pieces w, w + NW, ...; lane -> patch pixel 8 * piece + lane / 8, physical slot lane % 8
+    unsigned offP[QP];
+    auto patch_setup = [&](int k, bool live) {
+        const int mt = start + k;
+        const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, n = mt / per_img;
+        const int iy0 = ty * TH - a.pad, ix0 = tx * TW - a.pad;
+#pragma unroll
+        for (int qq = 0; qq < QP; ++qq) {
+            int pp = 8 * (wave + qq * NW) + (lane >> 3);
+            int sl = (lane & 7) ^ patch_key<PW, TW>(pp);
+            int py = pp / PW, px = pp - py * PW;
+            int iy = iy0 + py, ix = ix0 + px;
+            bool v = live && pp < NPIX && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+            offP[qq] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + cin_off + sl * 4) * 4u : kOob;
+        }
+    };
+    auto patch_piece = [&](auto QC, int cb, int pstage) {
+        constexpr int qq = decltype(QC)::value;
+        const int piece = wave + qq * NW;
+        dma16(offP[qq] == kOob ? kOob : offP[qq] + (unsigned)cb * 128u, ra,
+              lds0 + (unsigned)pstage * (unsigned)(kPatchF * 4) + (unsigned)(piece < NPP ? piece : NPP) * 1024u);
+    };
+    int abase[3][4];                                            // (patch pixel of MFMA row li) * 32 + swizzled 16-B slot, per tap column and k-block
+    {
+        const int rr = 32 * wave + li;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) abase[kw][kb] = ((rr / TW) * PW + (rr % TW)) * 32 + (((2 * kb + lh) ^ ((((rr % TW) + kw) >> 1) & 7)) << 2);
+    }
+    int swb[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) swb[kb] = li * 32 + ((2 * kb + lh) ^ ((li >> 1) & 7)) * 4;
+    f32x16 acc[TN];
+
+    patch_setup(i0, true);
+    [&]<int... Q>(std::integer_sequence<int, Q...>) { (patch_piece(std::integral_constant<int, Q>{}, 0, 0), ...); }(std::make_integer_sequence<int, QP>{});
+    int ps = 0;
+    for (int k = i0; k < len; k += per) {
+        const int mt = start + k;
+        const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, n = mt / per_img;
+        const int kn = k + per;
+        const bool more = kn < len;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nn = n0 + 32 * j + li;
+            const float b = (a.bias && nn < a.cout_g) ? a.bias[cout_off + nn] : 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) acc[j][rr] = b;
+        }
+        for (int cb = 0; cb < ncb; ++cb, ps ^= 1) {
+            const bool last_cb = cb + 1 == ncb;
+            // this (tile, channel block)'s patch has landed (every wave waits for its own pieces, then the barrier), and everybody has finished
+            // reading the other stage (its fragment reads have completed: lgkmcnt) -- it is refilled below
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (last_cb) patch_setup(more ? kn : k, more);
+            const int ncbo = last_cb ? 0 : cb + 1;
+            const float *SW = lds + 2 * kPatchF + (cb * 9) * (BN * 32);
+            auto tapf = [&](auto TAPC) {
+                constexpr int tap = decltype(TAPC)::value, kh = tap / 3, kw = tap - 3 * kh;
+                const float *SP = lds + ps * kPatchF + (kh * PW + kw) * 32;
+                const float *SB = SW + tap * (BN * 32);
+                float4 af[2], bf[2][TN];
+                auto rd = [&](int kb, int buf) {
+                    af[buf] = *reinterpret_cast<const float4 *>(SP + abase[kw][kb]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[buf][j] = *reinterpret_cast<const float4 *>(SB + j * 1024 + swb[kb]);
+                };
+                rd(0, 0);
+                [&]<int... G>(std::integer_sequence<int, G...>) {
+                    ([&] {
+                        constexpr int kb = G / 4, t = G % 4, buf = kb & 1;
+                        // the next patch goes out four pieces per tap (behind MFMA groups 0, 4, 8, 12 of taps 0, 1, ...)
+                        if constexpr (t == 0 && 4 * tap + kb < QP) { patch_piece(std::integral_constant<int, 4 * tap + kb>{}, ncbo, ps ^ 1); __builtin_amdgcn_sched_barrier(0); }
+                        if constexpr (t == 1 && kb < 3) { rd(kb + 1, buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float av = t == 0 ? af[buf].x : (t == 1 ? af[buf].y : (t == 2 ? af[buf].z : af[buf].w));
+                            const float bv = t == 0 ? bf[buf][j].x : (t == 1 ? bf[buf][j].y : (t == 2 ? bf[buf][j].z : bf[buf][j].w));
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }(), ...);
+                }(std::make_integer_sequence<int, 16>{});
+            };
+            static_assert(QP <= 36, "the patch pieces must fit the nine taps");
+            tapf(std::integral_constant<int, 0>{}); tapf(std::integral_constant<int, 1>{}); tapf(std::integral_constant<int, 2>{});
+            tapf(std::integral_constant<int, 3>{}); tapf(std::integral_constant<int, 4>{}); tapf(std::integral_constant<int, 5>{});
+            tapf(std::integral_constant<int, 6>{}); tapf(std::integral_constant<int, 7>{}); tapf(std::integral_constant<int, 8>{});
+        }
+        // epilogue: lane holds column li of each 32-wide column tile, tile pixels 32 wave + (r & 3) + 8 (r >> 2) + 4 lh
+        float slope[TN]; int ncol[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            ncol[j] = n0 + 32 * j + li;
+            slope[j] = (a.slope && ncol[j] < a.cout_g) ? a.slope[cout_off + ncol[j]] : 0.0f;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int rrow = 32 * wave + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            const int oy = ty * TH + rrow / TW, ox = tx * TW + rrow % TW;
+            if (oy >= ho || ox >= wo) continue;
+            const int64_t m = ((int64_t)n * ho + oy) * wo + ox;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nn = ncol[j];
+                if (nn >= a.cout_g) continue;
+                float v = acc[j][rr];
+                if (a.res_mode == 1) v += a.res.p[m * a.res.ld + cout_off + nn];
+                v = apply_act(v, a.act, slope[j]);
+                if (a.res_mode == 2) v += a.res.p[m * a.res.ld + cout_off + nn];
+                a.out.p[m * a.out.ld + cout_off + nn] = v;
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetches must land before the block's LDS is released
 }
@@ -2156,7 +2332,7 @@ int launch_conv_patch(const ConvArgs &a, hipStream_t st) {
     return launch_conv_patch_t<WM, WN, TM, TN, TW, false>(a, st);
 }
 
-template <int WM, int WN, int TM, int TN, int TW, bool SER>
+template <int WM, int WN, int TM, int TN, int TW, bool SER, int MINW = 2>
 int launch_conv_patch_p_t(const ConvArgs &a0, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, TH = BM / TW;
     constexpr int NW = WM * WN, NPP = ((((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW) * NW;
@@ -2166,22 +2342,47 @@ int launch_conv_patch_p_t(const ConvArgs &a0, hipStream_t st) {
     a.ngroup = choose_ngroup(a, BN);
     const size_t lds = ((size_t)2 * NPP * 8 * 32 + (size_t)2 * BN * 32) * 4;
     static KernelPrep prep;
-    const int blocks_per_cu = prep.ensure([&] { return prepare_kernel(&k_conv_patch_p<WM, WN, TM, TN, TW, SER>, 64 * WM * WN, lds); });
+    const int blocks_per_cu = prep.ensure([&] { return prepare_kernel(&k_conv_patch_p<WM, WN, TM, TN, TW, SER, MINW>, 64 * WM * WN, lds); });
     const int n_n = (a.cout_g + BN - 1) / BN;
     const int64_t total = (int64_t)a.m_tiles * n_n * a.groups;
     if (total >= (1ll << 30)) return launch_conv_patch<WM, WN, TM, TN, TW>(a0, st);
     int64_t grid = 256ll * blocks_per_cu;
     if (grid > ((total + 7) & ~7ll)) grid = (total + 7) & ~7ll;
-    k_conv_patch_p<WM, WN, TM, TN, TW, SER><<<(unsigned)grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y, n_n, (int)total);
+    k_conv_patch_p<WM, WN, TM, TN, TW, SER, MINW><<<(unsigned)grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y, n_n, (int)total);
     return csm::check_launch("k_conv_patch_p");
 }
-template <int WM, int WN, int TM, int TN, int TW>
+template <int WM, int WN, int TM, int TN, int TW, int MINW = 2>
 int launch_conv_patch_p(const ConvArgs &a, hipStream_t st) {
     if (a.ksplit > 1) {
-        if (a.serial && a.groups == 1) return launch_conv_patch_p_t<WM, WN, TM, TN, TW, true>(a, st);
+        if (a.serial && a.groups == 1) return launch_conv_patch_p_t<WM, WN, TM, TN, TW, true, MINW>(a, st);
         return launch_conv_patch<WM, WN, TM, TN, TW>(a, st);                   // parallel split-K: one tile per block + reduce
     }
-    return launch_conv_patch_p_t<WM, WN, TM, TN, TW, false>(a, st);
+    return launch_conv_patch_p_t<WM, WN, TM, TN, TW, false, MINW>(a, st);
+}
+
+// weights-stationary launch: one round of blocks, 8 XCDs x (column tiles x `per` blocks), every block keeps ITS column tile's weight panel
+constexpr int kWsPatchBytes = 2 * (((16 + 2) * (16 + 2) + 7) / 8 + 1) * 1024;      // two patch stages of k_conv_ws
+static bool ws_fits(const ConvArgs &a, int BN) {
+    return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil == 1 && a.ksplit <= 1 && a.m_begin == 0 && (a.cin_g & 31) == 0 &&
+           (size_t)kWsPatchBytes + (size_t)9 * a.ncb * BN * 128 <= (size_t)160 * 1024;
+}
+template <int TN>
+int launch_conv_ws(const ConvArgs &a0, hipStream_t st) {
+    constexpr int BN = 32 * TN;
+    ConvArgs a = a0;
+    const int tiles_x = (a.out.w + 15) / 16, tiles_y = (a.out.h + 15) / 16;
+    a.m_tiles = tiles_x * tiles_y * a.out.n;
+    const int n_n = (a.cout_g + BN - 1) / BN, n_ct = a.groups * n_n;
+    const size_t lds = (size_t)kWsPatchBytes + (size_t)9 * a.ncb * BN * 128;
+    static KernelPrep prep;
+    (void)prep.ensure([&] { return prepare_kernel(&k_conv_ws<TN>, 512, (size_t)160 * 1024); });
+    // 32 CUs per XCD, one block per CU: `per` blocks share a column tile's M range on an XCD (at least one; never more than it has tiles)
+    int per = 32 / n_ct;
+    if (per < 1) per = 1;
+    const int len_max = (a.m_tiles + 7) / 8;
+    if (per > len_max) per = len_max;
+    k_conv_ws<TN><<<(unsigned)(8 * n_ct * per), 512, lds, st>>>(a, tiles_x, tiles_y, n_n, n_ct);
+    return csm::check_launch("k_conv_ws");
 }
 
 static bool narrow_eligible(const ConvArgs &a) {
@@ -2219,7 +2420,11 @@ enum { CFG_128x128_4w = 0, CFG_128x64 = 1, CFG_64x64 = 2, CFG_128x128_8w = 3, CF
        CFG_Q64x64 = 38, CFG_Q128x64 = 39, CFG_Q64x128 = 40, CFG_Q128x128_8w = 41, CFG_Q128x32 = 42,
        // persistent patch kernel (k_conv_patch_p): the next tile's patch is fetched during the current tile's taps
        CFG_R128x32 = 43, CFG_R64x64 = 44, CFG_R128x64 = 45, CFG_R128x32_w8 = 46, CFG_R128x128_8w = 47, CFG_R64x128 = 48, CFG_R64x64_w8 = 49,
-       CFG_COUNT = 50 };
+       // the 8-wave persistent patch tile capped at 128 VGPRs: two blocks per CU
+       CFG_R128x128_8w_o4 = 50,
+       // weights-stationary 3x3 (k_conv_ws): 16 x 16 pixel tiles x 32 / 64 output channels, the column tile's whole weight panel in LDS
+       CFG_W256x32 = 51, CFG_W256x64 = 52,
+       CFG_COUNT = 53 };
 static int g_force_cfg = -1;
 static int g_force_serial = -1;    // tests: -1 = rule / tuned, 0 = parallel split-K, 1 = serial split-K
 static int g_tune_split = 1;       // tuner: consider mixed-tile launches (csm_debug_conv_tuner_options)
@@ -2297,6 +2502,9 @@ static int launch_conv_cfg(int cfg, const ConvArgs &a, hipStream_t st) {
         case CFG_R128x32_w8: return launch_conv_patch_p<4, 1, 1, 1, 16>(a, st);     // (the 8-wide persistent tiles were dropped, see CFG_R64x64_w8)
         case CFG_R128x128_8w: return launch_conv_patch_p<2, 4, 2, 1, 16>(a, st);
         case CFG_R64x128: return launch_conv_patch_p<2, 2, 1, 2, 16>(a, st);
+        case CFG_R128x128_8w_o4: return launch_conv_patch_p<2, 4, 2, 1, 16, 4>(a, st);
+        case CFG_W256x32: return launch_conv_ws<1>(a, st);
+        case CFG_W256x64: return launch_conv_ws<2>(a, st);
         // (the 8-wide persistent tiles: where the LDS-read / barrier hazard of the unrolled taps showed; found by tools/check_persistent.py,
         // fixed in k_conv_patch_p, the variants themselves stay out)
         case CFG_R64x64_w8: return launch_conv_patch_p<2, 2, 1, 1, 16>(a, st);
@@ -2367,6 +2575,7 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 a.serial = a.ksplit > 1 && (g_force_serial >= 0 ? g_force_serial != 0 : tuned ? (op.tile & kTileSerial) != 0
                                             : (int64_t)((a.M + 63) / 64) * ((op.cout_g + 63) / 64) >= 512);
                 int cfg = tuned ? tcfg - 1 : choose_cfg(a, op.cout_g);
+                if ((cfg == CFG_W256x32 || cfg == CFG_W256x64) && !(patch_eligible(a) && ws_fits(a, cfg == CFG_W256x32 ? 32 : 64))) cfg = CFG_R64x64;
                 if (((cfg >= CFG_P64x64 && cfg <= CFG_P128x128_8w) || cfg == CFG_P256x64 || cfg >= CFG_R128x32) && !patch_eligible(a)) cfg = CFG_D64x64;
                 if (cfg == CFG_NARROW && !narrow_eligible(a)) cfg = CFG_64x16;
                 if (cfg >= CFG_D64x64 && cfg != CFG_NARROW && !dma_eligible(a)) cfg = op.cout_g <= 16 ? CFG_64x16 : (op.cout_g <= 32 ? CFG_128x32 : CFG_64x64);
@@ -2562,11 +2771,12 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
                                        CFG_D224x128, CFG_D192x128, CFG_P64x64, CFG_P128x64, CFG_P64x128, CFG_P128x128, CFG_P256x128,
                                        CFG_P128x32, CFG_P64x64_w8, CFG_P128x128_w8, CFG_P128x32_w8, CFG_P128x128_8w,
                                        CFG_Q64x64, CFG_Q128x64, CFG_Q64x128, CFG_Q128x128_8w, CFG_Q128x32,
-                                       CFG_R128x32, CFG_R64x64, CFG_R128x64, CFG_R128x128_8w, CFG_R64x128};
+                                       CFG_R128x32, CFG_R64x64, CFG_R128x64, CFG_R128x128_8w, CFG_R64x128, CFG_R128x128_8w_o4,
+                                       CFG_W256x32, CFG_W256x64};
         static const int cand_bn[] = {64, 32, 16, 64, 64, 128, 128, 128, 128, 32, 4, 128, 128, 128, 128,
                                       64, 64, 128, 128, 128, 32, 64, 128, 32, 128,
                                       64, 64, 128, 128, 32,
-                                      32, 64, 64, 128, 128};
+                                      32, 64, 64, 128, 128, 128, 32, 64};
         // identical layers (same shapes / strides / split) share one measurement, also across programs
         View vin{}, vout{};
         rc = make_view(tensors, n_tensors, op.in0, workspace, ext, n_ext, vin); if (rc) break;
@@ -2611,6 +2821,9 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
             }
             else if (((cand_all[c] >= CFG_P64x64 && cand_all[c] <= CFG_P128x128_8w) || cand_all[c] == CFG_P256x64) &&
                      !(op.kh == 3 && op.kw == 3 && op.stride == 1 && op.dil == 1)) continue;
+            if ((cand_all[c] == CFG_W256x32 || cand_all[c] == CFG_W256x64) &&
+                (op.ksplit > 1 || (op.cin_g & 31) || (size_t)kWsPatchBytes + (size_t)9 * ((op.cin_g + 31) / 32) * cand_bn[c] * 128 > (size_t)160 * 1024 ||
+                 op.groups * ((op.cout_g + cand_bn[c] - 1) / cand_bn[c]) > 64)) continue;
             if (cand_bn[c] == 4 && (op.cout_g > 4 || op.groups != 1 || op.ksplit > 1)) continue;
             if (cand_bn[c] == 16 && op.cout_g > 16) continue;
             if (cand_bn[c] == 32 && op.cout_g > 64 && (op.cout_g % 64) != 32) continue;   // (96, 160 ... outputs: 32-wide tiles waste no MFMA columns)

@@ -142,6 +142,7 @@ FULL_SIZE_LAYERS = [
     (1, 160, 160, 128, 256, 3, 2, 1, 1),     # CSPNeXt stride-2 stage conv
     (1, 333, 517, 32, 32, 3, 1, 1, 1),       # GridNet-like 32 -> 32 on a ragged frame: several tiles per persistent block, M tail
     (4, 80, 80, 32, 96, 1, 1, 1, 1),         # one-chunk 1x1 (every chunk is a tile's last), ragged N
+    (2, 120, 104, 64, 96, 3, 1, 1, 1),       # 64 input channels (two channel blocks), ragged 16 x 16 tiles and N: the weights-stationary kernel
 ]
 
 
@@ -172,7 +173,7 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
     L = _lib.load()
     ref, names = None, {}
     try:
-        for cfg in list(range(28)) + list(range(38, 50)):       # 38..49: the persistent-block kernels (fall back when K is split / not a 3x3)
+        for cfg in list(range(28)) + list(range(38, 53)):       # 38..49: the persistent-block kernels (fall back when K is split / not a 3x3)
             L.csm_debug_force_conv_cfg(cfg)
             cp.run()
             out = cp.read_view(y).cpu().numpy()
@@ -213,8 +214,8 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
             assert np.array_equal(tot, ref[0, oy, ox]), "fmaf chain mismatch at (%d,%d): %g" % (oy, ox, np.abs(tot - ref[0, oy, ox]).max())
 
 
-# LDS-DMA tile configurations (include/csm355.h `tile`): plain 6-12 / 14-17 / 28-37, 3x3 patch 18-27 / 36, persistent 38-49
-DMA_CFGS = [c for c in range(6, 50) if c != 13]
+# LDS-DMA tile configurations (include/csm355.h `tile`): plain 6-12 / 14-17 / 28-37, 3x3 patch 18-27 / 36, persistent 38-50, weights-stationary 51-52
+DMA_CFGS = [c for c in range(6, 53) if c != 13]
 
 
 def test_dma_kernels_repeated_runs_are_bitwise_stable():

@@ -44,7 +44,7 @@ for o in prog.ops:
         return cp.read_view(y).clone()
     ref = run(6, 0)
     res = []
-    for cfg in range(38, 50):
+    for cfg in range(38, 53):
         out = run(cfg, 1)
         for _ in range(int(os.environ.get('REPS', '1')) - 1):
             o2 = run(cfg, 1)
