@@ -23,6 +23,8 @@ LAYERS = [
     # 26..: the GridNet of the point-cloud inpainting at 1024^2 (per pass)
     (11, 1, 1024, 1024, 32, 32, 3, 1, 1, 1), (2, 1, 1024, 1024, 64, 32, 3, 1, 1, 1), (10, 1, 512, 512, 64, 64, 3, 1, 1, 1),
     (1, 16, 360, 360, 64, 32, 3, 1, 1, 1),
+    # 30..: ISNet's narrow layers (side outputs, the 16-channel stage) and LeReS's last conv
+    (1, 16, 360, 360, 64, 1, 3, 1, 1, 1), (1, 16, 180, 180, 64, 1, 3, 1, 1, 1), (1, 16, 360, 360, 64, 16, 3, 1, 1, 1), (1, 8, 320, 320, 128, 1, 3, 1, 1, 1),
 ]
 CFGS = [int(c) for c in os.environ.get('CFGS', '').split()]
 DBG = int(os.environ.get('DBG', '0'))
