@@ -6,14 +6,16 @@ OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
 export CSM_TUNE_CACHE=/tmp/csm_tiles.txt   # first bench run tunes + saves; the profiled runs reuse the tiles (no tuning launches)
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $OUT/pytest_gpu.log; tail -2 $OUT/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $OUT/pytest_gpu.log; tail -2 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $OUT/smoke.log
-timeout 600 python bench.py 2>/dev/null | tail -1 > $OUT/bench_frame.json; head -c 400 $OUT/bench_frame.json; echo
+timeout 900 python bench.py 2>/dev/null | tail -1 > $OUT/bench_frame.json; head -c 400 $OUT/bench_frame.json; echo
 timeout 300 python bench.py --workload warp --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_warp.json; head -c 300 $OUT/bench_warp.json; echo
 timeout 300 python tools/layer_profile.py 2>/dev/null > $OUT/layer_profile.txt; grep "^==" $OUT/layer_profile.txt
 LP_BATCH=8 timeout 300 python tools/layer_profile.py 2>/dev/null > $OUT/layer_profile_b8.txt; grep "^==" $OUT/layer_profile_b8.txt
 timeout 200 python tools/video_breakdown.py 2>/dev/null | grep rep > $OUT/video_breakdown.txt; cat $OUT/video_breakdown.txt
 timeout 100 python tools/time_autozoom.py 1024 2>/dev/null | grep autozoom | head -1 > $OUT/autozoom.txt; cat $OUT/autozoom.txt
+(timeout 200 python tools/zoe_core_profile.py 672 672; timeout 200 python tools/zoe_core_profile.py 384 512) 2>/dev/null > $OUT/zoe_core_profile.txt; cat $OUT/zoe_core_profile.txt
+python tools/check_isa_barriers.py > $OUT/isa_barriers.txt 2>&1; cat $OUT/isa_barriers.txt
 [ "$2" = "quick" ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 RP="timeout 200 rocprofv3 --kernel-trace --stats --output-format csv"
@@ -68,4 +70,6 @@ traffic["_note"]="HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH
 json.dump(traffic, open("$OUT/traffic.json","w"), indent=1)
 for k,v in sorted(tr.items(), key=lambda kv:-kv[1].get("fetch_KB",0))[:16]: print(k, v)
 PY
+# pipe-utilisation counters (SQ / LDS / L2) of the kernels that carry the conv time + the warp render pass: one table
+bash /root/repo/tools/gpu/r04b.sh > $OUT/pmc_sq.log 2>&1; python /root/repo/tools/pmc_table.py /root/repo/gpurun_out/r04b/summary.txt > $OUT/conv_pmc.txt 2>&1; cat $OUT/conv_pmc.txt
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +1M -delete; find $OUT -name "*agent_info.csv" -delete
