@@ -53,6 +53,14 @@ __device__ __forceinline__ unsigned xcd_id() {
 // Before a block takes its ticket its counts must have been PERFORMED (they are atomic read-modify-writes, read back by the last block
 // with coherent atomic loads: single-location coherence needs no cache maintenance, only completion -- on gfx9 vmcnt covers atomics
 // and stores).  A full __threadfence() here is a buffer_wbl2 per block: 256 write-backs of the L2 made each pass 35 us long.
+// This hand-off is an ARCHITECTURE contract, not a language one: it holds on gfx9-family targets where device-scope atomic
+// read-modify-writes execute at the memory side of the XCD L2s and are counted by vmcnt; the library is built for gfx950 only and refuses
+// anything else at compile time.  The per-stream tables must be all-zero on entry: the last block re-zeroes them with plain stores, and
+// every public entry point that uses them runs to completion or reports a launch error before touching them again (a device fault
+// aborts the context anyway).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "frametail.hip's last-block hand-off (s_waitcnt vmcnt(0) before a relaxed ticket atomic, HW_REG_XCC_ID) is validated for gfx950 only"
+#endif
 __device__ __forceinline__ void counts_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // sum of one bin over the XCD copies of a table (`tab` = copy 0, copies kXcdStride words apart)
 __device__ __forceinline__ unsigned ld_bin(const unsigned *tab, int64_t stride, unsigned bin) {

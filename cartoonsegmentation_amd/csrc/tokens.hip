@@ -6,6 +6,7 @@
 // The attention kernel streams the keys with a running max / sum (no N x N matrix): see k_attention.
 #include "csm_common.h"
 #include "csm_tokens.h"
+#include <utility>
 
 namespace {
 
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ in,
 //                 pairs the keys of register r in the two lane halves): P never goes through LDS.
 // 64 MFMAs per wave and tile, none wasted.  Reductions are tolerance-level against the oracle (see the header).
 template <int D>
-__global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv, int ld, float *__restrict__ out, int out_ld, int N, int heads,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_attention(const float *__restrict__ qkv, int ld, float *__restrict__ out, int out_ld, int N, int heads,
                                                    const float *__restrict__ table /* [heads][T] or null */, int gh, int gw) {
     constexpr int NCT = D / 32, PITCH = D + 4, TILE = 32 * PITCH;       // floats of one staged K or V tile
     extern __shared__ __attribute__((aligned(16))) float lds[];          // [half][K tile | V tile] then [half][32] key terms of the bias index
@@ -100,15 +101,34 @@ __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv
     float m_run = -3.0e38f, l_run = 0.0f;
 
     const int NT = (N + 31) >> 5, half = (NT + 1) >> 1;
+    // the K / V tiles of iteration it + 1 are fetched into registers BEFORE the MFMAs of iteration it (their round trip runs under the
+    // compute) and stored to LDS behind the barrier that ends it: per thread 2 halves x (K + V) x 32 x D / 4 / 256 float4
+    constexpr int NPF = 2 * 32 * (D / 4) / 256;
+    float4 pk[NPF], pv[NPF];
+    auto prefetch = [&](int itn) {              // (constant indices through a pack expansion: a plain unrolled loop left pk / pv in scratch)
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ([&] {
+                constexpr int e_ = U * 256;
+                const int e = tid + e_;
+                const int hs = e / (32 * (D / 4)), rem = e - hs * (32 * (D / 4)), row = rem / (D / 4), c4 = rem - row * (D / 4);
+                const int key = min((hs * half + itn) * 32 + row, N - 1);
+                pk[U] = *reinterpret_cast<const float4 *>(K + (int64_t)key * ld + 4 * c4);
+                pv[U] = *reinterpret_cast<const float4 *>(V + (int64_t)key * ld + 4 * c4);
+            }(), ...);
+        }(std::make_integer_sequence<int, NPF>{});
+    };
+    prefetch(0);
     for (int it = 0; it < half; ++it) {
         // ---- stage the two halves' K and V tiles (rows beyond N repeat row N - 1: finite values, their probabilities are forced to 0)
         __syncthreads();                                                // everybody is done with the previous tiles
-        for (int e = tid; e < 2 * 32 * (D / 4); e += 256) {
-            const int hsel = e / (32 * (D / 4)), rem = e - hsel * (32 * (D / 4)), row = rem / (D / 4), c4 = rem - row * (D / 4);
-            const int key = min((hsel * half + it) * 32 + row, N - 1);
-            *reinterpret_cast<float4 *>(lds + 2 * hsel * TILE + row * PITCH + 4 * c4) = *reinterpret_cast<const float4 *>(K + (int64_t)key * ld + 4 * c4);
-            *reinterpret_cast<float4 *>(lds + (2 * hsel + 1) * TILE + row * PITCH + 4 * c4) = *reinterpret_cast<const float4 *>(V + (int64_t)key * ld + 4 * c4);
-        }
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ([&] {
+                const int e = tid + U * 256;
+                const int hsel = e / (32 * (D / 4)), rem = e - hsel * (32 * (D / 4)), row = rem / (D / 4), c4 = rem - row * (D / 4);
+                *reinterpret_cast<float4 *>(lds + 2 * hsel * TILE + row * PITCH + 4 * c4) = pk[U];
+                *reinterpret_cast<float4 *>(lds + (2 * hsel + 1) * TILE + row * PITCH + 4 * c4) = pv[U];
+            }(), ...);
+        }(std::make_integer_sequence<int, NPF>{});
         if (tid < 64) {
             const int j = ((tid >> 5) * half + it) * 32 + (tid & 31);
             int kt = 0;
@@ -116,8 +136,9 @@ __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv
             kterm[tid] = kt;
         }
         __syncthreads();
+        prefetch(min(it + 1, half - 1));
         const int tile = kh * half + it;
-        if (tile >= NT || (kh == 1 && tile < half)) continue;           // (odd tile counts: the second half has one tile fewer)
+        if (tile >= NT) continue;                                       // (odd tile counts: the second half has one tile fewer)
         const float *Kt = lds + 2 * kh * TILE, *Vt = Kt + TILE;
         // ---- s^T = K q^T
         f32x16 sacc;

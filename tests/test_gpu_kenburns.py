@@ -620,3 +620,25 @@ def test_fused_frame_call_equals_the_separate_calls():
             b.frame_into(got, pts, rgb, dep, sc['focal'], sc['baseline'], shift, ph, pw, W / 2.0, H / 2.0, dof)
             b.frame_into(got, pts, rgb, dep, sc['focal'], sc['baseline'], shift, ph, pw, W / 2.0, H / 2.0, dof)     # scratch re-arms itself
             assert torch.equal(got, want), (dof, shift)
+
+
+def test_frame_lanes_collect_every_result_before_raising():
+    """FrameLanes.map: an item that raises does not leave the other results of the call in the queue for the next call, and the
+    tensors it hands over are registered with the caller's stream"""
+    from cartoonsegmentation_amd.lanes import FrameLanes
+
+    def make_worker(i):
+        def fn(item):
+            if item == 'boom':
+                raise ValueError('boom')
+            return {'v': torch.full((1024,), float(item), device='cuda'), 'lane': i}
+        return fn
+    fl = FrameLanes(make_worker, lanes=2)
+    try:
+        with pytest.raises(ValueError):
+            fl.map([1, 'boom', 3, 4, 5])
+        out = fl.map([5, 6, 7])
+        assert [float(o['v'][0]) for o in out] == [5.0, 6.0, 7.0] and [o['lane'] for o in out] == [0, 1, 0]
+        assert float(sum(o['v'].sum() for o in out)) == 1024.0 * 18
+    finally:
+        fl.close()
