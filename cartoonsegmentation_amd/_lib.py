@@ -48,6 +48,8 @@ def load():
         _lib.csm_kenburns_frame_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_det_decode_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_mean_std_scratch_bytes.restype = ctypes.c_size_t
+        if os.environ.get("CSM_TUNER_OPTIONS"):          # measurement aid (A/B of launch forms, include/csm355.h csm_debug_conv_tuner_options); speed only
+            _lib.csm_debug_conv_tuner_options(int(os.environ["CSM_TUNER_OPTIONS"]))
     return _lib
 
 

@@ -104,16 +104,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // the K / V tiles of iteration it + 1 are fetched into registers BEFORE the MFMAs of iteration it (their round trip runs under the
     // compute) and stored to LDS behind the barrier that ends it: per thread 2 halves x (K + V) x 32 x D / 4 / 256 float4
     constexpr int NPF = 2 * 32 * (D / 4) / 256;
-    float4 pk[NPF], pv[NPF];
-    auto prefetch = [&](int itn) {              // (constant indices through a pack expansion: a plain unrolled loop left pk / pv in scratch)
+    // (native vectors: HIP's float4 is a struct, its global -> private -> LDS copies stay memcpys that SROA does not split, and the
+    // arrays end up in scratch)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 pk[NPF], pv[NPF];
+    auto prefetch = [&](int itn) __attribute__((always_inline)) {
         [&]<int... U>(std::integer_sequence<int, U...>) {
             ([&] {
                 constexpr int e_ = U * 256;
                 const int e = tid + e_;
                 const int hs = e / (32 * (D / 4)), rem = e - hs * (32 * (D / 4)), row = rem / (D / 4), c4 = rem - row * (D / 4);
                 const int key = min((hs * half + itn) * 32 + row, N - 1);
-                pk[U] = *reinterpret_cast<const float4 *>(K + (int64_t)key * ld + 4 * c4);
-                pv[U] = *reinterpret_cast<const float4 *>(V + (int64_t)key * ld + 4 * c4);
+                pk[U] = *reinterpret_cast<const f32x4 *>(K + (int64_t)key * ld + 4 * c4);
+                pv[U] = *reinterpret_cast<const f32x4 *>(V + (int64_t)key * ld + 4 * c4);
             }(), ...);
         }(std::make_integer_sequence<int, NPF>{});
     };
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             ([&] {
                 const int e = tid + U * 256;
                 const int hsel = e / (32 * (D / 4)), rem = e - hsel * (32 * (D / 4)), row = rem / (D / 4), c4 = rem - row * (D / 4);
-                *reinterpret_cast<float4 *>(lds + 2 * hsel * TILE + row * PITCH + 4 * c4) = pk[U];
-                *reinterpret_cast<float4 *>(lds + (2 * hsel + 1) * TILE + row * PITCH + 4 * c4) = pv[U];
+                *reinterpret_cast<f32x4 *>(lds + 2 * hsel * TILE + row * PITCH + 4 * c4) = pk[U];
+                *reinterpret_cast<f32x4 *>(lds + (2 * hsel + 1) * TILE + row * PITCH + 4 * c4) = pv[U];
             }(), ...);
         }(std::make_integer_sequence<int, NPF>{});
         if (tid < 64) {

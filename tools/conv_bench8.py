@@ -29,6 +29,8 @@ LAYERS = [
 CFGS = [int(c) for c in os.environ.get('CFGS', '').split()]
 DBG = int(os.environ.get('DBG', '0'))
 ONLY = [int(c) for c in os.environ.get('ONLY', '').split()]
+SCALE_N = int(os.environ.get('SCALE_N', '1'))          # 8: the single-frame step's layers (n = 1; ISNet 2 instances)
+SERIAL = int(os.environ.get('SERIAL', '-1'))            # split-K execution of the forced configurations: 0 parallel, 1 serial
 
 
 def main():
@@ -41,6 +43,7 @@ def main():
     for li, (mult, n, h, w, cin, cout, k, s, d, g) in enumerate(LAYERS):
         if ONLY and li not in ONLY:
             continue
+        n = max(1, n // SCALE_N)
         p = Program("l")
         x = p.buffer(n, h, w, cin)
         x.buf.first = 0
@@ -54,10 +57,12 @@ def main():
         per, same = [], []
         for cfg in [-1] + CFGS:
             L.csm_debug_force_conv_cfg(cfg if cfg < 0 else cfg | (DBG << 8))
+            L.csm_debug_force_splitk_serial(SERIAL if cfg >= 0 else -1)
             cp.run()
             per.append(min(cp.profile()[0] for _ in range(5)))
             same.append(bool(torch.equal(cp.workspace, ref)))
         L.csm_debug_force_conv_cfg(-1)
+        L.csm_debug_force_splitk_serial(-1)
         fl = p.flops
         tot += mult * per[0]; best += mult * min(per)
         print("%2d x%-2d %8.1f us %6.1f TF/s T%-2d %-40s | %s" % (li, mult, per[0] * 1e3, fl / per[0] / 1e9, cp.ops[0].tile - 1,
