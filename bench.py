@@ -333,8 +333,8 @@ class FrameWorkload(Workload):
                         "stream, double-buffered, inside the timed region)" % B}
 
     def _zoe_variant(self, frames=3):
-        """BASELINE configs[2] with its literal depth network: seg + ZoeDepth (built-in MiDaS DPT-BEiT-L core, 672 x 672, flip TTA: two
-        passes of 1765 tokens) + one warp per 1024 x 1024 frame, serial; and the core program's own conv population against the MFMA roof"""
+        """BASELINE configs[2] with its literal depth network: seg + ZoeDepth (built-in MiDaS DPT-BEiT-L core, 672 x 672, flip TTA: the plain
+        and the mirrored pass, 1765 tokens each, as the two samples of one core run) + one warp per 1024 x 1024 frame, serial; and the core program's own conv population against the MFMA roof"""
         from cartoonsegmentation_amd.kenburns import KenBurnsConfig, KenBurnsPipeline
         size = self.H
         cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='zoe', max_size=size, refine_crf=False, depth_field=False, focal=size / 2.0,

@@ -3,8 +3,9 @@
 124-202, base_models/midas.py:49-350}).
 
 Built here, all on the device:
-  * DepthModel.infer: reflect padding by int(sqrt(size / 2) * 3), horizontal-flip test-time augmentation, bicubic resize of the
-    prediction back to the padded size, crop, average of the two passes            (csrc/zoedepth.hip);
+  * DepthModel.infer: reflect padding by int(sqrt(size / 2) * 3), horizontal-flip test-time augmentation (the mirrored pass runs as extra
+    samples of the same core / head run), bicubic resize of the prediction back to the padded size, crop, average of the two passes
+    (csrc/zoedepth.hip);
   * MidasCore.forward's PrepForMidas: Resize.get_size ("minimal", multiple of 32, aspect ratio kept: config "infer": force_keep_ar),
     bilinear align_corners=True, Normalize(0.5, 0.5) -- fused with the padding / flip into one pass;
   * ZoeDepth.forward after `self.core(...)`: the metric-bins head as a layer program (nets/zoedepth_head.py);
@@ -139,13 +140,18 @@ class ZoeDepth:
         Hp, Wp = H + 2 * pad_h, W + 2 * pad_w
         nw, nh = midas_size(Wp, Hp, self.net_w, self.net_h, self.keep_aspect_ratio)
         out = torch.empty((B, 1, H, W), dtype=torch.float32, device=self.device)
-        xp = torch.empty((B, 3, nh, nw), dtype=torch.float32, device=self.device)
-        for k, flip in enumerate((0, 1) if with_flip_aug else (0,)):
-            check(L.csm_zoe_pad_prep(ptr(x), i32(B), i32(H), i32(W), i32(pad_h), i32(pad_w), i32(flip), i32(nh), i32(nw), ptr(xp),
+        # the flipped pass of infer_with_flip_aug (depth_model.py:113-129) rides in the SAME core / head run as the plain one, as samples
+        # B .. 2B - 1: the layer programs are batch invariant (every sample's bits are those of a run by itself), the matrix pipe sees
+        # twice the rows per weight tile and the attention twice the blocks
+        flips = (0, 1) if with_flip_aug else (0,)
+        xp = torch.empty((len(flips) * B, 3, nh, nw), dtype=torch.float32, device=self.device)
+        for k, flip in enumerate(flips):
+            check(L.csm_zoe_pad_prep(ptr(x), i32(B), i32(H), i32(W), i32(pad_h), i32(pad_w), i32(flip), i32(nh), i32(nw), ptr(xp[k * B:]),
                                      stream_ptr()), "zoe_pad_prep")
-            d = self.forward_prepared(xp)
-            check(L.csm_zoe_resize_crop(ptr(d), i32(B), i32(d.shape[2]), i32(d.shape[3]), i32(pad_h), i32(pad_w), i32(H), i32(W), i32(flip),
-                                        i32(k), ptr(out), stream_ptr()), "zoe_resize_crop")
+        d = self.forward_prepared(xp)
+        for k, flip in enumerate(flips):
+            check(L.csm_zoe_resize_crop(ptr(d[k * B:]), i32(B), i32(d.shape[2]), i32(d.shape[3]), i32(pad_h), i32(pad_w), i32(H), i32(W),
+                                        i32(flip), i32(k), ptr(out), stream_ptr()), "zoe_resize_crop")
         return out
 
 
