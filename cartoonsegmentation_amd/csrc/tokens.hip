@@ -68,11 +68,25 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ in,
 //   o^T += V^T p^T with A = V (staged tile, a lane reads V[key][its dimension]) and B = p STRAIGHT FROM THE SCORE REGISTERS (MFMA step r
 //                 pairs the keys of register r in the two lane halves): P never goes through LDS.
 // 64 MFMAs per wave and tile, none wasted.  Reductions are tolerance-level against the oracle (see the header).
-template <int D>
+// The relative position bias of a (32 queries) x (32 keys) tile pair comes from a WINDOW of the head's table: 32 consecutive tokens span
+// at most R = 31 / gw + 2 grid rows, so yi - yj takes at most 2 R - 1 values and the pair needs the (2 R - 1) (2 gw - 1) consecutive table
+// entries starting at row yq0 - yk0 - R + gh (249 floats at 42 x 42).  Every wave fetches the window of its NEXT key tile into its own LDS
+// region by DMA (buffer_load_dword ... lds: no registers, out-of-table entries read as 0 through the buffer range check) behind the softmax
+// of the current one, and the 16 bias values of a lane are LDS reads at  base(query) - kterm(key).  (Gathering them from the table in
+// global memory -- 16 scattered loads per lane and tile -- kept the texture path as busy as the matrix pipe: 216 -> 150 us per layer at
+// 1765 tokens.)  wcap = floats of one wave's window (a multiple of 64), 0 = window too large for the LDS budget: gather from global memory.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma4(unsigned voff, i32x4_t rsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <int D, bool WIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_attention(const float *__restrict__ qkv, int ld, float *__restrict__ out, int out_ld, int N, int heads,
-                                                   const float *__restrict__ table /* [heads][T] or null */, int gh, int gw) {
+                                                   const float *__restrict__ table /* [heads][T] or null */, int gh, int gw, int wcap) {
     constexpr int NCT = D / 32, PITCH = D + 4, TILE = 32 * PITCH;       // floats of one staged K or V tile
-    extern __shared__ __attribute__((aligned(16))) float lds[];          // [half][K tile | V tile] then [half][32] key terms of the bias index
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [half][K tile | V tile], [half][32] key terms of the bias index, [wave][wcap] bias windows
     // half h: K tile at lds + 2 h TILE, V tile behind it
     int *kterm = reinterpret_cast<int *>(lds + 4 * TILE);               // [2][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -84,8 +98,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int T = (2 * gh - 1) * (2 * gw - 1) + 3;
     const float *tab = table ? table + (int64_t)head * T : nullptr;
     // the query's part of the bias index: idx(i, j) = Ci - Kj for patch tokens, Kj = yj (2 gw - 1) + xj
-    int Ci = 0;
-    if (tab && qi >= 1) { const int yi = (qi - 1) / gw, xi = (qi - 1) - yi * gw; Ci = yi * (2 * gw - 1) + xi + (gh - 1) * (2 * gw - 1) + gw - 1; }
+    int Ci = 0, yi = 0, xi = 0;
+    if (tab && qi >= 1) { yi = (qi - 1) / gw; xi = (qi - 1) - yi * gw; Ci = yi * (2 * gw - 1) + xi + (gh - 1) * (2 * gw - 1) + gw - 1; }
+    // bias window of this wave (see above)
+    const int W2 = 2 * gw - 1, R = 31 / gw + 2, WN = (2 * R - 1) * W2, yq0 = q0 >= 1 ? (q0 - 1) / gw : 0;
+    constexpr bool win = WIN;                                          // (the launcher: WIN <=> table && wcap > 0)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float *wbuf = lds + 4 * TILE + 64 + wave_u * wcap;
+    const unsigned wbuf_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds + (unsigned)(4 * TILE + 64 + wave_u * wcap) * 4u;
+    i32x4_t rtab = {0, 0, 0, 0};
+    float b_cp = 0.0f, b_pc = 0.0f, b_cc = 0.0f;                       // class token -> patch, patch -> class token, class -> class
+    if (tab) {
+        const uint64_t pt = (uint64_t)tab;
+        rtab = i32x4_t{(int)(unsigned)pt, (int)(unsigned)(pt >> 32), (int)((unsigned)(T - 3) * 4u), 0x00020000};
+        b_cp = tab[T - 3]; b_pc = tab[T - 2]; b_cc = tab[T - 1];
+    }
+    auto fetch_window = [&](int tl) __attribute__((always_inline)) {   // the window of key tile tl -> wbuf (asynchronous: vmcnt)
+        const int j0 = tl * 32, yk0 = j0 >= 1 ? (j0 - 1) / gw : 0;
+        const int g0 = (yq0 - yk0 - R + gh) * W2;
+        for (int u = 0; u * 64 < wcap; ++u) {
+            const int e = u * 64 + lane;
+            dma4(e < WN ? (unsigned)((g0 + e) * 4) : 0x80000000u, rtab, wbuf_addr + (unsigned)u * 256u);
+        }
+    };
 
     float4 qf[D / 8];
     {
@@ -121,6 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }(std::make_integer_sequence<int, NPF>{});
     };
     prefetch(0);
+    if (win && kh * half < NT) fetch_window(kh * half);
     for (int it = 0; it < half; ++it) {
         // ---- stage the two halves' K and V tiles (rows beyond N repeat row N - 1: finite values, their probabilities are forced to 0)
         __syncthreads();                                                // everybody is done with the previous tiles
@@ -143,6 +179,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int tile = kh * half + it;
         if (tile >= NT) continue;                                       // (odd tile counts: the second half has one tile fewer)
         const float *Kt = lds + 2 * kh * TILE, *Vt = Kt + TILE;
+        const int yk0 = tile >= 1 ? (tile * 32 - 1) / gw : 0;
+        const int wbase = (yi - yq0 + yk0 + R - 1) * W2 + xi + gw - 1;  // window index of (this query, key) = wbase - kterm(key)
         // ---- s^T = K q^T
         f32x16 sacc;
 #pragma unroll
@@ -155,42 +193,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kb].z, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kb].w, sacc, 0, 0, 0);
         }
-        // ---- bias, padded keys, running max
+        // ---- bias, padded keys, running max.  Interior tile pairs (no class token, no padding on either side: all but the first / last
+        // tiles) take a path without per-element conditions: 16 + 16 LDS reads issued together, one add and one max per score
         float mt = -3.0e38f;
+        if (win) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's window has landed (issued one tile ago, behind the K / V prefetch)
+        const bool interior = tile > 0 && q0 > 0 && tile * 32 + 32 <= N && q0 + 32 <= N;      // (wave-uniform)
+        if (win && interior) {
+            int kt[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int krow = (r & 3) + 8 * (r >> 2) + 4 * lh, j = tile * 32 + krow;
-            float v = sacc[r];
-            if (tab) {
-                int idx;
-                if (qi == 0) idx = j == 0 ? T - 1 : T - 3;
-                else if (j == 0) idx = T - 2;
-                else idx = Ci - kterm[kh * 32 + krow];
-                v += tab[min(max(idx, 0), T - 1)];                      // (clamped: padded queries / keys carry meaningless indices)
+            for (int r = 0; r < 16; ++r) kt[r] = kterm[kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] += wbuf[wbase - kt[r]]; mt = fmaxf(mt, sacc[r]); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow = (r & 3) + 8 * (r >> 2) + 4 * lh, j = tile * 32 + krow;
+                float v = sacc[r];
+                if (tab) {
+                    float bv;
+                    if (win) {
+                        const float w = wbuf[min(max(wbase - kterm[kh * 32 + krow], 0), WN - 1)];   // (clamped: padded queries / keys carry meaningless indices)
+                        bv = qi == 0 ? (j == 0 ? b_cc : b_cp) : (j == 0 ? b_pc : w);
+                    } else {
+                        int idx;
+                        if (qi == 0) idx = j == 0 ? T - 1 : T - 3;
+                        else if (j == 0) idx = T - 2;
+                        else idx = Ci - kterm[kh * 32 + krow];
+                        bv = tab[min(max(idx, 0), T - 1)];
+                    }
+                    v += bv;
+                }
+                if (j >= N) v = -3.0e38f;
+                sacc[r] = v;
+                mt = fmaxf(mt, v);
             }
-            if (j >= N) v = -3.0e38f;
-            sacc[r] = v;
-            mt = fmaxf(mt, v);
+        }
+        if (win && it + 1 < half && tile + 1 < NT) {                    // the next tile's window, under the rest of this tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the reads of this one have returned)
+            fetch_window(tile + 1);
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f((m_run - m_new) * 1.44269504088896341f);
+        // p = 2^((s - m) log2 e) on the raw v_exp_f32 (arguments <= 0: a result below 2^-126 is 0 either way at the tolerance of this op);
+        // a padded key's score is -3e38: its p is exactly 0 without a test
+        const float ms = m_new * 1.44269504088896341f;
         float lt = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float pv = j < N ? exp2f((sacc[r] - m_new) * 1.44269504088896341f) : 0.0f;
+            const float pv = __builtin_amdgcn_exp2f(sacc[r] * 1.44269504088896341f - ms);
             sacc[r] = pv;
             lt += pv;
         }
         lt += __shfl_xor(lt, 32, 64);
-        l_run = l_run * alpha + lt;
+        // the running maximum settles after a few tiles: rescale l and o only when some query of the wave moved (wave-uniform test; alpha
+        // is exactly 1 otherwise)
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * 1.44269504088896341f);
+            l_run *= alpha;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        }
+        l_run += lt;
         m_run = m_new;
-        // ---- o^T = o^T alpha + V^T p^T
+        // ---- o^T += V^T p^T
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int krow = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -286,9 +355,25 @@ int launch_layernorm(const float *in, int in_ld, float *out, int out_ld, int64_t
 template <int D> static int launch_attention_t(const float *qkv, int ld, float *out, int out_ld, int n, int N, int heads, const float *table, int gh,
                                                int gw, hipStream_t st) {
     constexpr int kTiles = 4 * 32 * (D + 4) + 64, kExchange = 2 * 64 * (16 * (D / 32) + 2);
-    const size_t lds = sizeof(float) * (size_t)(kTiles > kExchange ? kTiles : kExchange);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attention<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k_attention<D><<<dim3((unsigned)((N + 63) / 64), (unsigned)heads, (unsigned)n), 256, lds, st>>>(qkv, ld, out, out_ld, N, heads, table, gh, gw);
+    // bias windows: (2 R - 1) (2 gw - 1) floats per wave, rounded up to whole 64-lane DMA pieces; at most 2 K floats per wave (grids up to
+    // ~340 tokens wide), else the kernel gathers from the table in global memory
+    int wcap = 0;
+    if (table) {
+        const int R = 31 / gw + 2, WN = (2 * R - 1) * (2 * gw - 1);
+        wcap = (WN + 63) / 64 * 64;
+        if (wcap > 2048) wcap = 0;
+    }
+    size_t fl = (size_t)kTiles + 4 * (size_t)wcap;
+    if (fl < (size_t)kExchange) fl = kExchange;
+    const size_t lds = sizeof(float) * fl;
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)heads, (unsigned)n);
+    if (wcap > 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attention<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k_attention<D, true><<<grid, 256, lds, st>>>(qkv, ld, out, out_ld, N, heads, table, gh, gw, wcap);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attention<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k_attention<D, false><<<grid, 256, lds, st>>>(qkv, ld, out, out_ld, N, heads, table, gh, gw, 0);
+    }
     return check_launch("k_attention");
 }
 
