@@ -620,6 +620,7 @@ class FrameWorkload(Workload):
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         tot_fl /= self.frames_per_step
         return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_mfma (fp32 implicit GEMM, all conv launches of one step = %d frames)" % self.frames_per_step,
+                "vendor_fp32_gemm_context": self._vendor_gemm_context() if self.frames_per_step == 8 else None,
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                 "traffic": load_traffic("k_conv"), "traffic_source": TRAFFIC_SOURCE,
                 "algorithmic_bytes_per_launch": int(alg_bytes / max(n_launch, 1)),
@@ -627,6 +628,25 @@ class FrameWorkload(Workload):
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_step": n_launch, "conv_ms_per_step": round(tot_ms, 3),
                 "note": "a launch = one conv op of a layer program (a mixed-tile or split-K op issues two kernels: rocprofv3's per-kernel "
                         "average is lower, its k_conv_* total per step is the comparable figure -- profiles/README.md)", "per_net": per_net}
+
+    def _vendor_gemm_context(self):
+        """context for `frac`, measured in this run: what the vendor library's fp32 GEMM (torch.mm -> hipBLASLt / rocBLAS, TF32 off, the
+        im2col matrix handed over for free) reaches on the GEMM shapes of the layers that carry the conv time at 8 frames per step.  Not part of
+        any product path; see profiles/r04_vendor_gemm_ceiling.txt for the same table next to this build's conv ops."""
+        prev = torch.backends.cuda.matmul.allow_tf32
+        torch.backends.cuda.matmul.allow_tf32 = False
+        res = {}
+        try:
+            for name, M, N, K in (("leres_1x1_1024_1024_at_40", 12800, 1024, 1024), ("leres_3x3_256_256_at_160", 204800, 256, 2304),
+                                  ("isnet_3x3_64_64_at_360", 2073600, 64, 576), ("rtmdet_3x3_256_256_at_80", 51200, 256, 2304)):
+                a_, b_ = torch.randn(M, K, device=self.device), torch.randn(K, N, device=self.device)
+                ms = event_time_ms(lambda: a_ @ b_, 5, warm=2)
+                res[name] = {"M_N_K": [M, N, K], "tflops": round(2.0 * M * N * K / ms / 1e9, 1), "frac_of_mfma_peak": round(2.0 * M * N * K / ms / 1e9 / MFMA_F32_PEAK_TF, 3)}
+                del a_, b_
+        finally:
+            torch.backends.cuda.matmul.allow_tf32 = prev
+        torch.cuda.empty_cache()
+        return res
 
     def extra(self):
         return {}

@@ -352,13 +352,15 @@ int launch_layernorm(const float *in, int in_ld, float *out, int out_ld, int64_t
     return check_launch("k_layernorm");
 }
 
+static int g_attention_options = 0;      // csm_debug_attention_options: bit 0 = no bias window (the large-grid path), for tests
+
 template <int D> static int launch_attention_t(const float *qkv, int ld, float *out, int out_ld, int n, int N, int heads, const float *table, int gh,
                                                int gw, hipStream_t st) {
     constexpr int kTiles = 4 * 32 * (D + 4) + 64, kExchange = 2 * 64 * (16 * (D / 32) + 2);
     // bias windows: (2 R - 1) (2 gw - 1) floats per wave, rounded up to whole 64-lane DMA pieces; at most 2 K floats per wave (grids up to
     // ~340 tokens wide), else the kernel gathers from the table in global memory
     int wcap = 0;
-    if (table) {
+    if (table && !(g_attention_options & 1)) {
         const int R = 31 / gw + 2, WN = (2 * R - 1) * (2 * gw - 1);
         wcap = (WN + 63) / 64 * 64;
         if (wcap > 2048) wcap = 0;
@@ -405,3 +407,10 @@ int launch_depth_to_space(const float *in, int in_ld, float *out, int out_ld, in
 }
 
 }  // namespace csm
+
+// test aid (not stable ABI): bit 0 = attention gathers the relative position bias from the table in global memory even when the window
+// fits the LDS budget (the path grids wider than ~340 tokens take)
+extern "C" int csm_debug_attention_options(int options) {
+    csm::g_attention_options = options;
+    return CSM_OK;
+}

@@ -265,6 +265,9 @@ int csm_debug_force_splitk_serial(int mode);
 /* Measurement aid (not stable ABI): bit 0 = the autotuner may choose mixed-tile launches (default on); bit 1 = N-grouped tile order
  * (layers whose weights exceed an XCD's L2) OFF (default on).  Speed only. */
 int csm_debug_conv_tuner_options(int options);
+/* Test aid (not stable ABI): bit 0 = CSM_OP_ATTENTION gathers the relative position bias from the table in global memory even when the
+ * tile pair's window of the table fits the LDS budget (the path token grids wider than ~340 take).  Same results at the op's tolerance. */
+int csm_debug_attention_options(int options);
 /* Measurement aid: same execution, each op bracketed by HIP events on `stream`; synchronises and returns ms per op. */
 int csm_run_program_profile(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors, int n_tensors,
                             const float *weights, float *workspace, void *const *ext, int n_ext, void *stream,

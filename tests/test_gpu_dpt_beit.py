@@ -52,6 +52,38 @@ def test_dpt_beit_small_hip_vs_oracle(n, H, W, kw):
     _compare(prog, x, cfg, 1e-4)
 
 
+def test_attention_bias_window_and_table_gather_agree():
+    """the attention kernel reads the relative position bias of a tile pair from an LDS window of the table (DMA) when the window fits, else
+    from the table in global memory: both paths on the same program (a 36 x 36 token grid: several key tiles per half, class-token row /
+    column, padded last tiles) give the same tensors, and the gather path by itself meets the oracle tolerance"""
+    from cartoonsegmentation_amd import _lib
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    L = _lib.load()
+    cfg = DPTBeitConfig(**dict(SMALL, depth=2, hooks=(0, 1, 1, 1)))
+    n, H, W = 2, 576, 576
+    prog = build_dpt_beit(SynthWeights('dptbeit_small.'), n, H, W, cfg)
+    x = torch.from_numpy(np.random.default_rng(5).normal(0, 1, (n, 3, H, W)).astype(np.float32)).cuda()
+    cp = CompiledProgram(prog, 'cuda')
+    res = []
+    try:
+        for opt in (0, 1):
+            L.csm_debug_attention_options(opt)
+            dev = [torch.from_numpy(a).cuda() for a in _outs(n, H, W, cfg, np.nan)]
+            cp.run(x, *dev)
+            torch.cuda.synchronize()
+            res.append(dev)
+    finally:
+        L.csm_debug_attention_options(0)
+    for a, b in zip(*res):
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    try:
+        L.csm_debug_attention_options(1)
+        xs = np.random.default_rng(6).normal(0, 1, (1, 3, 64, 96)).astype(np.float32)
+        _compare(build_dpt_beit(SynthWeights('dptbeit_small.'), 1, 64, 96, DPTBeitConfig(**SMALL)), xs, DPTBeitConfig(**SMALL), 1e-4)
+    finally:
+        L.csm_debug_attention_options(0)
+
+
 def test_dpt_beit_large_384x512_hip_vs_oracle():
     """the network of BASELINE configs[2] itself: BEiT-L/16 (24 blocks, 1024 wide, 16 heads) + DPT decoder on a 384 x 512 prepared input
     (24 x 32 + 1 = 769 tokens: the relative-position table is re-sampled from the 24 x 24 pre-training window)"""
