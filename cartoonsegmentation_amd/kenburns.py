@@ -241,9 +241,9 @@ class KenBurnsPipeline:
         self._depth_est = self._depth_est_leres
 
     def _set_zoe_estimator(self):
-        """depth_modules/__init__.py:40-47 load_zoe(DEPTH_ZOE_CKPT, img_size=[672, 672]): the metric-bins head's weights come from the
-        checkpoint (or closed-form); the MiDaS DPT-BEiT-L core is a plug (self.set_zoe_core) -- the reference downloads it with
-        torch.hub and does not vendor it, so without a core the estimator raises at its first call"""
+        """depth_modules/__init__.py:40-47 load_zoe(DEPTH_ZOE_CKPT, img_size=[672, 672]): the head's and the MiDaS DPT-BEiT-L core's weights
+        come from the checkpoint (`core.core.*`; or closed-form).  The core is the built-in layer program (zoedepth.DPTBeitCore: the
+        reference downloads that network with torch.hub and does not vendor it) unless self.set_zoe_core plugged another callable"""
         from .zoedepth import ZoeDepth
         if getattr(self, 'depth_zoe', None) is None:
             p = 'models/AnimeInstanceSegmentation/ZoeD_M12_N.pt'                     # utils/constants.py:82
@@ -258,7 +258,8 @@ class KenBurnsPipeline:
         self._depth_est = self._depth_est_zoe
 
     def set_zoe_core(self, core):
-        """plug the MiDaS core: core(x_prepared [B,3,h,w]) -> (rel_depth [B,h,w], [out_conv, bottleneck, r4, r3, r2, r1])"""
+        """plug a MiDaS core in place of the built-in one: core(x_prepared [B,3,h,w]) -> (rel_depth [B,h,w], [out_conv, bottleneck, r4, r3,
+        r2, r1]); B = 2 x frames when the flip TTA is on (the mirrored pass rides in the same call).  None restores the built-in program"""
         self._zoe_core = core
         if getattr(self, 'depth_zoe', None) is not None:
             self.depth_zoe.set_core(core)
