@@ -8,7 +8,8 @@ cd /root/repo
 export CSM_TUNE_CACHE=/tmp/csm_tiles.txt   # first bench run tunes + saves; the profiled runs reuse the tiles (no tuning launches)
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $OUT/pytest_gpu.log; tail -2 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $OUT/smoke.log
-timeout 900 python bench.py 2>/dev/null | tail -1 > $OUT/bench_frame.json; head -c 400 $OUT/bench_frame.json; echo
+T0=$(date +%s); timeout 900 python bench.py 2>/dev/null | tail -1 > $OUT/bench_frame.json; head -c 400 $OUT/bench_frame.json; echo
+echo "python bench.py (default flags, all variants): $(( $(date +%s) - T0 )) s wall" | tee $OUT/bench_seconds.txt
 timeout 300 python bench.py --workload warp --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_warp.json; head -c 300 $OUT/bench_warp.json; echo
 timeout 300 python tools/layer_profile.py 2>/dev/null > $OUT/layer_profile.txt; grep "^==" $OUT/layer_profile.txt
 LP_BATCH=8 timeout 300 python tools/layer_profile.py 2>/dev/null > $OUT/layer_profile_b8.txt; grep "^==" $OUT/layer_profile_b8.txt
