@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""per-kind profile of the built-in DPT-BEiT-L core of ZoeDepth (HIP events per op): argv = height width [batch] (default 672 672 1)"""
+"""per-kind profile of the built-in DPT-BEiT-L core of ZoeDepth (HIP events per op): argv = height width [batch] (default 672 672 1);
+ATT_OPTIONS=<bits> sets csm_debug_attention_options (A/B of the attention kernel's variants)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +12,9 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 KIND = {1: 'conv', 4: 'bilinear', 6: 'add', 9: 'to_nhwc', 10: 'to_nchw', 11: 'act', 15: 'layernorm', 16: 'attention', 17: 'tokens', 18: 'depth_to_space'}
 p = build_dpt_beit(SynthWeights('zoe.core.core.'), B, H, W)
 cp = CompiledProgram(p, 'cuda')
+if os.environ.get('ATT_OPTIONS'):
+    from cartoonsegmentation_amd import _lib
+    _lib.load().csm_debug_attention_options(int(os.environ['ATT_OPTIONS']))
 ext = [torch.randn(b.n, b.c, b.h, b.w, device='cuda') for b in sorted((b for b in p.bufs if b.ext >= 0), key=lambda b: b.ext)]
 cp.run(*ext)
 ms = None
