@@ -142,7 +142,35 @@ struct ConvArgs {
     int split;                         // launcher hint: cover the last partial round of the grid with small tiles (see launch_conv_dma_t)
     int dbg;                           // tuning aid: 1 = no global loads, 2 = no MFMA, 4 = no LDS stores, 8 = no epilogue stores
     int ngroup;                        // tile order (speed only): N tiles per group, 0 = one group (see rem_to_tile)
+    unsigned dv_hw_mul, dv_hw_shr, dv_w_mul, dv_w_shr;   // magic numbers of m / (ho * wo) and rem / wo (fast_div; filled by set_fast_div)
 };
+
+// Row set-up of the LDS-DMA loaders: output row m -> (sample, oy, ox) with two divisions by run-time constants, and the validity mask of
+// its kh x kw taps.  The compiler's 32-bit division is ~35 vector instructions and the tap double loop ~9 per tap; on short-K tiles (K = 288:
+// 144 MFMAs per wave) the loader's set-up was a third of the 1 337 vector instructions a wave executes (profiles/r04_grouped_conv_pmc.txt).
+// fast_div: q = (mulhi(n, mul) + n) >> shr with shr = ceil(log2 d), mul = floor(2^32 (2^shr - d) / d) + 1 -- exact for n < 2^31.
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned shr) { return (__umulhi(n, mul) + n) >> shr; }
+static void set_fast_div(unsigned d, unsigned &mul, unsigned &shr) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    shr = l;
+    mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+}
+struct RowSetup { int n, iy0, ix0; unsigned vm; };
+__device__ __forceinline__ RowSetup row_setup(const ConvArgs &a, int mm, bool rv) {
+    const int wo = a.out.w, howo = a.out.h * wo;
+    RowSetup r;
+    r.n = (int)fast_div((unsigned)mm, a.dv_hw_mul, a.dv_hw_shr);
+    const int rem = mm - r.n * howo;
+    const int oy = (int)fast_div((unsigned)rem, a.dv_w_mul, a.dv_w_shr), ox = rem - oy * wo;
+    r.iy0 = oy * a.stride - a.pad; r.ix0 = ox * a.stride - a.pad;
+    // taps: valid rows x valid columns (bit kh * kw_count + kw)
+    unsigned colm = 0u, vm = 0u;
+    for (int kw = 0; kw < a.kw; ++kw) { const int ix = r.ix0 + kw * a.dil; colm |= (ix >= 0 && ix < a.in.w) ? 1u << kw : 0u; }
+    for (int kh = 0; kh < a.kh; ++kh) { const int iy = r.iy0 + kh * a.dil; vm |= (iy >= 0 && iy < a.in.h) ? colm << (kh * a.kw) : 0u; }
+    r.vm = rv ? vm : 0u;
+    return r;
+}
 
 // Block -> tile map (speed only).  Workgroups are handed to the 8 XCDs round-robin in launch order, and each XCD has its own L2:
 // give XCD x a CONTIGUOUS run of tiles in the order (z, m-tile, n-tile) with n fastest, so the blocks resident on one XCD
@@ -482,19 +510,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         int slot = (lane & 7) ^ ((row >> 1) & 7);
         int m = m0 + row;
         bool rv = m < a.M;
-        int mm = rv ? m : 0;
-        int n = mm / (ho * wo), rem = mm - n * ho * wo;
-        int oy = rem / wo, ox = rem - oy * wo;
-        int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-        offA[p] = (unsigned)(((n * a.in.h + iy0) * a.in.w + ix0) * a.in.ld + cin_off + slot * 4) * 4u;
-        unsigned vm = 0u;
-        if (rv)
-            for (int kh = 0; kh < a.kh; ++kh)
-                for (int kw = 0; kw < a.kw; ++kw) {
-                    int iy = iy0 + kh * a.dil, ix = ix0 + kw * a.dil;
-                    if (iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w) vm |= 1u << (kh * a.kw + kw);
-                }
-        vmA[p] = vm;
+        const RowSetup rs = row_setup(a, rv ? m : 0, rv);
+        offA[p] = (unsigned)(((rs.n * a.in.h + rs.iy0) * a.in.w + rs.ix0) * a.in.ld + cin_off + slot * 4) * 4u;
+        vmA[p] = rs.vm;
     }
 #pragma unroll
     for (int p = 0; p < GB; ++p) {
@@ -669,20 +687,27 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
         int n = n0 + 32 * (TN * wn + j) + li;
         if (n >= a.cout_g) continue;
         float slope = a.slope ? a.slope[cout_off + n] : 0.0f;
+        // (row pointers once per accumulator: the 16 rows of a lane are at compile-time row offsets x the uniform pitch -- no per-element
+        // 64-bit multiply; the quarter-rate integer multiplies were ~500 cycles of a tile's epilogue)
+        const int64_t ldo = a.out.ld, ldr = a.res.ld;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + 32 * (TM * wm + i) + 4 * lh;
+            float *ob = a.out.p + (int64_t)mb * ldo + cout_off + n;
+            const float *rb = a.res_mode ? a.res.p + (int64_t)mb * ldr + cout_off + n : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int mo = (r & 3) + 8 * (r >> 2), m = mb + mo;
                 if (m >= a.M) continue;
                 float v = acc[i][j][r];
                 if constexpr (SER) v = tot[i][j][r] + v;
                 if (!SER && a.ksplit > 1) { a.partial[((int64_t)m * a.ksplit + ks) * a.cout_g + n] = v; continue; }
-                if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
+                if (a.res_mode == 1) v += rb[mo * ldr];
                 v = apply_act(v, a.act, slope);
-                if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
-                a.out.p[(int64_t)m * a.out.ld + cout_off + n] = v;
+                if (a.res_mode == 2) v += rb[mo * ldr];
+                ob[mo * ldo] = v;
             }
+        }
     }
 }
 
@@ -744,19 +769,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n
             int slot = (lane & 7) ^ ((row >> 1) & 7);
             int m = m0 + row;
             bool rv = live && m < a.M;
-            int mm = rv ? m : 0;
-            int n = mm / (ho * wo), rem2 = mm - n * ho * wo;
-            int oy = rem2 / wo, ox = rem2 - oy * wo;
-            int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            offA[p] = (unsigned)(((n * a.in.h + iy0) * a.in.w + ix0) * a.in.ld + cin_off + slot * 4) * 4u;
-            unsigned vm = 0u;
-            if (rv)
-                for (int kh = 0; kh < a.kh; ++kh)
-                    for (int kw = 0; kw < a.kw; ++kw) {
-                        int iy = iy0 + kh * a.dil, ix = ix0 + kw * a.dil;
-                        if (iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w) vm |= 1u << (kh * a.kw + kw);
-                    }
-            vmA[p] = vm;
+            const RowSetup rs = row_setup(a, rv ? m : 0, rv);
+            offA[p] = (unsigned)(((rs.n * a.in.h + rs.iy0) * a.in.w + rs.ix0) * a.in.ld + cin_off + slot * 4) * 4u;
+            vmA[p] = rs.vm;
         }
 #pragma unroll
         for (int p = 0; p < GB; ++p) {
@@ -909,19 +924,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma_p(ConvArgs a, int n_n
             int n = n0 + 32 * (TN * wn + jj) + li;
             if (n >= a.cout_g) continue;
             float slope = a.slope ? a.slope[cout_off + n] : 0.0f;
+            const int64_t ldo = a.out.ld, ldr = a.res.ld;          // (row pointers once per accumulator, as in k_conv_dma)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + 32 * (TM * wm + i) + 4 * lh;
+                float *ob = a.out.p + (int64_t)mb * ldo + cout_off + n;
+                const float *rb = a.res_mode ? a.res.p + (int64_t)mb * ldr + cout_off + n : nullptr;
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) {
-                    int m = m0 + 32 * (TM * wm + i) + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                    const int mo = (rr & 3) + 8 * (rr >> 2), m = mb + mo;
                     if (m >= a.M) continue;
                     float v = acc[i][jj][rr];
                     if constexpr (SER) v = tot[i][jj][rr] + v;
-                    if (a.res_mode == 1) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
+                    if (a.res_mode == 1) v += rb[mo * ldr];
                     v = apply_act(v, a.act, slope);
-                    if (a.res_mode == 2) v += a.res.p[(int64_t)m * a.res.ld + cout_off + n];
-                    a.out.p[(int64_t)m * a.out.ld + cout_off + n] = v;
+                    if (a.res_mode == 2) v += rb[mo * ldr];
+                    ob[mo * ldo] = v;
                 }
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetch must land before the block's LDS is released
@@ -2651,6 +2671,7 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 a.groups = op.groups; a.cin_g = op.cin_g; a.cout_g = op.cout_g; a.npad = (op.cout_g + 31) / 32 * 32;
                 a.act = op.act; a.res_mode = op.in1 >= 0 ? op.res_mode : 0;
                 a.M = out.n * out.h * out.w; a.ncb = (op.cin_g + 31) / 32;
+                set_fast_div((unsigned)(out.h * out.w), a.dv_hw_mul, a.dv_hw_shr); set_fast_div((unsigned)out.w, a.dv_w_mul, a.dv_w_shr);
                 a.ksplit = op.ksplit > 1 ? op.ksplit : 1; a.partial = nullptr;
                 if (a.ksplit > 1) {
                     View sc{};
