@@ -28,8 +28,8 @@ MFMA_F32_PEAK_TF = 157.3  # same guide: fp32-input MFMA dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=16)      # 1.4 s timed at 8 frames per step: the 0.7 s of 8 steps moved +-1.5 % with the box's clock state
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--workload", default="auto", help="auto | warp | frame")
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (frame workload); 8 per rank = BASELINE configs[3] "
