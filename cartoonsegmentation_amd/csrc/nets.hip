@@ -1130,14 +1130,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
         ncol[j] = n0 + 32 * (TN * wn + j) + li;
         slope[j] = (a.slope && ncol[j] < a.cout_g) ? a.slope[cout_off + ncol[j]] : 0.0f;
     }
+    // (one row pointer per accumulator: a lane's 16 pixels sit at compile-time (dy, dx) from its first one -- 4 lh + (r & 3) never carries
+    // into the next tile row -- so an element's address is pointer + a UNIFORM offset, no per-element 64-bit multiply)
+    const int64_t ldo = a.out.ld, ldr = a.res.ld;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        const int oyb = ty * TH + (32 / TW) * (TM * wm + i), oxb = tx * TW + 4 * lh;
+        const int64_t mb = ((int64_t)n * ho + oyb) * wo + oxb;
+        float *ob = a.out.p + mb * ldo + cout_off;
+        const float *rb = a.res_mode ? a.res.p + mb * ldr + cout_off : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rr = 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int oy = ty * TH + rr / TW, ox = tx * TW + rr % TW;
-            if (oy >= ho || ox >= wo) continue;
-            const int64_t m = ((int64_t)n * ho + oy) * wo + ox;
+            const int rl = (r & 3) + 8 * (r >> 2), dy = rl / TW, dx = rl % TW;
+            if (oyb + dy >= ho || oxb + dx >= wo) continue;
+            const int64_t eo = (int64_t)dy * wo + dx, m = mb + eo;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int nn = ncol[j];
@@ -1145,12 +1151,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_conv_patch(ConvArgs a, int 
                 float v = acc[i][j][r];
                 if constexpr (SER) v = tot[i][j][r] + v;
                 if (!SER && a.ksplit > 1) { a.partial[(m * a.ksplit + ks) * a.cout_g + nn] = v; continue; }
-                if (a.res_mode == 1) v += a.res.p[m * a.res.ld + cout_off + nn];
+                if (a.res_mode == 1) v += rb[eo * ldr + nn];
                 v = apply_act(v, a.act, slope[j]);
-                if (a.res_mode == 2) v += a.res.p[m * a.res.ld + cout_off + nn];
-                a.out.p[m * a.out.ld + cout_off + nn] = v;
+                if (a.res_mode == 2) v += rb[eo * ldr + nn];
+                ob[eo * ldo + nn] = v;
             }
         }
+    }
 }
 
 // ---- persistent form of k_conv_patch: the NEXT tile's input patch is fetched during the current tile's taps -------------------------
@@ -1410,26 +1417,31 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_patch_p(ConvArgs a,
             ncol[j] = n0 + 32 * (TN * wn + j) + li;
             slope[j] = (a.slope && ncol[j] < a.cout_g) ? a.slope[cout_off + ncol[j]] : 0.0f;
         }
+        const int64_t ldo = a.out.ld, ldr = a.res.ld;              // (row pointers once per accumulator, as in k_conv_patch)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const int oyb = ty * TH + (32 / TW) * (TM * wm + i), oxb = tx * TW + 4 * lh;
+            const int64_t mb = ((int64_t)n * ho + oyb) * wo + oxb;
+            float *ob = a.out.p + mb * ldo + cout_off;
+            const float *rb = a.res_mode ? a.res.p + mb * ldr + cout_off : nullptr;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
-                const int rrow = 32 * (TM * wm + i) + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                const int oy = ty * TH + rrow / TW, ox = tx * TW + rrow % TW;
-                if (oy >= ho || ox >= wo) continue;
-                const int64_t m = ((int64_t)n * ho + oy) * wo + ox;
+                const int rl = (rr & 3) + 8 * (rr >> 2), dy = rl / TW, dx = rl % TW;
+                if (oyb + dy >= ho || oxb + dx >= wo) continue;
+                const int64_t eo = (int64_t)dy * wo + dx;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int nn = ncol[j];
                     if (nn >= a.cout_g) continue;
                     float v = acc[i][j][rr];
                     if constexpr (SER) v = tot[i][j][rr] + v;
-                    if (a.res_mode == 1) v += a.res.p[m * a.res.ld + cout_off + nn];
+                    if (a.res_mode == 1) v += rb[eo * ldr + nn];
                     v = apply_act(v, a.act, slope[j]);
-                    if (a.res_mode == 2) v += a.res.p[m * a.res.ld + cout_off + nn];
-                    a.out.p[m * a.out.ld + cout_off + nn] = v;
+                    if (a.res_mode == 2) v += rb[eo * ldr + nn];
+                    ob[eo * ldo + nn] = v;
                 }
             }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetches must land before the block's LDS is released
 }
@@ -1582,21 +1594,25 @@ __global__ __launch_bounds__(512, 2) void k_conv_ws(ConvArgs a, int tiles_x, int
             ncol[j] = n0 + 32 * j + li;
             slope[j] = (a.slope && ncol[j] < a.cout_g) ? a.slope[cout_off + ncol[j]] : 0.0f;
         }
+        const int64_t ldo = a.out.ld, ldr = a.res.ld;              // (row pointer once per tile, as in k_conv_patch)
+        const int oyb = ty * TH + (32 / TW) * wave, oxb = tx * TW + 4 * lh;
+        const int64_t mb = ((int64_t)n * ho + oyb) * wo + oxb;
+        float *ob = a.out.p + mb * ldo + cout_off;
+        const float *rb = a.res_mode ? a.res.p + mb * ldr + cout_off : nullptr;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
-            const int rrow = 32 * wave + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-            const int oy = ty * TH + rrow / TW, ox = tx * TW + rrow % TW;
-            if (oy >= ho || ox >= wo) continue;
-            const int64_t m = ((int64_t)n * ho + oy) * wo + ox;
+            const int rl = (rr & 3) + 8 * (rr >> 2), dy = rl / TW, dx = rl % TW;
+            if (oyb + dy >= ho || oxb + dx >= wo) continue;
+            const int64_t eo = (int64_t)dy * wo + dx;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int nn = ncol[j];
                 if (nn >= a.cout_g) continue;
                 float v = acc[j][rr];
-                if (a.res_mode == 1) v += a.res.p[m * a.res.ld + cout_off + nn];
+                if (a.res_mode == 1) v += rb[eo * ldr + nn];
                 v = apply_act(v, a.act, slope[j]);
-                if (a.res_mode == 2) v += a.res.p[m * a.res.ld + cout_off + nn];
-                a.out.p[m * a.out.ld + cout_off + nn] = v;
+                if (a.res_mode == 2) v += rb[eo * ldr + nn];
+                ob[eo * ldo + nn] = v;
             }
         }
     }
