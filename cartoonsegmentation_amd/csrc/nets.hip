@@ -19,6 +19,7 @@
 //     that the 3x3 halo re-reads of neighbouring tiles hit the same 4 MiB L2.
 // Numerical contract: see include/csm355.h (one fmaf chain per output, fixed K order).
 #include "csm_common.h"
+#include "csm_conv.h"
 #include "csm_tokens.h"
 #include <array>
 #include <cstdio>
@@ -34,171 +35,9 @@
 #define CSM_ILV 1        // persistent conv kernels: DMA pieces interleaved with the MFMA groups (0 = burst behind the barrier; A/B builds)
 #endif
 
+using namespace csmconv;
+
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// ---- shared scalar math (restated independently in oracle/nets_oracle.c) -----------------------
-__device__ __forceinline__ float csm_expf(float x) {
-    x = fminf(fmaxf(x, -87.0f), 88.0f);
-    float n = rintf(x * 1.44269504088896341f);
-    float r = fmaf(n, -0.693145751953125f, x);
-    r = fmaf(n, -1.42860682030941723212e-6f, r);
-    float p = 1.9875691500e-4f;
-    p = fmaf(p, r, 1.3981999507e-3f);
-    p = fmaf(p, r, 8.3334519073e-3f);
-    p = fmaf(p, r, 4.1665795894e-2f);
-    p = fmaf(p, r, 1.6666665459e-1f);
-    p = fmaf(p, r, 5.0000001201e-1f);
-    float e = fmaf(p, r * r, r) + 1.0f;
-    return e * __int_as_float(((int)n + 127) << 23);
-}
-
-// natural logarithm of a positive normal float (Cephes logf: mantissa in [sqrt(1/2), sqrt(2)), degree-8 polynomial); restated in the oracle
-__device__ __forceinline__ float csm_logf(float x) {
-    int bits = __float_as_int(x);
-    int e = ((bits >> 23) & 0xff) - 126;
-    float m = __int_as_float((bits & 0x007fffff) | 0x3f000000);        // [0.5, 1)
-    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
-    const float z = m * m;
-    float y = 7.0376836292e-2f;
-    y = fmaf(y, m, -1.1514610310e-1f); y = fmaf(y, m, 1.1676998740e-1f); y = fmaf(y, m, -1.2420140846e-1f);
-    y = fmaf(y, m, 1.4249322787e-1f); y = fmaf(y, m, -1.6668057665e-1f); y = fmaf(y, m, 2.0000714765e-1f);
-    y = fmaf(y, m, -2.4999993993e-1f); y = fmaf(y, m, 3.3333331174e-1f);
-    y = y * m * z;
-    const float fe = (float)e;
-    y = fmaf(fe, -2.12194440e-4f, y);
-    y = fmaf(z, -0.5f, y);
-    return fmaf(fe, 0.693359375f, m + y);
-}
-// erf, Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7), on the same expf
-__device__ __forceinline__ float csm_erff(float x) {
-    const float ax = fabsf(x);
-    const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
-    float p = 1.061405429f;
-    p = fmaf(p, t, -1.453152027f); p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
-    const float r = 1.0f - (p * t) * csm_expf(-(ax * ax));
-    return x < 0.0f ? -r : r;
-}
-
-__device__ __forceinline__ float apply_act(float v, int act, float slope) {
-    switch (act) {
-        case CSM_ACT_SOFTPLUS: return v > 20.0f ? v : csm_logf(1.0f + csm_expf(v));
-        case CSM_ACT_GELU: return (0.5f * v) * (1.0f + csm_erff(v * 0.707106781186547524f));
-        case CSM_ACT_RELU: return fmaxf(v, 0.0f);
-        case CSM_ACT_SILU: return v / (1.0f + csm_expf(-v));
-        case CSM_ACT_PRELU: return v >= 0.0f ? v : v * slope;
-        case CSM_ACT_HSIGMOID: return fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
-        case CSM_ACT_SIGMOID: return 1.0f / (1.0f + csm_expf(-v));
-        default: return v;
-    }
-}
-
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the occupancy query are per DEVICE, and FrameLanes drives run_ops from several host
-// threads: the check, the preparation and its publication happen under one mutex, so a launch can never see "prepared" before the
-// attribute has been set (a > 64 KB dynamic-LDS launch would fail), and the blocks-per-CU figure is kept per device.
-struct KernelPrep {
-    std::mutex m;
-    unsigned done = 0;                 // bit d: prepared on device d
-    int blocks_per_cu[32] = {};
-    template <class F> int ensure(F &&prepare /* () -> resident blocks per CU (<= 0: unknown) */) {
-        int d = 0;
-        (void)hipGetDevice(&d);
-        d &= 31;
-        std::lock_guard<std::mutex> lk(m);
-        if (!(done & (1u << d))) {
-            const int nb = prepare();
-            blocks_per_cu[d] = nb > 0 ? nb : 1;
-            done |= 1u << d;
-        }
-        return blocks_per_cu[d];
-    }
-};
-template <class K> static int prepare_kernel(K kernel, int threads, size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), threads, lds) != hipSuccess) nb = 0;
-    return nb;
-}
-
-struct View {           // NHWC view
-    float *p;
-    int n, h, w, c, ld;
-};
-
-struct ConvArgs {
-    View in, out, res;
-    const float *w, *bias, *slope;
-    int kh, kw, stride, pad, dil;
-    int groups, cin_g, cout_g, npad;   // npad = cout_g rounded up to 32 (packed weight rows)
-    int act, res_mode;
-    int M;                             // n*ho*wo
-    int ncb;                           // ceil(cin_g / 32)
-    int m_tiles;
-    int ksplit;                        // >1: blockIdx.z = g*ksplit + s, raw partial sums go to `partial`
-    float *partial;                    // [M][ksplit*cout] (groups == 1 only)
-    int serial;                        // ksplit > 1 only: 1 = one block walks all runs and combines them in registers (SER kernels)
-    int m_begin;                       // k_conv_dma: first output row of this launch (rows [m_begin, M)); 0 unless the launch is split
-    int split;                         // launcher hint: cover the last partial round of the grid with small tiles (see launch_conv_dma_t)
-    int dbg;                           // tuning aid: 1 = no global loads, 2 = no MFMA, 4 = no LDS stores, 8 = no epilogue stores
-    int ngroup;                        // tile order (speed only): N tiles per group, 0 = one group (see rem_to_tile)
-    unsigned dv_hw_mul, dv_hw_shr, dv_w_mul, dv_w_shr;   // magic numbers of m / (ho * wo) and rem / wo (fast_div; filled by set_fast_div)
-};
-
-// Row set-up of the LDS-DMA loaders: output row m -> (sample, oy, ox) with two divisions by run-time constants, and the validity mask of
-// its kh x kw taps.  The compiler's 32-bit division is ~35 vector instructions and the tap double loop ~9 per tap; on short-K tiles (K = 288:
-// 144 MFMAs per wave) the loader's set-up was a third of the 1 337 vector instructions a wave executes (profiles/r04_grouped_conv_pmc.txt).
-// fast_div: q = (mulhi(n, mul) + n) >> shr with shr = ceil(log2 d), mul = floor(2^32 (2^shr - d) / d) + 1 -- exact for n < 2^31.
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned shr) { return (__umulhi(n, mul) + n) >> shr; }
-static void set_fast_div(unsigned d, unsigned &mul, unsigned &shr) {
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    shr = l;
-    mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
-}
-struct RowSetup { int n, iy0, ix0; unsigned vm; };
-__device__ __forceinline__ RowSetup row_setup(const ConvArgs &a, int mm, bool rv) {
-    const int wo = a.out.w, howo = a.out.h * wo;
-    RowSetup r;
-    r.n = (int)fast_div((unsigned)mm, a.dv_hw_mul, a.dv_hw_shr);
-    const int rem = mm - r.n * howo;
-    const int oy = (int)fast_div((unsigned)rem, a.dv_w_mul, a.dv_w_shr), ox = rem - oy * wo;
-    r.iy0 = oy * a.stride - a.pad; r.ix0 = ox * a.stride - a.pad;
-    // taps: valid rows x valid columns (bit kh * kw_count + kw)
-    unsigned colm = 0u, vm = 0u;
-    for (int kw = 0; kw < a.kw; ++kw) { const int ix = r.ix0 + kw * a.dil; colm |= (ix >= 0 && ix < a.in.w) ? 1u << kw : 0u; }
-    for (int kh = 0; kh < a.kh; ++kh) { const int iy = r.iy0 + kh * a.dil; vm |= (iy >= 0 && iy < a.in.h) ? colm << (kh * a.kw) : 0u; }
-    r.vm = rv ? vm : 0u;
-    return r;
-}
-
-// Block -> tile map (speed only).  Workgroups are handed to the 8 XCDs round-robin in launch order, and each XCD has its own L2:
-// give XCD x a CONTIGUOUS run of tiles in the order (z, m-tile, n-tile) with n fastest, so the blocks resident on one XCD
-// share a few activation tiles (read from HBM once, all their N tiles hit L2) instead of streaming the whole activation
-// tensor once per N tile.  L -> (x = L%8, i = L/8) -> j = start(x) + i is a bijection because both sides split `total`
-// into 8 runs whose lengths differ by at most one, longer runs first.
-// Order of the tiles inside one z slice, n fastest.  With `ngroup` (a divisor of the N-tile count, chosen by the host when the layer's
-// weights exceed an XCD's L2) the order is (N group, m tile, n inside the group): an XCD's contiguous run then stays inside ONE group of
-// N tiles whose weight slices fit its 4 MB L2 together with the activation tiles in flight, instead of cycling through the whole weight
-// tensor once per M tile (K = 1024 -> 1024 1x1 at batch 8: 4 MB of weights + 2 MB of activation tiles thrash the L2 -- 243 MB fetched
-// for 56 MB of inputs, profiles/r04_conv_pmc.txt).
-__device__ __forceinline__ void rem_to_tile(unsigned rem, unsigned nm, unsigned nn, int ngroup, int &mt, int &nt) {
-    if (ngroup > 0) {
-        const unsigned per_g = nm * (unsigned)ngroup, gi = rem / per_g, r2 = rem - gi * per_g, m = r2 / (unsigned)ngroup;
-        mt = (int)m; nt = (int)(gi * (unsigned)ngroup + (r2 - m * (unsigned)ngroup));
-    } else {
-        mt = (int)(rem / nn); nt = (int)(rem - (rem / nn) * nn);
-    }
-}
-__device__ __forceinline__ void block_to_tile(int &mt, int &nt, int &z, int ngroup = 0) {
-    const unsigned nm = gridDim.x, nn = gridDim.y, total = nm * nn * gridDim.z;
-    const unsigned L = blockIdx.x + nm * (blockIdx.y + nn * blockIdx.z);
-    const unsigned x = L & 7u, i = L >> 3, q = total >> 3, r = total & 7u;
-    const unsigned j = x * q + (x < r ? x : r) + i;
-    const unsigned per_z = nm * nn, zz = j / per_z, rem = j - zz * per_z;
-    z = (int)zz;
-    rem_to_tile(rem, nm, nn, ngroup, mt, nt);
-}
 
 constexpr int kLdsLd = 36;  // floats per LDS row: 32 + 4 pad (conflict-free b128 reads, see MI355X LDS notes)
 
@@ -460,13 +299,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 4 : 2)) void k_conv_m
 //    block tile (32 TM WM) x (32 TN WN), two LDS stages, ONE raw s_barrier per chunk, vmcnt counted by hand (the loads are
 //    asm: with the builtin hipcc puts vmcnt(0) in front of every ds_read and the prefetch serialises).
 // Requirements (host-checked, else k_conv_mfma): cin_g % 32 == 0, kh*kw <= 32, views < 2 GiB.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void dma16(unsigned voff, i32x4 rsrc, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_byte_addr) : "memory");
-}
 
 template <int WM, int WN, int TM, int TN, int NS, bool SER = false, bool ILV = (CSM_ILV != 0)>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_dma(ConvArgs a) {
@@ -2699,6 +2531,12 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                     csm::set_error("op %d: conv input must be 16-byte aligned with channels %% 4 == 0", i); return CSM_ERR_ARG;
                 }
                 a.dbg = g_dbg;
+                if (op.flags & CSM_CONV_FLAG_WINOGRAD) {      // Winograd F(2x2, 3x3): its own arithmetic (part of the lowering's contract), its own kernel
+                    if (!wino_eligible(a)) { csm::set_error("op %d: Winograd flag on an ineligible convolution (3x3 / stride 1 / pad 1 / dense / cin %% 32 / cout %% 64 / ksplit 1)", i); return CSM_ERR_ARG; }
+                    rc = launch_conv_wino(a, st);
+                    if (rc) return rc;
+                    break;
+                }
                 if (op.flags & 2) {      // stem: (tap, channel)-packed K (weights packed by the host for exactly this kernel)
                     if (op.groups != 1 || op.cin_g != 4 || a.ksplit != 1) { csm::set_error("op %d: stem flag needs groups 1, cin 4, ksplit 1", i); return CSM_ERR_ARG; }
                     dim3 grid((a.M + 63) / 64, (op.cout_g + 63) / 64, 1);
@@ -2904,7 +2742,7 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
     int tuned = 0, rc = CSM_OK;
     for (int i = 0; i < n_ops && rc == CSM_OK; ++i) {
         csm_op &op = ops[i];
-        if (op.kind != CSM_OP_CONV || (op.flags & 2)) continue;          // stems have one dedicated kernel
+        if (op.kind != CSM_OP_CONV || (op.flags & (CSM_CONV_FLAG_STEM | CSM_CONV_FLAG_WINOGRAD))) continue;          // stems and Winograd layers have one dedicated kernel
         const int npad = (op.cout_g + 31) / 32 * 32;
         static const int cand_all[] = {CFG_64x64, CFG_128x32, CFG_64x16, CFG_D64x64, CFG_D128x64, CFG_D64x128, CFG_D128x128,
                                        CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32, CFG_NARROW, CFG_D96x128, CFG_D160x128,

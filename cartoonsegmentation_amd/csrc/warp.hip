@@ -353,30 +353,33 @@ __global__ __launch_bounds__(kBlock) void k_laplacian(const float *__restrict__ 
 }
 
 
-// spatial_filter 'median-5' (models/utils.py:32-36): reflect pad 2, 5x5 window, torch.median = lower median (13th of 25)
-__global__ __launch_bounds__(kBlock) void k_median5(const float *__restrict__ in, float *__restrict__ out, int H, int W) {
+// spatial_filter 'median-3' / 'median-5' (models/utils.py:26-36): reflect pad K/2, K x K window, torch.median = lower median (5th of 9,
+// 13th of 25)
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_median(const float *__restrict__ in, float *__restrict__ out, int H, int W) {
+    constexpr int R = K / 2, NV = K * K;
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const float *I = in + (int64_t)blockIdx.z * H * W;
-    float v[25];
+    float v[NV];
 #pragma unroll
-    for (int dy = -2; dy <= 2; ++dy) {
+    for (int dy = -R; dy <= R; ++dy) {
         int yy = y + dy; yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
 #pragma unroll
-        for (int dx = -2; dx <= 2; ++dx) {
+        for (int dx = -R; dx <= R; ++dx) {
             int xx = x + dx; xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
-            v[(dy + 2) * 5 + (dx + 2)] = I[(int64_t)yy * W + xx];
+            v[(dy + R) * K + (dx + R)] = I[(int64_t)yy * W + xx];
         }
     }
-    // rank of each element (ties broken by index) -> the element of rank 12 is the lower median
+    // rank of each element (ties broken by index) -> the element of rank (NV - 1) / 2 is the lower median
     float med = v[0];
 #pragma unroll
-    for (int i = 0; i < 25; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int rank = 0;
 #pragma unroll
-        for (int j = 0; j < 25; ++j) rank += (v[j] < v[i] || (v[j] == v[i] && j < i)) ? 1 : 0;
-        if (rank == 12) med = v[i];
+        for (int j = 0; j < NV; ++j) rank += (v[j] < v[i] || (v[j] == v[i] && j < i)) ? 1 : 0;
+        if (rank == (NV - 1) / 2) med = v[i];
     }
     out[((int64_t)blockIdx.z * H + y) * W + x] = med;
 }
@@ -533,8 +536,14 @@ extern "C" int csm_spatial_filter_laplacian(const float *in, float *out, int BC,
 
 extern "C" int csm_spatial_filter_median5(const float *in, float *out, int BC, int H, int W, void *stream) {
     CSM_REQUIRE(in && out && in != out && BC > 0 && H > 2 && W > 2);
-    k_median5<<<grid2d(W, H, BC, 64, 4), kBlock, 0, (hipStream_t)stream>>>(in, out, H, W);
+    k_median<5><<<grid2d(W, H, BC, 64, 4), kBlock, 0, (hipStream_t)stream>>>(in, out, H, W);
     return csm::check_launch("k_median5");
+}
+
+extern "C" int csm_spatial_filter_median3(const float *in, float *out, int BC, int H, int W, void *stream) {
+    CSM_REQUIRE(in && out && in != out && BC > 0 && H > 1 && W > 1);
+    k_median<3><<<grid2d(W, H, BC, 64, 4), kBlock, 0, (hipStream_t)stream>>>(in, out, H, W);
+    return csm::check_launch("k_median3");
 }
 
 extern "C" int csm_depth_to_points(const float *depth, float *pts, int B, int H, int W, double focal, void *stream) {

@@ -1,0 +1,306 @@
+// wino.hip -- exact-fp32 Winograd F(2x2, 3x3) convolution on the matrix pipe (gfx950), fused: input transform in registers,
+// 16 frequency GEMMs on v_mfma_f32_32x32x2_f32, output transform + bias + residual + activation in the epilogue.
+//
+// Why: 3x3 / stride-1 dense convolutions carry two thirds of the dense nets' time (ISNet almost entirely; LeReS' decoder; RTMDet's
+// CSP blocks) and the direct implicit-GEMM kernels of nets.hip run them at 0.87-0.91 of the fp32 MFMA peak -- there is nothing left in
+// the inner loop, so the lever is the FLOP count: F(2x2, 3x3) needs 16 multiplications per 2x2 output tile and channel pair where the
+// direct form needs 36 (2.25x), with transform matrices made of 0, +-1, +-1/2 (error: a few fp32 ulps).
+//
+// Arithmetic = the "Winograd contract" of include/csm355.h, restated independently in oracle/nets_oracle.c::orc_conv_wino; this
+// kernel reproduces it bit for bit (every transform value is ONE fp32 operation, every product sum ONE fmaf chain in the direct
+// contract's channel order -- fp32 MFMA is bitwise an fmaf chain over k).
+//
+// Mapping (CDNA4-first):
+//   * block = 4 waves (WM x WN = 2 x 2), ONE block per CU (512 registers per wave): 16 x 4 Winograd tiles (32 x 8 output pixels) x 64
+//     output channels.  A wave owns 32 tiles x 32 channels x ALL 16 frequencies = sixteen 32x32 accumulators (256 AGPRs), so the output
+//     transform is lane-local: no exchange, no extra pass over HBM.
+//   * the MFMA A operand never exists in memory: a lane (tile, k-half) reads its tile's 4 x 4 raw input window from the LDS patch
+//     (16 ds_read_b128 = 4 channels each), does the 32 adds of B^T d B per channel in registers (VALU issues in the shadow of the
+//     64-cycle fp32 MFMAs) and feeds 64 MFMAs with the result.  LDS holds only the raw (OH + 2) x (OW + 2) x 32-channel patch, moved by
+//     LDS-DMA, stored de-interleaved by column parity so that the stride-2 tile windows of a lane group are consecutive 128-B rows
+//     (XOR-swizzled 16-B slots: conflict-free ds_read_b128).
+//   * transformed weights U are packed on the host in exactly the LDS image of one pipeline step (8 input channels: [f][k-half][64 co][4]
+//     = 32 KB), so the B side is a linear LDS-DMA copy and a B fragment is ONE conflict-free ds_read_b128 per frequency.
+//   * pipeline: step = 8 input channels = 64 MFMAs per wave (4096 cycles); ONE barrier per step, placed in front of the step's last
+//     MFMA group, after which the other U stage is known to have landed and the stage just read is refilled -- every DMA piece has a
+//     full step to land; fragments, raw windows and transform values are all produced one MFMA group ahead of their use.
+#include "csm_conv.h"
+#include <utility>
+
+using namespace csmconv;
+
+namespace {
+
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f32x4n *lds_f4_ptr;
+
+__device__ __forceinline__ f32x4n lds_read4(unsigned byte_addr) { return *(lds_f4_ptr)(size_t)byte_addr; }
+
+// LDS-DMA piece with a scalar byte offset on the global side (no address VALU): 64 lanes x 16 B -> LDS [lds_byte_addr, +1 KB)
+__device__ __forceinline__ void dma16s(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory");
+}
+
+template <int N> using ic = std::integral_constant<int, N>;
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// B^T rows: one fp32 operation per value (the contract's order)
+__device__ __forceinline__ float bt_row(int i, float d0, float d1, float d2, float d3) {
+    return i == 0 ? d0 - d2 : (i == 1 ? d1 + d2 : (i == 2 ? d2 - d1 : d1 - d3));
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int NW = WM * WN;
+    constexpr int OH = 4 * WM, OW = 32;                       // output pixels of a block
+    constexpr int PH = OH + 2, PWH = 18;                       // patch rows; entries per (parity, row): px = 2 pxh + parity < OW + 2, padded to even
+    constexpr int NENT = 2 * PH * PWH, NPP = (NENT + 7) / 8;   // patch entries (128 B each) / DMA pieces
+    constexpr int QP = (NPP + NW - 1) / NW;                    // patch pieces per wave
+    constexpr int QG = (QP + 2) / 3;                           // ... issued in three steps
+    constexpr unsigned kPatchB = NPP * 1024u, kUB = 32768u, kU0 = 2u * kPatchB;
+    constexpr int UPW = 32 / NW;                               // U pieces per wave per stage
+    static_assert(WN == 2 && UPW * NW == 32 && (NENT % 8) == 0 && (PWH & 1) == 0, "tile shape");
+    constexpr unsigned kOob = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [patch 0][patch 1][U 0][U 1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    int mt, ntile, zz;
+    block_to_tile(mt, ntile, zz, 0);
+    const int btx = mt % tiles_x, bty = (mt / tiles_x) % tiles_y, n = mt / (tiles_x * tiles_y);
+    const int ho = a.out.h, wo = a.out.w;
+    const int ncb = a.ncb, nsteps = 4 * ncb;
+    const int oy0 = bty * OH, ox0 = btx * OW;
+
+    i32x4 ra, rb;
+    {
+        uint64_t pa = (uint64_t)a.in.p, pb = (uint64_t)a.w;
+        unsigned na = (unsigned)((((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4);
+        unsigned nb = (unsigned)((int64_t)(a.cout_g / 64) * nsteps * kUB);
+        ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
+        rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
+    }
+    // ---- patch loader: wave w owns pieces w, w + NW, ... (a piece past the end repeats the last one: same bytes, same place) ----
+    // entry e = (parity * PH + py) * PWH + pxh holds patch pixel (py, 2 pxh + parity); its 16-B slot s sits at physical slot s ^ key,
+    // key = (pxh >> 1) & 7: the 16 lanes of a ds_read_b128 group read 16 distinct pxh (mod 16) of rows whose first entry is even.
+    unsigned offP[QP], ldsP[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        int p = wave + q * NW;
+        if (p > NPP - 1) p = NPP - 1;
+        const int e = 8 * p + (lane >> 3);
+        const int par = e / (PH * PWH), rem = e - par * (PH * PWH), py = rem / PWH, pxh = rem - py * PWH;
+        const int px = 2 * pxh + par, slot = (lane & 7) ^ ((pxh >> 1) & 7);
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool v = px < OW + 2 && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+        offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
+        ldsP[q] = (unsigned)p * 1024u;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned voffU = (unsigned)lane * 16u;
+    unsigned u_src = (unsigned)(ntile * nsteps) * kUB + (unsigned)(wave * UPW) * 1024u;   // this wave's first piece of the NEXT U stage to fetch
+    const unsigned ldsU = lds0 + kU0 + (unsigned)(wave * UPW) * 1024u;
+
+    // pieces [k0, k1) of U stage `u_src` -> LDS stage par
+    auto issue_u = [&](int par, int k0, int k1, bool live) {
+        const unsigned vo = live ? voffU : kOob;
+#pragma unroll
+        for (int k = k0; k < k1; ++k) dma16s(vo, rb, u_src + (unsigned)k * 1024u, ldsU + (unsigned)par * kUB + (unsigned)k * 1024u);
+    };
+    // pieces [q0, q1) of the patch of channel block cbn -> patch stage cbn & 1
+    auto issue_patch = [&](int cbn, int q0, int q1, bool live) {
+        const unsigned sb = lds0 + (unsigned)(cbn & 1) * kPatchB;
+#pragma unroll
+        for (int q = q0; q < q1; ++q)
+            if (q < QP) dma16s(live ? offP[q] : kOob, ra, (unsigned)cbn * 128u, sb + ldsP[q]);
+    };
+
+    // ---- fragment addresses ----
+    // raw window of the lane's tile (tx = li & 15, ty = 2 wm + (li >> 4)): position (i, j) is entry e0 + ((j & 1) PH + i) PWH + (j >> 1)
+    const int tx = li & 15, ty = 2 * wm + (li >> 4);
+    unsigned rbase[2];
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh)
+        rbase[jh] = lds0 + (unsigned)((2 * ty) * PWH + tx) * 128u + (unsigned)((lh ^ (((tx + jh) >> 1) & 7)) << 4);
+    const unsigned ub = lds0 + kU0 + (unsigned)(lh * 64 + wn * 32 + li) * 16u;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+
+    float R[16][4];           // raw window of the NEXT step (4 channels per position)
+    float T[4][4][4];         // row-transformed window of the current step: T[i][j][c]
+    float V[2][4][4];         // A operands of an MFMA group: V[buf][j][c]
+    f32x4n Bq[2][4];          // B fragments of an MFMA group
+
+    auto read_raw = [&](int cbn, int sub, int p0, int p1) {            // positions [p0, p1) of step (cbn, sub) -> R
+        unsigned b[2];
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) b[jh] = (rbase[jh] + (unsigned)(cbn & 1) * kPatchB) ^ (unsigned)(sub << 5);
+#pragma unroll
+        for (int p = p0; p < p1; ++p) {
+            const int i = p >> 2, j = p & 3;
+            const f32x4n v = lds_read4(b[j >> 1] + (unsigned)((((j & 1) * PH + i) * PWH + (j >> 1)) * 128));
+            R[p][0] = v.x; R[p][1] = v.y; R[p][2] = v.z; R[p][3] = v.w;
+        }
+    };
+    auto read_b = [&](int par, int g, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bq[buf][j] = lds_read4(ub + (unsigned)par * kUB + (unsigned)(4 * g + j) * 2048u);
+    };
+    // op k of the row pass (64 ops): T[i][j][c] from R, k = 16 i + 4 j + c
+    auto row_op = [&](auto K) {
+        constexpr int k = decltype(K)::value, i = k >> 4, j = (k >> 2) & 3, c = k & 3;
+        T[i][j][c] = bt_row(i, R[0 + j][c], R[4 + j][c], R[8 + j][c], R[12 + j][c]);
+    };
+    // op k of the column pass of group g (16 ops): V[buf][j][c] from T[g], k = 4 j + c
+    auto col_op = [&](auto G, auto BUF, auto K) {
+        constexpr int g = decltype(G)::value, buf = decltype(BUF)::value, k = decltype(K)::value, j = k >> 2, c = k & 3;
+        V[buf][j][c] = bt_row(j, T[g][0][c], T[g][1][c], T[g][2][c], T[g][3][c]);
+    };
+
+    // ---- DMA schedule (every piece gets at least three MFMA groups = 3 000 cycles to land before the barrier that publishes it) ----
+    //   U stage of step s + 2 -> the stage step s read: first half behind the barrier of step s (group 3), second half in group 0 of step
+    //   s + 1.  Patch of channel block cb + 2 -> the stage block cb read (released by the barrier of step (cb, 2)): a third each in group
+    //   1 of steps (cb, 3), (cb + 1, 0), (cb + 1, 1); it is first read in step (cb + 1, 3), behind the barrier of (cb + 1, 2).
+    // ---- prologue ----
+    issue_patch(0, 0, QP, true);
+    issue_u(0, 0, UPW, true); u_src += kUB;
+    issue_u(1, 0, UPW / 2, nsteps > 1);
+    issue_patch(1, 0, QG, ncb > 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_raw(0, 0, 0, 16);
+    read_b(0, 0, 0);
+    static_for<64>([&](auto K) { row_op(K); });
+    static_for<16>([&](auto K) { col_op(ic<0>{}, ic<0>{}, K); });
+
+    // ---- main loop: one iteration = one 32-channel block = 4 steps x 4 MFMA groups of 16 ----
+    for (int cb = 0; cb < ncb; ++cb) {
+        static_for<4>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int cbn = q == 3 ? cb + 1 : cb;                  // channel block / sub-step of the NEXT step
+            constexpr int subn = (q + 1) & 3;
+            const int s = 4 * cb + q;
+            static_for<4>([&](auto G) {
+                constexpr int g = decltype(G)::value, buf = g & 1;
+                if constexpr (g == 3) {
+                    // everybody's pieces of the next U stage (and the older patch pieces) have landed; everybody has finished reading this
+                    // step's U stage and -- at q == 2 -- this channel block's patch
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    read_b((q + 1) & 1, 0, buf ^ 1);
+                } else {
+                    read_b(q & 1, g + 1, buf ^ 1);
+                    read_raw(cbn, subn, g == 0 ? 0 : (g == 1 ? 6 : 11), g == 0 ? 6 : (g == 1 ? 11 : 16));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<16>([&](auto M) {
+                    constexpr int m = decltype(M)::value, tt = m >> 2, j = m & 3;
+                    const f32x4n bf = Bq[buf][j];
+                    const float bv = tt == 0 ? bf.x : (tt == 1 ? bf.y : (tt == 2 ? bf.z : bf.w));
+                    acc[4 * g + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[buf][j][tt], bv, acc[4 * g + j], 0, 0, 0);
+                    // this slot's share of the transform work for the NEXT group
+                    if constexpr (g < 3) {
+                        col_op(ic<g + 1>{}, ic<(buf ^ 1)>{}, M);
+                    } else {                                        // next step: row pass (64 ops), then group 0's column pass (16)
+                        static_for<5>([&](auto E) {
+                            constexpr int k = 5 * m + decltype(E)::value;
+                            if constexpr (k < 64) row_op(ic<k>{});
+                            else if constexpr (k < 80) col_op(ic<0>{}, ic<0>{}, ic<k - 64>{});
+                        });
+                    }
+                    // DMA pieces in MFMA slots 1, 5, 9, 13
+                    if constexpr ((m & 3) == 1) {
+                        constexpr int k = m >> 2;
+                        if constexpr (g == 3) {
+                            issue_u(q & 1, k * (UPW / 8), (k + 1) * (UPW / 8), s + 2 < nsteps);
+                        } else if constexpr (g == 0) {
+                            issue_u((q + 1) & 1, UPW / 2 + k * (UPW / 8), UPW / 2 + (k + 1) * (UPW / 8), s + 1 < nsteps);
+                            if constexpr (k == 3) u_src += kUB;
+                        } else if constexpr (g == 1 && q != 2) {
+                            constexpr int grp = q == 3 ? 0 : q;                       // q = 3, 0, 1 -> thirds 0, 1, 2 ... (q == 0 -> 1, q == 1 -> 2)
+                            constexpr int third = q == 3 ? 0 : (q == 0 ? 1 : 2);
+                            (void)grp;
+                            const int cbp = q == 3 ? cb + 2 : cb + 1;
+                            constexpr int per = (QG + 3) / 4;
+                            issue_patch(cbp, third * QG + k * per, third * QG + (k + 1) * per < (third + 1) * QG ? third * QG + (k + 1) * per : (third + 1) * QG, cbp < ncb);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetches must land before the block's LDS is released
+
+    // ---- epilogue: output transform A^T M A (columns j first), bias, residual, activation.  Lane (li, lh) holds output channel li of the
+    // wave's 32 and, in accumulator element r, the tile (tx, ty) = ((r & 3) + 8 ((r >> 2) & 1) + 4 lh, r >> 3) of the wave's 16 x 2 ----
+    const int co = ntile * 64 + 32 * wn + li;
+    const float bias = a.bias ? a.bias[co] : 0.0f;
+    const float slope = a.slope ? a.slope[co] : 0.0f;
+    const int64_t ldo = a.out.ld, ldr = a.res.ld;
+    const int oyb = oy0 + 4 * wm, oxb = ox0 + 8 * lh;
+    const int64_t mb = ((int64_t)n * ho + oyb) * wo + oxb;
+    float *ob = a.out.p + mb * ldo + co;
+    const float *rp = a.res_mode ? a.res.p + mb * ldr + co : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float sj[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float m0 = acc[4 * i][r], m1 = acc[4 * i + 1][r], m2 = acc[4 * i + 2][r], m3 = acc[4 * i + 3][r];
+            sj[i][0] = (m0 + m1) + m2;
+            sj[i][1] = (m1 - m2) - m3;
+        }
+        const int dyt = 2 * (r >> 3), dxt = 2 * ((r & 3) + 8 * ((r >> 2) & 1));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float y0 = (sj[0][b] + sj[1][b]) + sj[2][b], y1 = (sj[1][b] - sj[2][b]) - sj[3][b];
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const int dy = dyt + aa, dx = dxt + b;
+                if (oyb + dy >= ho || oxb + dx >= wo) continue;
+                const int64_t eo = (int64_t)dy * wo + dx;
+                float v = (aa == 0 ? y0 : y1) + bias;
+                if (a.res_mode == 1) v += rp[eo * ldr];
+                v = apply_act(v, a.act, slope);
+                if (a.res_mode == 2) v += rp[eo * ldr];
+                ob[eo * ldo] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace csmconv {
+
+bool wino_eligible(const ConvArgs &a) {
+    const int64_t bytes_in = (((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4;
+    const int64_t bytes_w = (int64_t)(a.cout_g / 64) * a.ncb * 4 * 32768;
+    return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil == 1 && a.pad == 1 && a.groups == 1 && a.ksplit <= 1 && (a.cin_g & 31) == 0 &&
+           (a.cout_g & 63) == 0 && bytes_in < (1ll << 31) && bytes_w < (1ll << 31) && !(a.in.ld & 3) && !(((uintptr_t)a.in.p | (uintptr_t)a.w) & 15) &&
+           a.out.h == a.in.h && a.out.w == a.in.w;
+}
+
+int launch_conv_wino(const ConvArgs &a0, hipStream_t st) {
+    constexpr int WM = 2, WN = 2, OH = 4 * WM, OW = 32;
+    constexpr size_t lds = (size_t)2 * ((2 * (OH + 2) * 18 + 7) / 8) * 1024 + (size_t)2 * 32768;
+    ConvArgs a = a0;
+    const int tiles_x = (a.out.w + OW - 1) / OW, tiles_y = (a.out.h + OH - 1) / OH;
+    a.m_tiles = tiles_x * tiles_y * a.out.n;
+    static KernelPrep prep;
+    (void)prep.ensure([&] { return prepare_kernel(&k_conv_wino<WM, WN>, 64 * WM * WN, lds); });
+    dim3 grid(a.m_tiles, a.cout_g / 64, 1);
+    k_conv_wino<WM, WN><<<grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y);
+    return csm::check_launch("k_conv_wino");
+}
+
+}  // namespace csmconv

@@ -109,13 +109,16 @@ def fill_disocclusion(tenInput, tenDepth):
 
 
 def spatial_filter(tenInput, strType):
-    """spatial_filter -- anime_3dkenburns/models/utils.py:9-40 ('laplacian' is the hot-path mode)"""
-    if strType not in ('laplacian', 'median-5'):
-        raise NotImplementedError("spatial_filter(%r): 'laplacian' and 'median-5' are the modes the hot path uses" % strType)
+    """spatial_filter -- anime_3dkenburns/models/utils.py:9-40: 'laplacian' (the hot-path mode), 'median-3', 'median-5'"""
+    L = _lib.load()
+    fns = {'laplacian': L.csm_spatial_filter_laplacian, 'median-3': L.csm_spatial_filter_median3, 'median-5': L.csm_spatial_filter_median5}
+    if strType not in fns:
+        raise ValueError("spatial_filter(%r): the reference knows 'laplacian', 'median-3' and 'median-5' (any other type leaves its "
+                         "tenOutput None)" % (strType,))
     tenInput = _dev(tenInput, "tenInput")
     B, C, H, W = tenInput.shape
     out = torch.empty_like(tenInput)
-    fn = _lib.load().csm_spatial_filter_laplacian if strType == 'laplacian' else _lib.load().csm_spatial_filter_median5
+    fn = fns[strType]
     check(fn(ptr(tenInput), ptr(out), i32(B * C), i32(H), i32(W), stream_ptr()), "spatial_filter")
     return out
 

@@ -101,6 +101,44 @@ def pack_stem_weights(w):
     return packed.reshape(-1)
 
 
+# ---- Winograd F(2x2, 3x3) (include/csm355.h "Winograd contract") ------------------------------------------------------------------
+# Which layers take it is part of the NUMERICAL contract of a lowered program (the result differs from the direct chain by fp32
+# rounding), so the rule sees one sample's shape only -- never the batch, never the tuner: 3x3 / stride 1 / dilation 1 / pad 1 / dense,
+# cin % 32 == 0, cout % 64 == 0 and at least WINO_MIN_PIXELS output pixels per sample.  CSM_CONV_EXACT_DIRECT=1 lowers every layer to
+# the direct chain (the round-1..4 arithmetic).
+CONV_FLAG_STEM, CONV_FLAG_WINOGRAD = 2, 4
+WINO_ENABLE = os.environ.get('CSM_CONV_EXACT_DIRECT', '0') != '1'
+WINO_MIN_PIXELS = int(os.environ.get('CSM_WINO_MIN_PIXELS', '25600'))
+WINO_BN = 64
+
+
+def wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo):
+    return (kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and groups == 1 and cin_g % 32 == 0 and cout % WINO_BN == 0
+            and ho * wo >= WINO_MIN_PIXELS)
+
+
+def wino_transform(w):
+    """w [cout, cin, 3, 3] fp32 -> U [16, cout, cin] fp32 = G g G^T, float64 arithmetic in the contract's fixed order (rows, then columns;
+    each row (g0, ((g0 + g1) + g2) / 2, ((g0 - g1) + g2) / 2, g2)) -- elementwise numpy operations only, so every value is the IEEE
+    result of the same expression the oracle evaluates in C"""
+    g = np.asarray(w, np.float64)
+
+    def rows(g0, g1, g2):
+        return [g0, ((g0 + g1) + g2) * 0.5, ((g0 - g1) + g2) * 0.5, g2]
+    r = rows(g[:, :, 0, :], g[:, :, 1, :], g[:, :, 2, :])                 # 4 x [cout, cin, 3]
+    u = [rows(ri[:, :, 0], ri[:, :, 1], ri[:, :, 2]) for ri in r]         # u[i][j] [cout, cin]
+    return np.stack([u[i][j] for i in range(4) for j in range(4)]).astype(np.float32)
+
+
+def pack_wino_weights(w):
+    """-> packed fp32 1-D in the LDS image order of k_conv_wino: [cout / 64][cb][q][f][h][64][4], channel 32 cb + 8 q + 4 h + e"""
+    cout, cin = w.shape[:2]
+    assert cout % WINO_BN == 0 and cin % 32 == 0
+    U = wino_transform(w)                                                  # [16, cout, cin]
+    U = U.reshape(16, cout // WINO_BN, WINO_BN, cin // 32, 4, 2, 4)       # f, nt, co, cb, q, h, e
+    return np.ascontiguousarray(U.transpose(1, 3, 4, 0, 5, 2, 6)).reshape(-1)   # nt, cb, q, f, h, co, e
+
+
 class Buf:
     def __init__(self, n, h, w, c, ext=-1, nchw=False):
         self.n, self.h, self.w, self.c, self.ext, self.nchw = n, h, w, c, ext, nchw
@@ -209,8 +247,11 @@ class Program:
             out = self.buffer(x.n, ho, wo, cout)
         assert out.shape == (x.n, ho, wo, cout), (out.shape, (x.n, ho, wo, cout))
         stem = groups == 1 and cin_g == 4 and cout > 4        # k_conv_stem: (tap, channel)-packed K, csm_op.flags bit 1
+        wino = self.winograd and wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo)
         if stem:
             packed, sg, cin_sg, cout_sg = pack_stem_weights(w), 1, 4, cout
+        elif wino:
+            packed, sg, cin_sg, cout_sg = pack_wino_weights(w), 1, cin_g, cout
         else:
             packed, sg, cin_sg, cout_sg = pack_conv_weights(w, groups)
         w_h, w_n = self._w(packed, w)
@@ -221,15 +262,17 @@ class Program:
             a_h, a_n = self._w(slope, slope)
         self.flops += 2 * x.n * ho * wo * cout * cin_g * kh * kw
         self.conv_bytes += 4 * (x.n * x.h * x.w * x.c + x.n * ho * wo * cout + w.size)
-        ksplit, scr = (1 if stem else self.choose_ksplit(ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups)), None
+        ksplit, scr = (1 if stem or wino else self.choose_ksplit(ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups)), None
         if ksplit > 1:
             scr = self.buffer(x.n, ho, wo, ksplit * cout)
         return self._emit(OP_CONV, x, res, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, groups=sg, cin_g=cin_sg,
                           cout_g=cout_sg, act=ACT[act], res_mode=res_mode if res is not None else 0, w_off=w_h, b_off=b_h,
-                          aux_off=a_h, ksplit=ksplit, scratch=-1 if scr is None else scr.id, scratch_view=scr, flags=2 if stem else 0,
+                          aux_off=a_h, ksplit=ksplit, scratch=-1 if scr is None else scr.id, scratch_view=scr,
+                          flags=CONV_FLAG_STEM if stem else (CONV_FLAG_WINOGRAD if wino else 0),
                           nat=dict(groups=groups, cin_g=cin_g, cout_g=cout // groups, w_off=w_n, b_off=b_n, aux_off=a_n))
 
     split_k = True
+    winograd = WINO_ENABLE          # (class default; a test may lower one program with / without it)
 
     def choose_ksplit(self, M, N, T, groups):
         """small feature maps (M = output pixels of ONE sample): not enough 64x64 output tiles to fill 256 CUs -> cut K

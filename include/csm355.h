@@ -82,6 +82,9 @@ int csm_spatial_filter_laplacian(const float *in, float *out, int BC, int H, int
 /* spatial_filter(x,'median-5')   models/utils.py:32-36 (reflect pad, lower median of 25) ; x,out [BC,H,W] */
 int csm_spatial_filter_median5(const float *in, float *out, int BC, int H, int W, void *stream);
 
+/* spatial_filter(x,'median-3')   models/utils.py:26-30 (reflect pad 1, lower median of 9) ; x,out [BC,H,W] */
+int csm_spatial_filter_median3(const float *in, float *out, int BC, int H, int W, void *stream);
+
 /* depth_to_points   models/utils.py:43-50 ; depth [B,1,H,W] -> pts [B,3,H,W] */
 int csm_depth_to_points(const float *depth, float *pts, int B, int H, int W, double focal, void *stream);
 
@@ -223,6 +226,19 @@ typedef struct csm_tensor_desc {
     int32_t ld;          /* channel pitch in floats (>= c); NCHW ext tensors: ld is ignored */
 } csm_tensor_desc;
 
+/* Winograd contract (csm_op.flags & CSM_CONV_FLAG_WINOGRAD; restated in oracle/nets_oracle.c::orc_conv_wino, executed by
+ * csrc/nets.hip::k_conv_wino): F(2x2, 3x3) with the transform matrices of Lavin & Gray (0, +-1, +-1/2 only).
+ *   U[f = 4i + j][co][c] = fp32(G g G^T) evaluated in double, rows first: r0 = g0, r1 = ((g0 + g1) + g2) / 2, r2 = ((g0 - g1) + g2) / 2,
+ *                          r3 = g2, then the same over the columns;
+ *   V = B^T d B on the 4 x 4 input window d (origin (2 ty - 1, 2 tx - 1), zeros outside): t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1,
+ *                          t3 = d1 - d3 over the row index first, then over the column index -- one fp32 operation per value;
+ *   M[f] = one fmaf chain per (f, tile, co) over the input channels from 0.0f, channel order of the direct contract;
+ *   Y = A^T M A over j first: s0 = (m0 + m1) + m2, s1 = (m1 - m2) - m3, then over i; y = Y + bias; residual / activation as usual.
+ * Packed device weights (cout tile of 64, 32-channel block cb, 8-channel step q): [co / 64][cb][q][f][h][co % 64][4] with channel
+ * c = 32 cb + 8 q + 4 h + e at element e -- exactly the LDS image of one pipeline step (32 KB), moved by a linear LDS-DMA copy. */
+#define CSM_CONV_FLAG_STEM 2
+#define CSM_CONV_FLAG_WINOGRAD 4
+
 typedef struct csm_op {
     int32_t kind;
     int32_t in0, in1, out;   /* tensor ids; in1 = residual / second operand, -1 if none */
@@ -232,7 +248,11 @@ typedef struct csm_op {
     int32_t act, res_mode;   /* res_mode: 0 none, 1 add before act, 2 add after act */
     int64_t w_off, b_off, aux_off;   /* float offsets into the weight buffer (aux = PReLU slopes); -1 = none */
     int32_t flags;           /* BILINEAR: bit 0 = align_corners.  CONV: bit 1 = stem (cin padded to 4): weights are packed with K =
-                                (tap, channel), 8 taps x 4 channels per 32-wide chunk, for k_conv_stem; the chain is unchanged */
+                                (tap, channel), 8 taps x 4 channels per 32-wide chunk, for k_conv_stem; the chain is unchanged.
+                                CONV bit 2 (CSM_CONV_FLAG_WINOGRAD): exact-fp32 Winograd F(2x2, 3x3) arithmetic (3x3, stride 1, dilation
+                                1, pad 1, dense, cin % 32 == 0, cout % 64 == 0, ksplit 1): weights are the transformed panels
+                                U = G g G^T packed for k_conv_wino; part of the NUMERICAL contract (set by the lowering from the layer's
+                                per-sample shape, never by the tuner) -- see "Winograd contract" below */
     int32_t ksplit;          /* CONV: K is cut into `ksplit` runs of (32-channel block, tap) chunks (block-major), run s = chunks
                                 [s*T/ksplit, (s+1)*T/ksplit); each run is its own fmaf chain (run 0 starts at the bias,
                                 the others at 0) and the runs are added in order ((p0+p1)+p2)...  1 = single chain */

@@ -233,6 +233,120 @@ static void orc_conv_fast(const csm_op *op, view_t in, view_t res, view_t out, c
     free(Wt); free(cidx); free(ncnt); free(koff); free(run_of);
 }
 
+/* ---- Winograd F(2x2, 3x3) convolution (csm_op.flags bit 2; 3x3, stride 1, dilation 1, pad 1, groups 1) -----------------------------
+ * Same result as a direct 3x3 convolution up to fp32 rounding (2.25x fewer multiplications), with its OWN fixed arithmetic -- the
+ * contract the HIP kernel k_conv_wino executes bit for bit:
+ *   weights   U[f][co][c] = fp32( G g G^T ), f = 4 i + j, evaluated in DOUBLE in a fixed order: rows of G applied to the kernel's rows
+ *             first (r0 = g0, r1 = ((g0 + g1) + g2) * 0.5, r2 = ((g0 - g1) + g2) * 0.5, r3 = g2), then the same to the columns.  This
+ *             function derives U from the NATURAL [cout][cin][3][3] weights itself; the product's host code packs its own copy.
+ *   input     d[i][j] = x[2 ty - 1 + i][2 tx - 1 + j] (0 outside the image); t_0 = d_0 - d_2, t_1 = d_1 + d_2, t_2 = d_2 - d_1,
+ *             t_3 = d_1 - d_3 over the ROW index i first, then the same over the column index j: V[i][j], one fp32 operation each.
+ *   products  M[f] = fmaf chain over the input channels starting at 0.0f, in the direct convolution's channel order (32-channel blocks
+ *             ascending, aligned 8-blocks in the order 0,4,1,5,2,6,3,7).
+ *   output    over j first: s[i][0] = (M[i][0] + M[i][1]) + M[i][2], s[i][1] = (M[i][1] - M[i][2]) - M[i][3]; then over i:
+ *             Y[0][b] = (s[0][b] + s[1][b]) + s[2][b], Y[1][b] = (s[1][b] - s[2][b]) - s[3][b]; y = Y + bias; residual / activation as in
+ *             orc_conv.  Output pixel (2 ty + a, 2 tx + b); tiles cover ceil(h / 2) x ceil(w / 2), the excess is dropped.
+ * The transforms contain only 0, +-1, +-0.5: |error| vs the direct chain is a few fp32 ulps of the largest partial sum. */
+static void orc_wino_weights(const float *W, int cout, int cin, const int *cidx, float *U /* [cout][cin in CHAIN order][16] */)
+{
+#pragma omp parallel for schedule(static)
+    for (int co = 0; co < cout; ++co)
+        for (int k = 0; k < cin; ++k) {
+            const float *g = W + ((int64_t)co * cin + cidx[k]) * 9;
+            double r[4][3], u[4][4];
+            for (int x = 0; x < 3; ++x) {
+                const double g0 = g[x], g1 = g[3 + x], g2 = g[6 + x];
+                r[0][x] = g0; r[1][x] = ((g0 + g1) + g2) * 0.5; r[2][x] = ((g0 - g1) + g2) * 0.5; r[3][x] = g2;
+            }
+            for (int i = 0; i < 4; ++i) {
+                const double g0 = r[i][0], g1 = r[i][1], g2 = r[i][2];
+                u[i][0] = g0; u[i][1] = ((g0 + g1) + g2) * 0.5; u[i][2] = ((g0 - g1) + g2) * 0.5; u[i][3] = g2;
+            }
+            for (int f = 0; f < 16; ++f) U[((int64_t)co * cin + k) * 16 + f] = (float)u[f >> 2][f & 3];
+        }
+}
+
+static void orc_conv_wino(const csm_op *op, view_t in, view_t res, view_t out, const float *W, const float *bias, const float *slope)
+{
+    const int cin = op->cin_g, cout = op->cout_g, ncb = (cin + 31) / 32;
+    const int ty_n = (out.h + 1) / 2, tx_n = (out.w + 1) / 2;
+    int *cidx = (int *)malloc(sizeof(int) * (size_t)ncb * 32);
+    int K = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int kb = cb * 32; kb < cb * 32 + 32 && kb < cin; kb += 8)
+            for (int t = 0; t < 4; ++t)
+                for (int h = 0; h < 2; ++h) { int c = kb + 4 * h + t; if (c < cin) cidx[K++] = c; }
+    float *U = (float *)malloc(sizeof(float) * (size_t)16 * cout * cin);
+    orc_wino_weights(W, cout, cin, cidx, U);
+    const int64_t T = (int64_t)out.n * ty_n * tx_n;
+#pragma omp parallel
+    {
+        float *V = (float *)malloc(sizeof(float) * (size_t)16 * cin);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t tile = 0; tile < T; ++tile) {
+            const int n = (int)(tile / ((int64_t)ty_n * tx_n)), rem = (int)(tile - (int64_t)n * ty_n * tx_n);
+            const int ty = rem / tx_n, tx = rem - ty * tx_n;
+            const float *xp[16];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const int iy = 2 * ty - 1 + i, ix = 2 * tx - 1 + j;
+                    xp[4 * i + j] = (iy < 0 || iy >= in.h || ix < 0 || ix >= in.w) ? NULL : in.p + ((int64_t)(n * in.h + iy) * in.w + ix) * in.ld;
+                }
+            for (int k = 0; k < cin; ++k) {
+                const int c = cidx[k];
+                float d[4][4], t[4][4];
+                for (int q = 0; q < 16; ++q) d[q >> 2][q & 3] = xp[q] ? xp[q][c] : 0.0f;
+                for (int j = 0; j < 4; ++j) {
+                    t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+                }
+                for (int i = 0; i < 4; ++i) {
+                    V[k * 16 + 4 * i + 0] = t[i][0] - t[i][2]; V[k * 16 + 4 * i + 1] = t[i][1] + t[i][2];
+                    V[k * 16 + 4 * i + 2] = t[i][2] - t[i][1]; V[k * 16 + 4 * i + 3] = t[i][1] - t[i][3];
+                }
+            }
+            for (int co0 = 0; co0 < cout; co0 += 4) {
+              /* four output channels x 16 frequencies = 64 independent chains (vector lanes = frequencies): same chain per (f, co) */
+              float m4[4][16] __attribute__((aligned(32)));
+              const int nco = cout - co0 < 4 ? cout - co0 : 4;
+              for (int q = 0; q < 4; ++q) for (int f = 0; f < 16; ++f) m4[q][f] = 0.0f;
+              const float *u0 = U + (int64_t)co0 * cin * 16, *u1 = u0 + (nco > 1 ? (int64_t)cin * 16 : 0),
+                          *u2 = u0 + (nco > 2 ? 2 * (int64_t)cin * 16 : 0), *u3 = u0 + (nco > 3 ? 3 * (int64_t)cin * 16 : 0);
+              for (int k = 0; k < cin; ++k) {
+                  const float *v = V + k * 16;
+#pragma omp simd
+                  for (int f = 0; f < 16; ++f) {
+                      m4[0][f] = fmaf(v[f], u0[k * 16 + f], m4[0][f]); m4[1][f] = fmaf(v[f], u1[k * 16 + f], m4[1][f]);
+                      m4[2][f] = fmaf(v[f], u2[k * 16 + f], m4[2][f]); m4[3][f] = fmaf(v[f], u3[k * 16 + f], m4[3][f]);
+                  }
+              }
+              for (int q = 0; q < nco; ++q) {
+                const int co = co0 + q;
+                const float *m = m4[q];
+                float s[4][2], Y[2][2];
+                for (int i = 0; i < 4; ++i) {
+                    s[i][0] = (m[4 * i] + m[4 * i + 1]) + m[4 * i + 2];
+                    s[i][1] = (m[4 * i + 1] - m[4 * i + 2]) - m[4 * i + 3];
+                }
+                for (int b = 0; b < 2; ++b) { Y[0][b] = (s[0][b] + s[1][b]) + s[2][b]; Y[1][b] = (s[1][b] - s[2][b]) - s[3][b]; }
+                for (int a_ = 0; a_ < 2; ++a_)
+                    for (int b = 0; b < 2; ++b) {
+                        const int oy = 2 * ty + a_, ox = 2 * tx + b;
+                        if (oy >= out.h || ox >= out.w) continue;
+                        const int64_t mrow = ((int64_t)n * out.h + oy) * out.w + ox;
+                        float acc = Y[a_][b] + (bias ? bias[co] : 0.0f);
+                        if (op->res_mode == 1 && res.p) acc += res.p[mrow * res.ld + co];
+                        acc = orc_act(acc, op->act, slope ? slope[co] : 0.0f);
+                        if (op->res_mode == 2 && res.p) acc += res.p[mrow * res.ld + co];
+                        out.p[mrow * out.ld + co] = acc;
+                    }
+              }
+            }
+        }
+        free(V);
+    }
+    free(U); free(cidx);
+}
+
 /* depthwise: weights natural [c][kh][kw] */
 static void orc_dwconv(const csm_op *op, view_t in, view_t out, const float *W, const float *bias, const float *slope)
 {
@@ -533,7 +647,12 @@ int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
         switch (op->kind) {
             case CSM_OP_CONV: {
                 const char *e = getenv("ORC_CONV_REFERENCE");
-                if (e && e[0] == '1') orc_conv(op, in, in1, out, W, B, S); else orc_conv_fast(op, in, in1, out, W, B, S);
+                if (op->flags & CSM_CONV_FLAG_WINOGRAD) {
+                    if (op->kh != 3 || op->kw != 3 || op->stride != 1 || op->dil != 1 || op->pad != 1 || op->groups != 1 || op->ksplit > 1) {
+                        fprintf(stderr, "orc_run_program: op %d: Winograd flag on an ineligible convolution\n", i); return 1;
+                    }
+                    orc_conv_wino(op, in, in1, out, W, B, S);
+                } else if (e && e[0] == '1') orc_conv(op, in, in1, out, W, B, S); else orc_conv_fast(op, in, in1, out, W, B, S);
                 break;
             }
             case CSM_OP_DWCONV: orc_dwconv(op, in, out, W, B, S); break;
@@ -570,6 +689,16 @@ int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
         }
     }
     return 0;
+}
+
+/* test hook: the oracle's own U = G g G^T for natural-order channels, [cout][cin][16] (tests/test_oracle_winograd.py compares the
+ * product's host packing with it bit for bit) */
+void orc_wino_transform_weights(const float *W, int cout, int cin, float *U)
+{
+    int *cidx = (int *)malloc(sizeof(int) * (size_t)cin);
+    for (int c = 0; c < cin; ++c) cidx[c] = c;
+    orc_wino_weights(W, cout, cin, cidx, U);
+    free(cidx);
 }
 
 size_t orc_sizeof_op(void) { return sizeof(csm_op); }

@@ -95,6 +95,13 @@ def spatial_filter_median5(x):
     return out
 
 
+def spatial_filter_median3(x):
+    x = _f(x); B, C, H, W = x.shape
+    out = np.empty_like(x)
+    lib().orc_spatial_filter_median3(ctypes.c_int(B * C), ctypes.c_int(H), ctypes.c_int(W), _p(x), _p(out))
+    return out
+
+
 def depth_to_points(depth, focal):
     depth = _f(depth); B, _, H, W = depth.shape
     pts = np.empty((B, 3, H, W), _F)

@@ -284,6 +284,25 @@ void orc_spatial_filter_median5(int B, int H, int W, const float *in, float *out
             }
 }
 
+/* spatial_filter(x,'median-3')  (models/utils.py:26-30): reflect pad 1, lower median (5th) of the 9 window values */
+void orc_spatial_filter_median3(int B, int H, int W, const float *in, float *out)
+{
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float v[9]; int k = 0;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        int yy = y + dy, xx = x + dx;
+                        yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+                        xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+                        v[k++] = in[((int64_t)b * H + yy) * W + xx];
+                    }
+                qsort(v, 9, sizeof(float), cmp_f);
+                out[((int64_t)b * H + y) * W + x] = v[4];
+            }
+}
+
 /* depth_to_points  (models/utils.py:43-50).  linspace(-W/2+.5, W/2-.5, W) has
  * step exactly 1.0f, so h[i] = -0.5*W + 0.5 + i exactly. */
 void orc_depth_to_points(int B, int H, int W, double focal, const float *depth, float *pts)

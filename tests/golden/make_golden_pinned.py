@@ -274,9 +274,23 @@ def autozoom_case(name, H, W, seed):
     print(name, 'candidates', len(counts), 'objTo', objTo)
 
 
+def median_case(name, seed):
+    """a12: spatial_filter(x, 'median-3' / 'median-5') (models/utils.py:26-36) executed: a smooth map, a binary mask (heavy ties), B = 2"""
+    mu, _, _ = ref_loader.load_warp_modules()
+    g = np.random.default_rng(seed)
+    x = g.normal(0, 1, (2, 2, 23, 31)).astype(np.float32)
+    x[1] = (g.uniform(0, 1, (2, 23, 31)) > 0.45).astype(np.float32)
+    t = torch.from_numpy(x)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), x=x, median3=mu.spatial_filter(t, 'median-3').numpy(),
+                        median5=mu.spatial_filter(t, 'median-5').numpy())
+    print(name, x.shape)
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['maskhead', 'boxprompt', 'refine', 'instances', 'depth', 'autozoom']
+    which = sys.argv[1:] or ['maskhead', 'boxprompt', 'refine', 'instances', 'depth', 'autozoom', 'median']
+    if 'median' in which:
+        median_case('pin_spatial_filter_median', 50)
     if 'maskhead' in which:
         maskhead_case('pin_maskhead_20x20', 20, 20, 5, 41)
         maskhead_case('pin_maskhead_12x28', 12, 28, 3, 42)

@@ -114,6 +114,14 @@ def test_pointwise(ops):
     assert np.array_equal(ops.spatial_filter(dev(m), 'median-5').cpu().numpy(), orc.spatial_filter_median5(m))
     f = np.random.default_rng(4).normal(0, 1, (1, 2, 19, 23)).astype(np.float32)
     assert np.array_equal(ops.spatial_filter(dev(f), 'median-5').cpu().numpy(), orc.spatial_filter_median5(f))
+    # 'median-3' / 'median-5' against the reference function's own output (models/utils.py:26-36), and the oracle on a 2 x 2 map
+    pm = np.load(os.path.join(GOLDEN, "pin_spatial_filter_median.npz"))
+    assert np.array_equal(ops.spatial_filter(dev(pm['x']), 'median-3').cpu().numpy(), pm['median3'])
+    assert np.array_equal(ops.spatial_filter(dev(pm['x']), 'median-5').cpu().numpy(), pm['median5'])
+    tiny = np.array([[[[1.0, 5.0], [3.0, 2.0]]]], np.float32)
+    assert np.array_equal(ops.spatial_filter(dev(tiny), 'median-3').cpu().numpy(), orc.spatial_filter_median3(tiny))
+    with pytest.raises(ValueError):
+        ops.spatial_filter(dev(tiny), 'median-7')
 
 
 def _frame_case(ops, H, W, seed, extra=0):

@@ -1,0 +1,159 @@
+"""BASELINE configs[2] literally, CHECKED (round 5): the reference loads ZoeDepth with img_size=[672, 672]
+(anime_3dkenburns/kenburns_effect.py:543) and calls infer(with_flip_aug=True, pad_input=True) (:812-817); on a 1024 x 1024 frame that is
+the MiDaS DPT-BEiT-L core on the TTA pair (n = 2) at 672 x 672 = 42 x 42 + 1 = 1765 tokens.  bench.py times exactly that; here it is
+compared with the oracle:
+  (i)   the BEiT-L core at 672 x 672, n = 2, all seven outputs, HIP vs oracle/nets.run_program <= 1e-3 (north_star's fp32 depth tolerance);
+  (ii)  KenBurnsPipeline(depth_est='zoe') on its BUILT-IN core on a 1024 x 1024 frame: the coarse disparity of _depth_est_zoe and the
+        tenRawDisparity of generate_kenburns_config vs the CPU chain (reflect pad + PrepForMidas in torch, core + metric-bins head on the
+        oracle interpreter, bicubic resize back, crop, flip average, depth -> disparity, oracle depth adjustment) <= 1e-3;
+  (iii) ONE full-width attention layer (16 heads x 64, BEiT-L's) at 1765 and at 769 tokens vs a float64 numpy softmax: the launch forms
+        (query-tile shape, bias-window capacity, key-range split) the kernel derives from the token count / grid width.
+The oracle run of the core (~4.5 TFLOP on the host cores) happens ONCE per session and feeds (i) and (ii)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+FRAME, NET = 1024, 672
+
+
+def _core_out_shapes(n, H, W, cfg):
+    gh, gw, F = H // 16, W // 16, cfg.features
+    return [(n, 1, H, W), (n, cfg.head_features_2, H, W), (n, F, gh // 2, gw // 2)] + [(n, F, gh << k, gw << k) for k in range(4)]
+
+
+@pytest.fixture(scope="module")
+def zoe_oracle():
+    """frame -> prepared TTA pair (torch CPU restatement of DepthModel.infer's padding and PrepForMidas) -> oracle core outputs"""
+    import torch.nn.functional as F
+    from cartoonsegmentation_amd import synth
+    from cartoonsegmentation_amd.nets import DPTBeitConfig, build_dpt_beit
+    from cartoonsegmentation_amd.weights import SynthWeights
+    from cartoonsegmentation_amd.zoedepth import midas_size
+    from oracle import nets as onets
+    img = synth.image_u8(FRAME, FRAME, 501)
+    x = torch.from_numpy(img).permute(2, 0, 1)[None].float() * (1.0 / 255.0)
+    ph = pw = int(np.sqrt(FRAME / 2) * 3)
+    preps = []
+    for flip in (0, 1):
+        xi = torch.flip(x, dims=[3]) if flip else x
+        xpd = F.pad(xi, [pw, pw, ph, ph], mode='reflect')
+        nw, nh = midas_size(xpd.shape[3], xpd.shape[2], NET, NET)
+        preps.append((F.interpolate(xpd, (nh, nw), mode='bilinear', align_corners=True) - 0.5) / 0.5)
+    xp = torch.cat(preps, 0).numpy().astype(np.float32)
+    assert xp.shape == (2, 3, NET, NET)
+    cfg = DPTBeitConfig()
+    prog = build_dpt_beit(SynthWeights('zoe.core.core.'), 2, NET, NET, cfg)
+    ref = [np.zeros(s, np.float32) for s in _core_out_shapes(2, NET, NET, cfg)]
+    onets.run_program(prog, [np.ascontiguousarray(xp)] + ref)
+    return dict(img=img, xp=xp, cfg=cfg, prog=prog, ref=ref, pad=(ph, pw))
+
+
+def test_dpt_beit_large_672_tta_pair_hip_vs_oracle(zoe_oracle):
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    z = zoe_oracle
+    assert z['prog'].views[[o for o in z['prog'].ops if o['kind'] == 16][0]['in0']].h == 42 * 42 + 1       # 1765 tokens
+    cp = CompiledProgram(z['prog'], 'cuda')
+    dev = [torch.full(s, float('nan'), device='cuda') for s in _core_out_shapes(2, NET, NET, z['cfg'])]
+    cp.run(torch.from_numpy(z['xp']).cuda(), *dev)
+    torch.cuda.synchronize()
+    for name, r, d in zip(('rel', 'out_conv', 'l4_rn', 'r4', 'r3', 'r2', 'r1'), z['ref'], dev):
+        d = d.cpu().numpy()
+        assert np.isfinite(d).all(), name
+        err = np.abs(d - r).max() / np.abs(r).max()
+        assert err < 1e-3, (name, err)
+    # the mirrored sample is a different input, not a copy of the plain one
+    assert np.abs(z['ref'][0][0] - z['ref'][0][1][..., ::-1]).max() > 0
+
+
+def test_pipeline_zoe_builtin_core_1024_disparity_vs_oracle_chain(zoe_oracle):
+    import torch.nn.functional as F
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd.nets import build_zoe_head
+    from cartoonsegmentation_amd.weights import SynthWeights
+    from cartoonsegmentation_amd.zoedepth import DPTBeitCore
+    from oracle import kenburns as okb, nets as onets
+    z = zoe_oracle
+    ph, pw = z['pad']
+    # ---- CPU chain behind the oracle core: head, bicubic resize back, crop, un-flip, average, depth -> disparity ----
+    ref = z['ref']
+    sizes = [tuple(r.shape[2:]) for r in ref[2:]]
+    head_out = np.zeros((2, 1, NET, NET), np.float32)
+    onets.run_program(build_zoe_head(SynthWeights('zoe.'), 2, NET, NET, sizes), ref + [head_out])
+    outs = []
+    for flip in (0, 1):
+        d = F.interpolate(torch.from_numpy(head_out[flip:flip + 1]), size=(FRAME + 2 * ph, FRAME + 2 * pw), mode='bicubic',
+                          align_corners=False)[:, :, ph:-ph, pw:-pw]
+        outs.append(torch.flip(d, dims=[3]) if flip else d)
+    depth = ((outs[0] + outs[1]) / 2).numpy()
+    assert (depth > 0).all()
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='zoe', max_size=FRAME, refine_crf=False, focal=FRAME / 2.0, num_frame=2,
+                         mask_refine_kwargs={'refine_method': 'none'})
+    fb = np.float32(cfg.focal * cfg.baseline)
+    disp_ref = (fb / (depth + np.float32(1e-5))).astype(np.float32)
+    # ---- the product: the pipeline on its built-in core ----
+    pipe = KenBurnsPipeline(cfg)
+    assert isinstance(pipe.depth_zoe.core, DPTBeitCore) and (pipe.depth_zoe.net_h, pipe.depth_zoe.net_w) == (NET, NET)
+    pipe.max_instances = 2
+    pipe.animeinsseg.set_detect_size(640)
+    frame_dev = pipe.animeinsseg._upload(z['img'])
+    coarse = pipe._depth_est(None, frame_dev).cpu().numpy()
+    assert coarse.shape == (1, 1, FRAME, FRAME) and np.isfinite(coarse).all()
+    assert (2, NET, NET) in pipe.depth_zoe.core._progs                               # the TTA pair went through ONE core run at 672 x 672
+    err = np.abs(coarse - disp_ref).max() / np.abs(disp_ref).max()
+    assert err < 1e-3, err
+    kc = pipe.generate_kenburns_config(z['img'])
+    raw = kc['tenRawDisparity'].cpu().numpy()
+    inst, _ = pipe.run_instance_segmentation(z['img'], scale_down_to_maxsize=False)
+    masks = [] if inst.is_empty else list(inst.masks.cpu().numpy())
+    adj = okb.depth_adjustment(masks, disp_ref)
+    adj = (adj / adj.max() * np.float32(kc['fltBaseline'])).astype(np.float32)
+    assert raw.shape == adj.shape and np.isfinite(raw).all()
+    err = np.abs(raw - adj).max() / np.abs(adj).max()
+    assert err < 1e-3, err
+
+
+@pytest.mark.parametrize("gh,gw,n", [(42, 42, 2), (24, 32, 1)])
+def test_full_width_attention_layer_vs_float64_softmax(gh, gw, n):
+    """CSM_OP_ATTENTION by itself at BEiT-L's width: 16 heads x 64, N = gh * gw + 1 tokens, relative-position bias gathered from the
+    (2 gh - 1)(2 gw - 1) + 3 table (timm beit.py gen_relative_position_index: class-token row / column / corner in the last three rows)"""
+    from cartoonsegmentation_amd.program import Program
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    heads, d = 16, 64
+    N, C, Tn = gh * gw + 1, heads * d, (2 * gh - 1) * (2 * gw - 1) + 3
+    rng = np.random.default_rng(gh * 100 + gw)
+    qkv = rng.normal(0, 1, (n, 3 * C, N, 1)).astype(np.float32)
+    qkv[:, :C] *= 0.125 * 1.5                                       # q arrives pre-scaled; logits of a few units, as in the trained net
+    table = rng.normal(0, 1.0, (Tn, heads)).astype(np.float32)
+    p = Program("attn")
+    x_ext = p.ext_nchw(n, 3 * C, N, 1)
+    y_ext = p.ext_nchw(n, C, N, 1)
+    y = p.attention(p.to_nhwc(x_ext), heads, grid=(gh, gw), rel_table=table)
+    p.to_nchw(y, y_ext)
+    os.environ.setdefault("CSM_AUTOTUNE", "1")
+    cp = CompiledProgram(p, 'cuda')
+    out = torch.full((n, C, N, 1), float('nan'), device='cuda')
+    cp.run(torch.from_numpy(qkv).cuda(), out)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()[..., 0]                                  # [n, C, N]
+    # float64 reference: index arithmetic restated here (dy, dx of the patch tokens; the three class-token entries)
+    ys, xs = np.divmod(np.arange(gh * gw), gw)
+    idx = np.zeros((N, N), np.int64)
+    idx[1:, 1:] = (ys[:, None] - ys[None, :] + gh - 1) * (2 * gw - 1) + (xs[:, None] - xs[None, :] + gw - 1)
+    idx[0, :] = Tn - 3; idx[:, 0] = Tn - 2; idx[0, 0] = Tn - 1
+    q64 = qkv[..., 0].astype(np.float64)
+    worst = 0.0
+    for b in range(n):
+        for h in range(0, heads, 5):                                 # heads 0, 5, 10, 15 (the host softmax is 50 MFLOP per head)
+            q, k, v = (q64[b, o * C + h * d:o * C + (h + 1) * d] for o in range(3))      # [d, N]
+            s = q.T @ k + table[:, h].astype(np.float64)[idx]
+            s -= s.max(axis=1, keepdims=True)
+            pr = np.exp(s); pr /= pr.sum(axis=1, keepdims=True)
+            ref = pr @ v.T                                           # [N, d]
+            got = out[b, h * d:(h + 1) * d].T
+            worst = max(worst, np.abs(got - ref).max() / np.abs(ref).max())
+    assert np.isfinite(out).all() and worst < 1e-5, worst

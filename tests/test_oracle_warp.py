@@ -106,6 +106,14 @@ def test_median5_matches_torch_restatement():
     assert np.array_equal(orc.spatial_filter_median5(x.numpy()), t.numpy())
 
 
+def test_median_filters_match_the_reference_function():
+    """spatial_filter(x, 'median-3' / 'median-5') (models/utils.py:26-36): fixture = the reference's own function executed
+    (tests/golden/make_golden_pinned.py median): a smooth map and a binary mask (ties), two samples"""
+    g = np.load(os.path.join(GOLDEN, "pin_spatial_filter_median.npz"))
+    assert np.array_equal(orc.spatial_filter_median3(g['x']), g['median3'])
+    assert np.array_equal(orc.spatial_filter_median5(g['x']), g['median5'])
+
+
 @pytest.mark.parametrize("path", RENDER_CASES, ids=[os.path.basename(p)[:-4] for p in RENDER_CASES])
 def test_fma_contraction_bracket(path):
     """NVRTC contracts a*b+c into FMA by default; the fixtures exist for both ends of that bracket (g++ -ffp-contract=off and
