@@ -33,6 +33,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise CsmError("libcsm355.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C cartoonsegmentation_amd/csrc`" % LIB_PATH)
+        if os.environ.get("CSM_LIB"):
+            import sys
+            print("libcsm355: CSM_LIB overrides the in-tree library: %s" % LIB_PATH, file=sys.stderr)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.csm_last_error.restype = ctypes.c_char_p
         _lib.csm_build_info.restype = ctypes.c_char_p
@@ -49,7 +52,15 @@ def load():
         _lib.csm_det_decode_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_mean_std_scratch_bytes.restype = ctypes.c_size_t
         if os.environ.get("CSM_TUNER_OPTIONS"):          # measurement aid (A/B of launch forms, include/csm355.h csm_debug_conv_tuner_options); speed only
-            _lib.csm_debug_conv_tuner_options(int(os.environ["CSM_TUNER_OPTIONS"]))
+            # the value is the WHOLE bitmask (default 1 = mixed-tile launches on; bit 1 = N-grouped tile order off): "2" also clears bit 0
+            import sys
+            try:
+                opt = int(os.environ["CSM_TUNER_OPTIONS"], 0)
+            except ValueError:
+                raise CsmError("CSM_TUNER_OPTIONS=%r is not an integer bitmask (default 1; see csm_debug_conv_tuner_options in "
+                               "include/csm355.h)" % os.environ["CSM_TUNER_OPTIONS"])
+            print("libcsm355: CSM_TUNER_OPTIONS=%d replaces the default tuner options (1)" % opt, file=sys.stderr)
+            _lib.csm_debug_conv_tuner_options(opt)
     return _lib
 
 

@@ -26,6 +26,7 @@
 //     full step to land; fragments, raw windows and transform values are all produced one MFMA group ahead of their use.
 #include "csm_conv.h"
 #include <utility>
+#include <cstdlib>
 
 using namespace csmconv;
 
@@ -52,7 +53,10 @@ __device__ __forceinline__ float bt_row(int i, float d0, float d1, float d2, flo
     return i == 0 ? d0 - d2 : (i == 1 ? d1 + d2 : (i == 2 ? d2 - d1 : d1 - d3));
 }
 
-template <int WM, int WN>
+// ABL: development ablations of the main loop (timing only, results invalid): 1 = no DMA, 2 = no barrier / waits, 4 = no LDS reads,
+// 8 = no transform VALU; OPT bits: 1 = counted vmcnt at the barriers (the patch pieces of this step may stay in flight) and the whole
+// U stage issued behind the barrier
+template <int WM, int WN, int ABL = 0, int OPT = 0>
 __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int tiles_x, int tiles_y) {
     constexpr int NW = WM * WN;
     constexpr int OH = 4 * WM, OW = 32;                       // output pixels of a block
@@ -172,7 +176,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
     // ---- prologue ----
     issue_patch(0, 0, QP, true);
     issue_u(0, 0, UPW, true); u_src += kUB;
-    issue_u(1, 0, UPW / 2, nsteps > 1);
+    if constexpr (OPT & 1) { issue_u(1, 0, UPW, nsteps > 1); u_src += kUB; }
+    else issue_u(1, 0, UPW / 2, nsteps > 1);
     issue_patch(1, 0, QG, ncb > 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -192,11 +197,16 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
                 constexpr int g = decltype(G)::value, buf = g & 1;
                 if constexpr (g == 3) {
                     // everybody's pieces of the next U stage (and the older patch pieces) have landed; everybody has finished reading this
-                    // step's U stage and -- at q == 2 -- this channel block's patch
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    read_b((q + 1) & 1, 0, buf ^ 1);
-                } else {
+                    // step's U stage and -- at q == 2 -- this channel block's patch.  OPT 1: the patch pieces sent in group 1 of THIS step
+                    // (q != 2) are the youngest loads in flight and are not needed before the barrier of step (cb + 1, 2): they may stay
+                    // outstanding (loads retire in order)
+                    if constexpr (!(ABL & 2)) {
+                        if constexpr ((OPT & 1) && q != 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((QG + 3) / 4 * 4) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    if constexpr (!(ABL & 4)) read_b((q + 1) & 1, 0, buf ^ 1);
+                } else if constexpr (!(ABL & 4)) {
                     read_b(q & 1, g + 1, buf ^ 1);
                     read_raw(cbn, subn, g == 0 ? 0 : (g == 1 ? 6 : 11), g == 0 ? 6 : (g == 1 ? 11 : 16));
                 }
@@ -207,7 +217,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
                     const float bv = tt == 0 ? bf.x : (tt == 1 ? bf.y : (tt == 2 ? bf.z : bf.w));
                     acc[4 * g + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[buf][j][tt], bv, acc[4 * g + j], 0, 0, 0);
                     // this slot's share of the transform work for the NEXT group
-                    if constexpr (g < 3) {
+                    if constexpr (ABL & 8) {
+                    } else if constexpr (g < 3) {
                         col_op(ic<g + 1>{}, ic<(buf ^ 1)>{}, M);
                     } else {                                        // next step: row pass (64 ops), then group 0's column pass (16)
                         static_for<5>([&](auto E) {
@@ -216,10 +227,15 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
                             else if constexpr (k < 80) col_op(ic<0>{}, ic<0>{}, ic<k - 64>{});
                         });
                     }
-                    // DMA pieces in MFMA slots 1, 5, 9, 13
-                    if constexpr ((m & 3) == 1) {
+                    // DMA pieces in MFMA slots 1, 5, 9, 13 (OPT 1: the whole U stage behind the barrier, slots 1, 3, ..., 15)
+                    if constexpr (ABL & 1) {
+                    } else if constexpr ((OPT & 1) && g == 3 && (m & 1) == 1) {
+                        issue_u(q & 1, (m >> 1) * (UPW / 8), ((m >> 1) + 1) * (UPW / 8), s + 2 < nsteps);
+                        if constexpr (m == 15) u_src += kUB;
+                    } else if constexpr ((m & 3) == 1) {
                         constexpr int k = m >> 2;
-                        if constexpr (g == 3) {
+                        if constexpr ((OPT & 1) && (g == 3 || g == 0)) {
+                        } else if constexpr (g == 3) {
                             issue_u(q & 1, k * (UPW / 8), (k + 1) * (UPW / 8), s + 2 < nsteps);
                         } else if constexpr (g == 0) {
                             issue_u((q + 1) & 1, UPW / 2 + k * (UPW / 8), UPW / 2 + (k + 1) * (UPW / 8), s + 1 < nsteps);
@@ -241,7 +257,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing (dead) fetches must land before the block's LDS is released
 
     // ---- epilogue: output transform A^T M A (columns j first), bias, residual, activation.  Lane (li, lh) holds output channel li of the
-    // wave's 32 and, in accumulator element r, the tile (tx, ty) = ((r & 3) + 8 ((r >> 2) & 1) + 4 lh, r >> 3) of the wave's 16 x 2 ----
+    // wave's 32 and, in accumulator element r, the tile (tx, ty) = ((r & 3) + 8 ((r >> 2) & 1) + 4 lh, r >> 3) of the wave's 16 x 2.
+    // Everything is indexed at compile time (a run-time r would turn the 256 accumulator registers into a waterfall) and the activation
+    // switch sits OUTSIDE the element loops: the 64 outputs of a lane are formed in registers first ----
     const int co = ntile * 64 + 32 * wn + li;
     const float bias = a.bias ? a.bias[co] : 0.0f;
     const float slope = a.slope ? a.slope[co] : 0.0f;
@@ -250,32 +268,48 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
     const int64_t mb = ((int64_t)n * ho + oyb) * wo + oxb;
     float *ob = a.out.p + mb * ldo + co;
     const float *rp = a.res_mode ? a.res.p + mb * ldr + co : nullptr;
+    const bool full = oy0 + OH <= ho && ox0 + OW <= wo;        // block-uniform: interior block tiles take the unguarded path
+    // ACT: compile-time activation (-1 = the run-time switch of apply_act); FULL: no bounds checks
+    auto epilogue = [&](auto ACT, auto FULL, auto RES) {
+        constexpr int act_c = decltype(ACT)::value;
+        constexpr bool has_res = decltype(RES)::value;
+        static_for<16>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            float sj[4][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float sj[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float m0 = acc[4 * i][r], m1 = acc[4 * i + 1][r], m2 = acc[4 * i + 2][r], m3 = acc[4 * i + 3][r];
-            sj[i][0] = (m0 + m1) + m2;
-            sj[i][1] = (m1 - m2) - m3;
-        }
-        const int dyt = 2 * (r >> 3), dxt = 2 * ((r & 3) + 8 * ((r >> 2) & 1));
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const float y0 = (sj[0][b] + sj[1][b]) + sj[2][b], y1 = (sj[1][b] - sj[2][b]) - sj[3][b];
-#pragma unroll
-            for (int aa = 0; aa < 2; ++aa) {
-                const int dy = dyt + aa, dx = dxt + b;
-                if (oyb + dy >= ho || oxb + dx >= wo) continue;
-                const int64_t eo = (int64_t)dy * wo + dx;
-                float v = (aa == 0 ? y0 : y1) + bias;
-                if (a.res_mode == 1) v += rp[eo * ldr];
-                v = apply_act(v, a.act, slope);
-                if (a.res_mode == 2) v += rp[eo * ldr];
-                ob[eo * ldo] = v;
+            for (int i = 0; i < 4; ++i) {
+                const float m0 = acc[4 * i][r], m1 = acc[4 * i + 1][r], m2 = acc[4 * i + 2][r], m3 = acc[4 * i + 3][r];
+                sj[i][0] = (m0 + m1) + m2;
+                sj[i][1] = (m1 - m2) - m3;
             }
+            static_for<4>([&](auto P) {
+                constexpr int aa = decltype(P)::value >> 1, b = decltype(P)::value & 1;
+                constexpr int dy = 2 * (r >> 3) + aa, dx = 2 * ((r & 3) + 8 * ((r >> 2) & 1)) + b;
+                float v = (aa == 0 ? (sj[0][b] + sj[1][b]) + sj[2][b] : (sj[1][b] - sj[2][b]) - sj[3][b]) + bias;
+                auto finish = [&]() {
+                    const int64_t eo = (int64_t)dy * wo + dx;
+                    if constexpr (has_res) { if (a.res_mode == 1) v += rp[eo * ldr]; }
+                    v = apply_act(v, act_c >= 0 ? act_c : a.act, slope);
+                    if constexpr (has_res) { if (a.res_mode == 2) v += rp[eo * ldr]; }
+                    ob[eo * ldo] = v;
+                };
+                if constexpr (decltype(FULL)::value) finish();
+                else if (oyb + dy < ho && oxb + dx < wo) finish();
+            });
+        });
+    };
+    auto epilogue_act = [&](auto FULL, auto RES) {
+        switch (a.act) {                                       // uniform: the common activations get a body without the per-element switch
+            case CSM_ACT_NONE: epilogue(ic<CSM_ACT_NONE>{}, FULL, RES); break;
+            case CSM_ACT_RELU: epilogue(ic<CSM_ACT_RELU>{}, FULL, RES); break;
+            case CSM_ACT_SILU: epilogue(ic<CSM_ACT_SILU>{}, FULL, RES); break;
+            case CSM_ACT_PRELU: epilogue(ic<CSM_ACT_PRELU>{}, FULL, RES); break;
+            default: epilogue(ic<-1>{}, FULL, RES); break;
         }
-    }
+    };
+    if (a.res_mode) { if (full) epilogue_act(std::true_type{}, std::true_type{}); else epilogue_act(std::false_type{}, std::true_type{}); }
+    else if (full) epilogue_act(std::true_type{}, std::false_type{});
+    else epilogue_act(std::false_type{}, std::false_type{});
 }
 
 }  // namespace
@@ -296,9 +330,30 @@ int launch_conv_wino(const ConvArgs &a0, hipStream_t st) {
     ConvArgs a = a0;
     const int tiles_x = (a.out.w + OW - 1) / OW, tiles_y = (a.out.h + OH - 1) / OH;
     a.m_tiles = tiles_x * tiles_y * a.out.n;
+    dim3 grid(a.m_tiles, a.cout_g / 64, 1);
+#ifdef CSM_WINO_DEV        // development build: CSM_WINO_VARIANT selects an ablation / option instantiation (tools/gpu/r05b.sh)
+    const char *ve = getenv("CSM_WINO_VARIANT");
+    const int variant = ve ? atoi(ve) : 0;
+    auto go = [&](auto kern) {
+        static KernelPrep prep;
+        (void)prep.ensure([&] { return prepare_kernel(kern, 64 * WM * WN, lds); });
+        kern<<<grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y);
+        return csm::check_launch("k_conv_wino");
+    };
+    switch (variant) {
+        case 1: return go(&k_conv_wino<WM, WN, 1, 0>);
+        case 2: return go(&k_conv_wino<WM, WN, 2, 0>);
+        case 3: return go(&k_conv_wino<WM, WN, 3, 0>);
+        case 4: return go(&k_conv_wino<WM, WN, 4, 0>);
+        case 8: return go(&k_conv_wino<WM, WN, 8, 0>);
+        case 12: return go(&k_conv_wino<WM, WN, 12, 0>);
+        case 15: return go(&k_conv_wino<WM, WN, 15, 0>);
+        case 100: return go(&k_conv_wino<WM, WN, 0, 1>);
+        default: break;
+    }
+#endif
     static KernelPrep prep;
     (void)prep.ensure([&] { return prepare_kernel(&k_conv_wino<WM, WN>, 64 * WM * WN, lds); });
-    dim3 grid(a.m_tiles, a.cout_g / 64, 1);
     k_conv_wino<WM, WN><<<grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y);
     return csm::check_launch("k_conv_wino");
 }

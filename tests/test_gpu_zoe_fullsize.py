@@ -3,9 +3,10 @@
 the MiDaS DPT-BEiT-L core on the TTA pair (n = 2) at 672 x 672 = 42 x 42 + 1 = 1765 tokens.  bench.py times exactly that; here it is
 compared with the oracle:
   (i)   the BEiT-L core at 672 x 672, n = 2, all seven outputs, HIP vs oracle/nets.run_program <= 1e-3 (north_star's fp32 depth tolerance);
-  (ii)  KenBurnsPipeline(depth_est='zoe') on its BUILT-IN core on a 1024 x 1024 frame: the coarse disparity of _depth_est_zoe and the
-        tenRawDisparity of generate_kenburns_config vs the CPU chain (reflect pad + PrepForMidas in torch, core + metric-bins head on the
-        oracle interpreter, bicubic resize back, crop, flip average, depth -> disparity, oracle depth adjustment) <= 1e-3;
+  (ii)  KenBurnsPipeline(depth_est='zoe') on its BUILT-IN core on a 1024 x 1024 frame: the metric depth of DepthModel.infer vs the CPU chain
+        (reflect pad + PrepForMidas in torch, core + metric-bins head on the oracle interpreter, bicubic resize back, crop, flip average)
+        <= 1e-3; the coarse disparity of _depth_est_zoe == the reference's tail applied to that depth; tenRawDisparity of
+        generate_kenburns_config == the oracle's depth adjustment + normalisation of that coarse disparity;
   (iii) ONE full-width attention layer (16 heads x 64, BEiT-L's) at 1765 and at 769 tokens vs a float64 numpy softmax: the launch forms
         (query-tile shape, bias-window capacity, key-range split) the kernel derives from the token count / grid width.
 The oracle run of the core (~4.5 TFLOP on the host cores) happens ONCE per session and feeds (i) and (ii)."""
@@ -73,6 +74,7 @@ def test_pipeline_zoe_builtin_core_1024_disparity_vs_oracle_chain(zoe_oracle):
     import torch.nn.functional as F
     os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
     from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd import ops
     from cartoonsegmentation_amd.nets import build_zoe_head
     from cartoonsegmentation_amd.weights import SynthWeights
     from cartoonsegmentation_amd.zoedepth import DPTBeitCore
@@ -89,32 +91,45 @@ def test_pipeline_zoe_builtin_core_1024_disparity_vs_oracle_chain(zoe_oracle):
         d = F.interpolate(torch.from_numpy(head_out[flip:flip + 1]), size=(FRAME + 2 * ph, FRAME + 2 * pw), mode='bicubic',
                           align_corners=False)[:, :, ph:-ph, pw:-pw]
         outs.append(torch.flip(d, dims=[3]) if flip else d)
-    depth = ((outs[0] + outs[1]) / 2).numpy()
-    assert (depth > 0).all()
+    depth_ref = ((outs[0] + outs[1]) / 2).numpy()
     cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='zoe', max_size=FRAME, refine_crf=False, focal=FRAME / 2.0, num_frame=2,
                          mask_refine_kwargs={'refine_method': 'none'})
-    fb = np.float32(cfg.focal * cfg.baseline)
-    disp_ref = (fb / (depth + np.float32(1e-5))).astype(np.float32)
     # ---- the product: the pipeline on its built-in core ----
     pipe = KenBurnsPipeline(cfg)
     assert isinstance(pipe.depth_zoe.core, DPTBeitCore) and (pipe.depth_zoe.net_h, pipe.depth_zoe.net_w) == (NET, NET)
     pipe.max_instances = 2
     pipe.animeinsseg.set_detect_size(640)
     frame_dev = pipe.animeinsseg._upload(z['img'])
-    coarse = pipe._depth_est(None, frame_dev).cpu().numpy()
-    assert coarse.shape == (1, 1, FRAME, FRAME) and np.isfinite(coarse).all()
+    # (1) metric depth of DepthModel.infer on the built-in core vs the CPU chain: north_star's fp32 depth tolerance.  (With closed-form
+    # weights the head's output spans 1e-6 .. 11 and the bicubic overshoot makes 1 % of the pixels slightly negative -- that is why the
+    # comparison is on the DEPTH: disparity = f b / (depth + 1e-5) has no bounded relative error where the depth crosses zero.)
+    depth = pipe.depth_zoe.infer(ops.image_tensor(frame_dev), with_flip_aug=True, pad_input=True).cpu().numpy()
     assert (2, NET, NET) in pipe.depth_zoe.core._progs                               # the TTA pair went through ONE core run at 672 x 672
-    err = np.abs(coarse - disp_ref).max() / np.abs(disp_ref).max()
+    assert depth.shape == (1, 1, FRAME, FRAME) and np.isfinite(depth).all()
+    err = np.abs(depth - depth_ref).max() / np.abs(depth_ref).max()
     assert err < 1e-3, err
+    # (2) _depth_est_zoe = that depth through the reference's tail (kenburns_effect.py:815-817): zeros -> smallest positive value,
+    # f b / (depth + 1e-5), nan / inf -> 0
+    coarse = pipe._depth_est(None, frame_dev).cpu().numpy()
+    d = depth.copy()
+    d[d == 0] = d[d > 0].min()
+    want = np.float32(cfg.focal * cfg.baseline) / (d + np.float32(1e-5))
+    want[~np.isfinite(want)] = 0.0
+    assert coarse.shape == (1, 1, FRAME, FRAME) and np.isfinite(coarse).all()
+    assert np.abs(coarse - want).max() <= 1e-5 * np.abs(want).max()
+    good = depth_ref > 0.25 * depth_ref.max()                                        # where the relative error of a reciprocal is bounded
+    ref_disp = np.float32(cfg.focal * cfg.baseline) / (depth_ref + np.float32(1e-5))
+    assert good.mean() > 0.2 and (np.abs(coarse - ref_disp)[good] <= 4e-3 * np.abs(ref_disp)[good]).all()
+    # (3) generate_kenburns_config on top of it: instance-wise depth adjustment + normalisation, oracle statement applied to the SAME
+    # coarse disparity (the adjustment itself is pinned by pin_depth_adjust.npz)
     kc = pipe.generate_kenburns_config(z['img'])
     raw = kc['tenRawDisparity'].cpu().numpy()
     inst, _ = pipe.run_instance_segmentation(z['img'], scale_down_to_maxsize=False)
     masks = [] if inst.is_empty else list(inst.masks.cpu().numpy())
-    adj = okb.depth_adjustment(masks, disp_ref)
+    adj = okb.depth_adjustment(masks, coarse)
     adj = (adj / adj.max() * np.float32(kc['fltBaseline'])).astype(np.float32)
     assert raw.shape == adj.shape and np.isfinite(raw).all()
-    err = np.abs(raw - adj).max() / np.abs(adj).max()
-    assert err < 1e-3, err
+    assert np.abs(raw - adj).max() <= 1e-5 * np.abs(adj).max()
 
 
 @pytest.mark.parametrize("gh,gw,n", [(42, 42, 2), (24, 32, 1)])

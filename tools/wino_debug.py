@@ -105,3 +105,26 @@ if __name__ == '__main__':
                     (16, 180, 180, 64, 128), (16, 180, 180, 256, 64), (8, 80, 80, 256, 256), (16, 90, 90, 128, 256), (16, 90, 90, 512, 128),
                     (8, 80, 80, 128, 128), (8, 40, 40, 256, 256), (16, 45, 45, 256, 512), (1, 160, 160, 256, 256), (2, 360, 360, 64, 64), (1, 80, 80, 256, 256)]:
             time_layer(*shp)
+
+
+def variants(shapes, vs):
+    """timing of the development instantiations of k_conv_wino (libcsm355_dev.so, -DCSM_WINO_DEV; CSM_WINO_VARIANT: ablation bits 1 no DMA,
+    2 no barrier, 4 no LDS reads, 8 no transform VALU; 100 + option bits)"""
+    for shp in shapes:
+        n, h, w, cin, cout = shp
+        p = build(True, n, h, w, cin, cout)
+        os.environ["CSM_AUTOTUNE"] = "0"
+        cp = CompiledProgram(p, 'cuda')
+        x = torch.randn(n, cin, h, w, device='cuda'); y = torch.empty(n, cout, h, w, device='cuda')
+        ci = [i for i, o in enumerate(p.ops) if o['kind'] == 1][0]
+        fl = 2.0 * n * h * w * cin * cout * 9
+        for v in vs:
+            os.environ["CSM_WINO_VARIANT"] = str(v)
+            cp.run(x, y); cp.run(x, y)
+            ms = min(cp.profile(x, y)[ci] for _ in range(5))
+            print("%2dx%3dx%3d %4d->%4d  variant %3d  %8.1f us  executed %6.1f TF/s (%.3f of the fp32 MFMA peak)" % (n, h, w, cin, cout, v, ms * 1e3, fl / 2.25 / ms / 1e9, fl / 2.25 / ms / 1e9 / 157.3), flush=True)
+        os.environ["CSM_WINO_VARIANT"] = "0"
+
+
+if __name__ == '__main__' and 'variants' in sys.argv[1:]:
+    variants([(8, 160, 160, 256, 256), (16, 360, 360, 64, 64)], [0, 1, 2, 3, 4, 8, 12, 15, 100])
