@@ -108,7 +108,7 @@ def pack_stem_weights(w):
 # the direct chain (the round-1..4 arithmetic).
 CONV_FLAG_STEM, CONV_FLAG_WINOGRAD = 2, 4
 WINO_ENABLE = os.environ.get('CSM_CONV_EXACT_DIRECT', '0') != '1'
-WINO_MIN_PIXELS = int(os.environ.get('CSM_WINO_MIN_PIXELS', '25600'))
+WINO_MIN_PIXELS = int(os.environ.get('CSM_WINO_MIN_PIXELS', '6400'))
 WINO_BN = 64
 
 
@@ -178,7 +178,8 @@ class Program:
         self.w_hip, self.w_nat = [], []
         self.n_hip = self.n_nat = 0
         self.n_ext = 0
-        self.flops = 0
+        self.flops = 0                # natural (direct-convolution) FLOPs of the net: 2 MAC
+        self.flops_exec = 0           # FLOPs the matrix pipe executes: Winograd layers count 16 / 36 of their natural work
         self.conv_bytes = 0
 
     # ---- tensors --------------------------------------------------------------------------
@@ -261,6 +262,7 @@ class Program:
         if slope is not None:
             a_h, a_n = self._w(slope, slope)
         self.flops += 2 * x.n * ho * wo * cout * cin_g * kh * kw
+        self.flops_exec += (2 * x.n * ((ho + 1) // 2) * ((wo + 1) // 2) * 16 * cout * cin_g) if wino else (2 * x.n * ho * wo * cout * cin_g * kh * kw)
         self.conv_bytes += 4 * (x.n * x.h * x.w * x.c + x.n * ho * wo * cout + w.size)
         ksplit, scr = (1 if stem or wino else self.choose_ksplit(ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups)), None
         if ksplit > 1:
@@ -299,6 +301,7 @@ class Program:
         if b is not None:
             b_h, b_n = self._w(b, b)
         self.flops += 2 * x.n * ho * wo * c * kh * kw
+        self.flops_exec += 2 * x.n * ho * wo * c * kh * kw
         return self._emit(OP_DWCONV, x, None, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, act=ACT[act], w_off=w_h,
                           b_off=b_h, nat=dict(w_off=w_n, b_off=b_n))
 
@@ -401,6 +404,7 @@ class Program:
             assert rel_table.shape == ((2 * gh - 1) * (2 * gw - 1) + 3, heads) and qkv.h == gh * gw + 1, (rel_table.shape, grid, qkv.h)
             a_h, a_n = self._w(np.ascontiguousarray(rel_table.T), rel_table)     # device: [heads][T] (a block reads one head's row)
         self.flops += 4 * qkv.n * heads * qkv.h * qkv.h * d
+        self.flops_exec += 4 * qkv.n * heads * qkv.h * qkv.h * d
         return self._emit(OP_ATTENTION, qkv, None, out, groups=heads, cin_g=d, kh=gh, kw=gw, aux_off=a_h, nat=dict(aux_off=a_n))
 
     def tokens_assemble(self, patches, cls):

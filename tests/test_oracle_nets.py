@@ -15,12 +15,35 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+class _arith:
+    """lower with the shipped per-sample rule ('rule': at fixture sizes every layer stays on the direct chain), or with the Winograd
+    arithmetic forced on EVERY eligible 3x3 layer ('winograd') -- the reference-module fixtures must hold under both"""
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from cartoonsegmentation_amd import program as P
+        self.P, self.old = P, (P.Program.winograd, P.WINO_MIN_PIXELS)
+        if self.mode == 'winograd':
+            P.Program.winograd, P.WINO_MIN_PIXELS = True, 0
+
+    def __exit__(self, *a):
+        self.P.Program.winograd, self.P.WINO_MIN_PIXELS = self.old
+
+
+def _n_wino(prog):
+    return sum(1 for o in prog.ops if o['kind'] == 1 and o['flags'] & 4)
+
+
+@pytest.mark.parametrize("arith", ["rule", "winograd"])
 @pytest.mark.parametrize("tag", ["64x64", "90x74"])
-def test_isnet_vs_reference_module(tag):
+def test_isnet_vs_reference_module(tag, arith):
     from cartoonsegmentation_amd.nets import build_isnet
     g = dict(np.load(os.path.join(GOLDEN, "net_isnet_%s.npz" % tag)))
     n, c, h, w = g['x'].shape
-    prog = build_isnet(SynthWeights('isnet.'), n, h, w)
+    with _arith(arith):
+        prog = build_isnet(SynthWeights('isnet.'), n, h, w)
+    assert (_n_wino(prog) >= 40) == (arith == 'winograd')
     y = np.zeros((n, 1, h, w), np.float32)
     onets.run_program(prog, [np.ascontiguousarray(g['x']), y])
     # BN folding + summation order differ from torch's kernels: fp32 roundoff level
@@ -29,12 +52,15 @@ def test_isnet_vs_reference_module(tag):
     assert ((y > thr) != (g['d1'] > thr)).mean() < 1e-3
 
 
+@pytest.mark.parametrize("arith", ["rule", "winograd"])
 @pytest.mark.parametrize("tag", ["64x64", "96x64"])
-def test_leres_vs_reference_module(tag):
+def test_leres_vs_reference_module(tag, arith):
     from cartoonsegmentation_amd.nets import build_leres
     g = dict(np.load(os.path.join(GOLDEN, "net_leres_%s.npz" % tag)))
     n, c, h, w = g['x'].shape
-    prog = build_leres(SynthWeights('leres.'), n, h, w)
+    with _arith(arith):
+        prog = build_leres(SynthWeights('leres.'), n, h, w)
+    assert (_n_wino(prog) >= 15) == (arith == 'winograd')
     y = np.zeros((n, 1, h, w), np.float32)
     onets.run_program(prog, [np.ascontiguousarray(g['x']), y])
     assert rel_err(y, g['y']) < 1e-4, rel_err(y, g['y'])
