@@ -273,6 +273,16 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
     auto epilogue = [&](auto ACT, auto FULL, auto RES) {
         constexpr int act_c = decltype(ACT)::value;
         constexpr bool has_res = decltype(RES)::value;
+        // residual: all 64 loads of a lane go out back to back BEFORE the first use (one wait instead of 64 load round trips in series)
+        float resv[has_res ? 64 : 1];
+        if constexpr (has_res)
+            static_for<64>([&](auto E) {
+                constexpr int e = decltype(E)::value, r = e >> 2, aa = (e >> 1) & 1, b = e & 1;
+                constexpr int dy = 2 * (r >> 3) + aa, dx = 2 * ((r & 3) + 8 * ((r >> 2) & 1)) + b;
+                const int64_t eo = (int64_t)dy * wo + dx;
+                if constexpr (decltype(FULL)::value) resv[e] = rp[eo * ldr];
+                else resv[e] = (oyb + dy < ho && oxb + dx < wo) ? rp[eo * ldr] : 0.0f;
+            });
         static_for<16>([&](auto RR) {
             constexpr int r = decltype(RR)::value;
             float sj[4][2];
@@ -288,9 +298,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
                 float v = (aa == 0 ? (sj[0][b] + sj[1][b]) + sj[2][b] : (sj[1][b] - sj[2][b]) - sj[3][b]) + bias;
                 auto finish = [&]() {
                     const int64_t eo = (int64_t)dy * wo + dx;
-                    if constexpr (has_res) { if (a.res_mode == 1) v += rp[eo * ldr]; }
+                    if constexpr (has_res) { if (a.res_mode == 1) v += resv[4 * r + 2 * aa + b]; }
                     v = apply_act(v, act_c >= 0 ? act_c : a.act, slope);
-                    if constexpr (has_res) { if (a.res_mode == 2) v += rp[eo * ldr]; }
+                    if constexpr (has_res) { if (a.res_mode == 2) v += resv[4 * r + 2 * aa + b]; }
                     ob[eo * ldo] = v;
                 };
                 if constexpr (decltype(FULL)::value) finish();
@@ -310,6 +320,275 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
     if (a.res_mode) { if (full) epilogue_act(std::true_type{}, std::true_type{}); else epilogue_act(std::false_type{}, std::true_type{}); }
     else if (full) epilogue_act(std::true_type{}, std::false_type{});
     else epilogue_act(std::false_type{}, std::false_type{});
+}
+
+
+// ---- eight-wave form: two waves per SIMD ----------------------------------------------------------------------------------------------
+// k_conv_wino runs ONE wave per SIMD (its 16 accumulators + operands take the whole 512-register file of a lane), and the counters say
+// what that costs (profiles/r05_wino_ablation.txt): nothing overlaps the matrix pipe but the wave's own next instructions, and the issue
+// time of the transform VALU, the LDS reads and above all the LDS-DMA pieces (~85 cycles each, eleven per step) shows up one for one --
+// the loop runs at 0.63 of the MFMA rate although no unit is busy.  Here the SAME block tile (16 x 4 Winograd tiles x 64 channels, same
+// LDS image, same packed weights, same arithmetic, bit for bit) is worked by EIGHT waves: wave (fh, wm, wn) owns the frequency rows
+// i = 2 fh, 2 fh + 1 of its 32 tiles x 32 channels -- eight accumulators, 128 registers -- so two waves share a SIMD and one's loads,
+// transforms and DMA issue run under the other's MFMAs.  A frequency row needs only two of the four raw window rows (B^T has two
+// non-zeros per row), so the transform work per wave halves as well.  The price is the output transform's row pass, which now spans two
+// waves: after the main loop each wave does the column pass on its two rows in registers, the partner waves swap half of the results
+// through LDS (32 floats per lane, the memory of the patch stages) and each finishes the outputs of half the tiles.
+// Pipeline of a step (8 channels = 2 MFMA groups of 16 per wave), every register buffer single:
+//   phase A: MFMA group 0 | B fragments of group 1 | transform of group 1's window rows (R -> V[1]) | R <- group-0 rows of step s + 1
+//   barrier  (the only one: the next U stage has landed, this step's U stage and -- at q == 3 -- this channel block's patch are released)
+//   phase B: MFMA group 1 | B fragments of group 0 of step s + 1 | DMA: U stage s + 2, a third of a patch | R -> V[0] of s + 1 | R <- group-1 rows
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int NW = 8, WN = 2;
+    constexpr int OH = 8, OW = 32, PH = OH + 2, PWH = 18;
+    constexpr int NENT = 2 * PH * PWH, NPP = (NENT + 7) / 8;   // 360 entries, 45 pieces
+    constexpr int QP = (NPP + NW - 1) / NW, QG = (QP + 2) / 3;  // 6 patch pieces per wave, 2 per third
+    constexpr unsigned kPatchB = NPP * 1024u, kUB = 32768u, kU0 = 2u * kPatchB;
+    constexpr int UPW = 32 / NW;                               // 4 U pieces per wave per stage
+    constexpr unsigned kOob = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [patch 0][patch 1][U 0][U 1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    int mt, ntile, zz;
+    block_to_tile(mt, ntile, zz, 0);
+    const int btx = mt % tiles_x, bty = (mt / tiles_x) % tiles_y, n = mt / (tiles_x * tiles_y);
+    const int ho = a.out.h, wo = a.out.w;
+    const int ncb = a.ncb, nsteps = 4 * ncb;
+    const int oy0 = bty * OH, ox0 = btx * OW;
+
+    i32x4 ra, rb;
+    {
+        uint64_t pa = (uint64_t)a.in.p, pb = (uint64_t)a.w;
+        unsigned na = (unsigned)((((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4);
+        unsigned nb = (unsigned)((int64_t)(a.cout_g / 64) * nsteps * kUB);
+        ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
+        rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
+    }
+    unsigned offP[QP], ldsP[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        int p = wave + q * NW;
+        if (p > NPP - 1) p = NPP - 1;
+        const int e = 8 * p + (lane >> 3);
+        const int par = e / (PH * PWH), rem = e - par * (PH * PWH), py = rem / PWH, pxh = rem - py * PWH;
+        const int px = 2 * pxh + par, slot = (lane & 7) ^ ((pxh >> 1) & 7);
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool v = px < OW + 2 && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+        offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
+        ldsP[q] = (unsigned)p * 1024u;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned voffU = (unsigned)lane * 16u;
+    unsigned u_src = (unsigned)(ntile * nsteps) * kUB + (unsigned)(wave * UPW) * 1024u;
+    const unsigned ldsU = lds0 + kU0 + (unsigned)(wave * UPW) * 1024u;
+    auto issue_u1 = [&](int par, int k, bool live) {
+        dma16s(live ? voffU : kOob, rb, u_src + (unsigned)k * 1024u, ldsU + (unsigned)par * kUB + (unsigned)k * 1024u);
+    };
+    auto issue_patch1 = [&](int cbn, int q, bool live) {
+        dma16s(live ? offP[q] : kOob, ra, (unsigned)cbn * 128u, lds0 + (unsigned)(cbn & 1) * kPatchB + ldsP[q]);
+    };
+
+    const int tx = li & 15, ty = 2 * wm + (li >> 4);
+    unsigned rbase[2];
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh)
+        rbase[jh] = lds0 + (unsigned)((2 * ty) * PWH + tx) * 128u + (unsigned)((lh ^ (((tx + jh) >> 1) & 7)) << 4);
+    const unsigned ub = lds0 + kU0 + (unsigned)(lh * 64 + wn * 32 + li) * 16u;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+
+    auto body = [&](auto FH) {
+        constexpr int kfh = decltype(FH)::value;
+        // frequency row i = 2 kfh + gg is  d[rowA] (+/-) d[rowB]  over the window rows (B^T): i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+        auto rowA = [](int i) constexpr { return i == 0 ? 0 : (i == 2 ? 2 : 1); };
+        auto rowB = [](int i) constexpr { return i == 0 ? 2 : (i == 1 ? 2 : (i == 2 ? 1 : 3)); };
+        float R[8][4];            // window rows of ONE group: [0..3] = rowA columns 0..3 (overwritten by the row pass), [4..7] = rowB
+        float V[2][4][4];         // A operands of the two groups
+        f32x4n Bq[2][4];          // B fragments of the two groups
+
+        auto read_raw = [&](auto GG, int cbn, int sub) {       // the two window rows of group gg of step (cbn, sub) -> R
+            constexpr int i = 2 * kfh + decltype(GG)::value;
+            unsigned b[2];
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) b[jh] = (rbase[jh] + (unsigned)(cbn & 1) * kPatchB) ^ (unsigned)(sub << 5);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int row = p < 4 ? rowA(i) : rowB(i), j = p & 3;
+                const f32x4n v = lds_read4(b[j >> 1] + (unsigned)((((j & 1) * PH + row) * PWH + (j >> 1)) * 128));
+                R[p][0] = v.x; R[p][1] = v.y; R[p][2] = v.z; R[p][3] = v.w;
+            }
+        };
+        auto read_b = [&](auto GG, int par) {
+            constexpr int gg = decltype(GG)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bq[gg][j] = lds_read4(ub + (unsigned)par * kUB + (unsigned)(4 * (2 * kfh + gg) + j) * 2048u);
+        };
+        // transform op k of group gg (32 ops): k < 16: row pass, R[j][c] = R[j][c] (+/-) R[4 + j][c]; k >= 16: column pass into V[gg]
+        auto xf_op = [&](auto GG, auto K) {
+            constexpr int gg = decltype(GG)::value, i = 2 * kfh + gg, k = decltype(K)::value;
+            if constexpr (k < 16) {
+                constexpr int j = k >> 2, c = k & 3;
+                R[j][c] = (i == 1) ? R[j][c] + R[4 + j][c] : R[j][c] - R[4 + j][c];
+            } else {
+                constexpr int j = (k - 16) >> 2, c = k & 3;
+                V[gg][j][c] = bt_row(j, R[0][c], R[1][c], R[2][c], R[3][c]);
+            }
+        };
+        // one MFMA group with its prefetch / transform / DMA work spread over the 16 slots.
+        //   NG: the group whose operands are prepared during this phase (the other one); its window rows are in R on entry
+        auto phase = [&](auto GG, auto Q, int cb) {
+            constexpr int gg = decltype(GG)::value, q = decltype(Q)::value;
+            const int s = 4 * cb + q;
+            // operands being prepared: phase A (gg = 0) prepares group 1 of THIS step, phase B prepares group 0 of the NEXT step
+            const int cbn = q == 3 ? cb + 1 : cb;
+            constexpr int subn = (q + 1) & 3;
+            if constexpr (gg == 1) {
+                if constexpr (!(ABL & 2)) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if constexpr (!(ABL & 4)) read_b(ic<0>{}, (q + 1) & 1);
+            } else if constexpr (!(ABL & 4)) read_b(ic<1>{}, q & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<16>([&](auto M) {
+                constexpr int m = decltype(M)::value, tt = m >> 2, j = m & 3;
+                const f32x4n bf = Bq[gg][j];
+                const float bv = tt == 0 ? bf.x : (tt == 1 ? bf.y : (tt == 2 ? bf.z : bf.w));
+                acc[4 * gg + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[gg][j][tt], bv, acc[4 * gg + j], 0, 0, 0);
+                if constexpr (m < 8 && !(ABL & 8)) {
+                    static_for<4>([&](auto E) { xf_op(ic<(gg ^ 1)>{}, ic<4 * m + decltype(E)::value>{}); });
+                }
+                if constexpr (m == 8 && !(ABL & 4)) {           // R is free: the window rows of the group prepared in the NEXT phase
+                    if constexpr (gg == 0) read_raw(ic<0>{}, cbn, subn);          // (phase B prepares group 0 of step s + 1)
+                    else read_raw(ic<1>{}, cbn, subn);                             // (phase A of step s + 1 prepares its group 1)
+                }
+                if constexpr (gg == 1 && !(ABL & 1)) {
+                    if constexpr (m >= 9 && m < 9 + UPW) {
+                        issue_u1(q & 1, m - 9, s + 2 < nsteps);
+                        if constexpr (m == 9 + UPW - 1) u_src += kUB;
+                    }
+                    if constexpr (q != 2 && m >= 13 && m < 13 + QG) {
+                        constexpr int third = q == 3 ? 0 : (q == 0 ? 1 : 2);
+                        const int cbp = q == 3 ? cb + 2 : cb + 1;
+                        if constexpr (third * QG + (m - 13) < QP) issue_patch1(cbp, third * QG + (m - 13), cbp < ncb);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+
+        // prologue: patch 0, U 0, U 1, the first third of patch 1; then the operands of group 0 of step 0 and the window rows of its group 1
+#pragma unroll
+        for (int q = 0; q < QP; ++q) issue_patch1(0, q, true);
+#pragma unroll
+        for (int k = 0; k < UPW; ++k) issue_u1(0, k, true);
+        u_src += kUB;
+#pragma unroll
+        for (int k = 0; k < UPW; ++k) issue_u1(1, k, nsteps > 1);
+        u_src += kUB;
+#pragma unroll
+        for (int q = 0; q < QG; ++q) issue_patch1(1, q, ncb > 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_b(ic<0>{}, 0);
+        read_raw(ic<0>{}, 0, 0);
+        static_for<32>([&](auto K) { xf_op(ic<0>{}, K); });
+        read_raw(ic<1>{}, 0, 0);
+
+        for (int cb = 0; cb < ncb; ++cb) {
+            static_for<4>([&](auto Q) {
+                phase(ic<0>{}, Q, cb);
+                phase(ic<1>{}, Q, cb);
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // trailing (dead) fetches landed, trailing prefetch reads done ...
+        __builtin_amdgcn_s_barrier();                                       // ... for every wave: the patch stages become the exchange area
+
+        // ---- output transform.  Column pass (j) on this wave's two frequency rows, in registers: s[ii][b] per accumulator element r ----
+        // rows i = 2 kfh + ii.  The row pass needs all four rows: wave fh = 0 finishes tiles r < 8, wave fh = 1 tiles r >= 8; each sends
+        // the partner its s values of the OTHER eight elements (32 floats per lane) through LDS.
+        constexpr int keep0 = 8 * kfh, send0 = 8 * (kfh ^ 1);
+        const unsigned xw = lds0 + (unsigned)wave * 8192u + (unsigned)lane * 16u, xr = lds0 + (unsigned)(wave ^ 4) * 8192u + (unsigned)lane * 16u;
+        static_for<8>([&](auto RR) {
+            constexpr int r = send0 + decltype(RR)::value;
+            f32x4n v;
+            v.x = (acc[0][r] + acc[1][r]) + acc[2][r]; v.y = (acc[1][r] - acc[2][r]) - acc[3][r];
+            v.z = (acc[4][r] + acc[5][r]) + acc[6][r]; v.w = (acc[5][r] - acc[6][r]) - acc[7][r];
+            *(__attribute__((address_space(3))) f32x4n *)(size_t)(xw + (unsigned)decltype(RR)::value * 1024u) = v;
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int co = ntile * 64 + 32 * wn + li;
+        const float bias = a.bias ? a.bias[co] : 0.0f;
+        const float slope = a.slope ? a.slope[co] : 0.0f;
+        const int64_t ldo = a.out.ld, ldr = a.res.ld;
+        const int oyb = oy0 + 4 * wm + 2 * kfh, oxb = ox0 + 8 * lh;        // (r >> 3 == kfh for the tiles this wave finishes)
+        const int64_t mb = ((int64_t)n * ho + oyb) * wo + oxb;
+        float *ob = a.out.p + mb * ldo + co;
+        const float *rp = a.res_mode ? a.res.p + mb * ldr + co : nullptr;
+        const bool full = oy0 + OH <= ho && ox0 + OW <= wo;
+        auto epilogue = [&](auto ACT, auto FULL, auto RES) {
+            constexpr int act_c = decltype(ACT)::value;
+            constexpr bool has_res = decltype(RES)::value;
+            float resv[has_res ? 32 : 1];
+            if constexpr (has_res)
+                static_for<32>([&](auto E) {
+                    constexpr int e = decltype(E)::value, rr = e >> 2, aa = (e >> 1) & 1, b = e & 1;
+                    constexpr int dy = aa, dx = 2 * ((rr & 3) + 8 * ((rr >> 2) & 1)) + b;
+                    const int64_t eo = (int64_t)dy * wo + dx;
+                    if constexpr (decltype(FULL)::value) resv[e] = rp[eo * ldr];
+                    else resv[e] = (oyb + dy < ho && oxb + dx < wo) ? rp[eo * ldr] : 0.0f;
+                });
+            static_for<8>([&](auto RR) {
+                constexpr int rr = decltype(RR)::value, r = keep0 + rr;
+                const f32x4n got = lds_read4(xr + (unsigned)rr * 1024u);     // the partner's rows of this tile: (row0 b0, row0 b1, row1 b0, row1 b1)
+                float sj[4][2];
+                const float o00 = (acc[0][r] + acc[1][r]) + acc[2][r], o01 = (acc[1][r] - acc[2][r]) - acc[3][r];
+                const float o10 = (acc[4][r] + acc[5][r]) + acc[6][r], o11 = (acc[5][r] - acc[6][r]) - acc[7][r];
+                if constexpr (kfh == 0) {
+                    sj[0][0] = o00; sj[0][1] = o01; sj[1][0] = o10; sj[1][1] = o11;
+                    sj[2][0] = got.x; sj[2][1] = got.y; sj[3][0] = got.z; sj[3][1] = got.w;
+                } else {
+                    sj[0][0] = got.x; sj[0][1] = got.y; sj[1][0] = got.z; sj[1][1] = got.w;
+                    sj[2][0] = o00; sj[2][1] = o01; sj[3][0] = o10; sj[3][1] = o11;
+                }
+                static_for<4>([&](auto P) {
+                    constexpr int aa = decltype(P)::value >> 1, b = decltype(P)::value & 1;
+                    constexpr int dy = aa, dx = 2 * ((rr & 3) + 8 * ((rr >> 2) & 1)) + b;
+                    float v = (aa == 0 ? (sj[0][b] + sj[1][b]) + sj[2][b] : (sj[1][b] - sj[2][b]) - sj[3][b]) + bias;
+                    auto finish = [&]() {
+                        const int64_t eo = (int64_t)dy * wo + dx;
+                        if constexpr (has_res) { if (a.res_mode == 1) v += resv[4 * rr + 2 * aa + b]; }
+                        v = apply_act(v, act_c >= 0 ? act_c : a.act, slope);
+                        if constexpr (has_res) { if (a.res_mode == 2) v += resv[4 * rr + 2 * aa + b]; }
+                        ob[eo * ldo] = v;
+                    };
+                    if constexpr (decltype(FULL)::value) finish();
+                    else if (oyb + dy < ho && oxb + dx < wo) finish();
+                });
+            });
+        };
+        auto epilogue_act = [&](auto FULL, auto RES) {
+            switch (a.act) {
+                case CSM_ACT_NONE: epilogue(ic<CSM_ACT_NONE>{}, FULL, RES); break;
+                case CSM_ACT_RELU: epilogue(ic<CSM_ACT_RELU>{}, FULL, RES); break;
+                case CSM_ACT_SILU: epilogue(ic<CSM_ACT_SILU>{}, FULL, RES); break;
+                case CSM_ACT_PRELU: epilogue(ic<CSM_ACT_PRELU>{}, FULL, RES); break;
+                default: epilogue(ic<-1>{}, FULL, RES); break;
+            }
+        };
+        if (a.res_mode) { if (full) epilogue_act(std::true_type{}, std::true_type{}); else epilogue_act(std::false_type{}, std::true_type{}); }
+        else if (full) epilogue_act(std::true_type{}, std::false_type{});
+        else epilogue_act(std::false_type{}, std::false_type{});
+    };
+    if (fh == 0) body(ic<0>{}); else body(ic<1>{});
 }
 
 }  // namespace
@@ -340,7 +619,19 @@ int launch_conv_wino(const ConvArgs &a0, hipStream_t st) {
         kern<<<grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y);
         return csm::check_launch("k_conv_wino");
     };
+    auto go8 = [&](auto kern) {
+        static KernelPrep prep;
+        (void)prep.ensure([&] { return prepare_kernel(kern, 512, lds); });
+        kern<<<grid, 512, lds, st>>>(a, tiles_x, tiles_y);
+        return csm::check_launch("k_conv_wino8");
+    };
     switch (variant) {
+        case 200: return go8(&k_conv_wino8<0>);
+        case 201: return go8(&k_conv_wino8<1>);
+        case 202: return go8(&k_conv_wino8<2>);
+        case 204: return go8(&k_conv_wino8<4>);
+        case 208: return go8(&k_conv_wino8<8>);
+        case 215: return go8(&k_conv_wino8<15>);
         case 1: return go(&k_conv_wino<WM, WN, 1, 0>);
         case 2: return go(&k_conv_wino<WM, WN, 2, 0>);
         case 3: return go(&k_conv_wino<WM, WN, 3, 0>);
@@ -352,6 +643,15 @@ int launch_conv_wino(const ConvArgs &a0, hipStream_t st) {
         default: break;
     }
 #endif
+    // two executions of the same arithmetic (same bits): the eight-wave form (two waves per SIMD) is the default; CSM_WINO_WAVES=4 selects
+    // the one-wave-per-SIMD form (A/B measurements, tests)
+    static const int waves = [] { const char *e = getenv("CSM_WINO_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    if (waves == 8) {
+        static KernelPrep prep8;
+        (void)prep8.ensure([&] { return prepare_kernel(&k_conv_wino8<0>, 512, lds); });
+        k_conv_wino8<0><<<grid, 512, lds, st>>>(a, tiles_x, tiles_y);
+        return csm::check_launch("k_conv_wino8");
+    }
     static KernelPrep prep;
     (void)prep.ensure([&] { return prepare_kernel(&k_conv_wino<WM, WN>, 64 * WM * WN, lds); });
     k_conv_wino<WM, WN><<<grid, 64 * WM * WN, lds, st>>>(a, tiles_x, tiles_y);

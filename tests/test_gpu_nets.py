@@ -155,6 +155,7 @@ def test_full_size_all_tile_configurations_agree_bitwise(layer):
     from cartoonsegmentation_amd.runtime import CompiledProgram
     n, h, w, cin, cout, k, stride, dil, groups = layer
     p = Program("full")
+    p.winograd = False          # this test is about the DIRECT kernels' tile configurations (the Winograd layers have one kernel: test_gpu_winograd.py)
     x = p.buffer(n, h, w, cin)
     W = rnd('fw%s' % (layer,), (cout, cin // groups, k, k), 1.0 / np.sqrt(cin // groups * k * k))
     b = rnd('fb%s' % (layer,), (cout,), 0.1)
@@ -231,6 +232,7 @@ def test_dma_kernels_repeated_runs_are_bitwise_stable():
         for layer in FULL_SIZE_LAYERS:
             n, h, w, cin, cout, k, stride, dil, groups = layer
             p = Program("stress")
+            p.winograd = False  # (direct LDS-DMA kernels; k_conv_wino's repeated-run test is in test_gpu_winograd.py)
             x = p.buffer(n, h, w, cin)
             W = rnd('sw%s' % (layer,), (cout, cin // groups, k, k), 1.0 / np.sqrt(cin // groups * k * k))
             y = p.conv(x, W, rnd('sb%s' % (layer,), (cout,), 0.1), stride=stride, pad=dil * (k // 2), dil=dil, groups=groups, act='relu')

@@ -127,4 +127,4 @@ def variants(shapes, vs):
 
 
 if __name__ == '__main__' and 'variants' in sys.argv[1:]:
-    variants([(8, 160, 160, 256, 256), (16, 360, 360, 64, 64)], [0, 1, 2, 3, 4, 8, 12, 15, 100])
+    variants([(8, 160, 160, 256, 256), (16, 360, 360, 64, 64)], [int(v) for v in os.environ.get('WINO_VARIANTS', '0,200,201,202,204,208,215').split(',')])
