@@ -48,6 +48,12 @@ template <int N> using ic = std::integral_constant<int, N>;
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// raw barrier with its waits in ONE asm block (the wait can never be separated from the barrier by a basic-block boundary or by a sunk
+// LDS read: tools/check_isa_barriers.py): everybody's DMA pieces counted by vmcnt have landed, everybody's LDS reads have completed
+template <int VM> __device__ __forceinline__ void wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(VM) : "memory");
+}
+
 // B^T rows: one fp32 operation per value (the contract's order)
 __device__ __forceinline__ float bt_row(int i, float d0, float d1, float d2, float d3) {
     return i == 0 ? d0 - d2 : (i == 1 ? d1 + d2 : (i == 2 ? d2 - d1 : d1 - d3));
@@ -179,8 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
     if constexpr (OPT & 1) { issue_u(1, 0, UPW, nsteps > 1); u_src += kUB; }
     else issue_u(1, 0, UPW / 2, nsteps > 1);
     issue_patch(1, 0, QG, ncb > 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    wait_barrier<0>();
     read_raw(0, 0, 0, 16);
     read_b(0, 0, 0);
     static_for<64>([&](auto K) { row_op(K); });
@@ -201,9 +206,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
                     // (q != 2) are the youngest loads in flight and are not needed before the barrier of step (cb + 1, 2): they may stay
                     // outstanding (loads retire in order)
                     if constexpr (!(ABL & 2)) {
-                        if constexpr ((OPT & 1) && q != 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((QG + 3) / 4 * 4) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
+                        if constexpr ((OPT & 1) && q != 2) wait_barrier<(QG + 3) / 4 * 4>();
+                        else wait_barrier<0>();
                     }
                     if constexpr (!(ABL & 4)) read_b((q + 1) & 1, 0, buf ^ 1);
                 } else if constexpr (!(ABL & 4)) {
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
 //   phase B: MFMA group 1 | B fragments of group 0 of step s + 1 | DMA: U stage s + 2, a third of a patch | R -> V[0] of s + 1 | R <- group-1 rows
 template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, int tiles_y) {
-    constexpr int NW = 8, WN = 2;
+    constexpr int NW = 8;
     constexpr int OH = 8, OW = 32, PH = OH + 2, PWH = 18;
     constexpr int NENT = 2 * PH * PWH, NPP = (NENT + 7) / 8;   // 360 entries, 45 pieces
     constexpr int QP = (NPP + NW - 1) / NW, QG = (QP + 2) / 3;  // 6 patch pieces per wave, 2 per third
@@ -450,10 +454,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
             const int cbn = q == 3 ? cb + 1 : cb;
             constexpr int subn = (q + 1) & 3;
             if constexpr (gg == 1) {
-                if constexpr (!(ABL & 2)) {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
+                if constexpr (!(ABL & 2)) wait_barrier<0>();
                 if constexpr (!(ABL & 4)) read_b(ic<0>{}, (q + 1) & 1);
             } else if constexpr (!(ABL & 4)) read_b(ic<1>{}, q & 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -495,8 +496,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
         u_src += kUB;
 #pragma unroll
         for (int q = 0; q < QG; ++q) issue_patch1(1, q, ncb > 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        wait_barrier<0>();
         read_b(ic<0>{}, 0);
         read_raw(ic<0>{}, 0, 0);
         static_for<32>([&](auto K) { xf_op(ic<0>{}, K); });
@@ -508,8 +508,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
                 phase(ic<1>{}, Q, cb);
             });
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // trailing (dead) fetches landed, trailing prefetch reads done ...
-        __builtin_amdgcn_s_barrier();                                       // ... for every wave: the patch stages become the exchange area
+        wait_barrier<0>();        // trailing (dead) fetches landed, trailing prefetch reads done, for every wave: the patch stages become the exchange area
 
         // ---- output transform.  Column pass (j) on this wave's two frequency rows, in registers: s[ii][b] per accumulator element r ----
         // rows i = 2 kfh + ii.  The row pass needs all four rows: wave fh = 0 finishes tiles r < 8, wave fh = 1 tiles r >= 8; each sends
@@ -523,8 +522,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
             v.z = (acc[4][r] + acc[5][r]) + acc[6][r]; v.w = (acc[5][r] - acc[6][r]) - acc[7][r];
             *(__attribute__((address_space(3))) f32x4n *)(size_t)(xw + (unsigned)decltype(RR)::value * 1024u) = v;
         });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        wait_barrier<0>();
         const int co = ntile * 64 + 32 * wn + li;
         const float bias = a.bias ? a.bias[co] : 0.0f;
         const float slope = a.slope ? a.slope[co] : 0.0f;
