@@ -332,7 +332,7 @@ class FrameWorkload(Workload):
                 "what": "headline step fed from pinned host memory (H2D of the %d input frames and D2H of their output records on a copy "
                         "stream, double-buffered, inside the timed region)" % B}
 
-    def _zoe_variant(self, frames=3):
+    def _zoe_variant(self, frames=3, batch=8):
         """BASELINE configs[2] with its literal depth network: seg + ZoeDepth (built-in MiDaS DPT-BEiT-L core, 672 x 672, flip TTA: the plain
         and the mirrored pass, 1765 tokens each, as the two samples of one core run) + one warp per 1024 x 1024 frame, serial; and the core program's own conv population against the MFMA roof"""
         from cartoonsegmentation_amd.kenburns import KenBurnsConfig, KenBurnsPipeline
@@ -352,6 +352,19 @@ class FrameWorkload(Workload):
         dt = (time.perf_counter() - t0) / frames
         res = {"frames_per_s": round(1.0 / dt, 2), "ms_per_frame": round(dt * 1e3, 2), "batch": 1, "build_and_tune_s": round(t_build, 1),
                "what": "seg (RTMDet + ISNet) + ZoeDepth on the built-in DPT-BEiT-L core (img_size 672, pad + flip TTA) + 1 warp, 1024x1024, serial"}
+        if batch > 1:
+            # the same workload as an 8-frame step like the headline (configs[2]-literal network, comparable with `value`): one core run over
+            # the 8 frames and their mirrored passes (n = 16 samples of 1765 tokens)
+            recs = torch.zeros((batch, self.rb), dtype=torch.uint8, device=self.device)
+            imgs = [self.all_imgs[k % len(self.all_imgs)] for k in range(batch)]
+            self.run_frames(pipe, self.wf, imgs, recs); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                self.run_frames(pipe, self.wf, imgs, recs)
+            torch.cuda.synchronize()
+            dtb = (time.perf_counter() - t0) / 2
+            res["batch%d" % batch] = {"frames_per_s": round(batch / dtb, 2), "ms_per_step": round(dtb * 1e3, 2), "batch": batch,
+                                      "what": "%d frames per step: seg + ZoeDepth (one DPT-BEiT-L core run, n = %d) + %d warps" % (batch, 2 * batch, batch)}
         core = getattr(pipe.depth_zoe, 'core', None)
         for (n, h, w), cp in getattr(core, '_progs', {}).items():
             ext = [torch.randn(b.n, b.c, b.h, b.w, device=self.device) for b in sorted((b for b in cp.prog.bufs if b.ext >= 0), key=lambda b: b.ext)]
@@ -518,6 +531,17 @@ class FrameWorkload(Workload):
             out["tiled_%d_3streams" % size] = {"us_per_frame": round(ms * 1e3, 2), "GBps": round(alg / (ms * 1e-3) / 1e9, 1),
                                                "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                "what": "60 frames round-robin over 3 streams with their own scratch (the video loop's issue order)"}
+            # ONE call, K frames (csm_warp_frames_tiled): the same overlap inside the library -- internal lanes forked from / joined to the
+            # caller's stream by events; the caller issues one asynchronous call on one stream
+            wfm = self.ops.WarpFrame(size, size, self.device, path="tiled")
+            K = 24
+            outm = torch.empty((K, size, size, 3), dtype=torch.uint8, device=self.device)
+            shifts = [shift] * K
+            ms = event_time_ms(lambda: wfm.frames(pts, rgb, dep, sc['focal'], sc['baseline'], shifts, lanes=3, out=outm), 5, warm=2) / K
+            out["tiled_%d_multiframe" % size] = {"us_per_frame": round(ms * 1e3, 2), "GBps": round(alg / (ms * 1e-3) / 1e9, 1),
+                                                 "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "what": "csm_warp_frames_tiled: %d frames per call on ONE caller stream (3 internal lanes)" % K}
+            del wfm, outm
             if size == 2048:
                 # SURVEY 8(d)'s L3-spilling point: EIGHT DIFFERENT 2048^2 clouds in a batch (8 x 155 P = 5.2 GB of algorithmic traffic, far
                 # beyond the 256 MB Infinity Cache: no frame finds its inputs cached), one stream, one scratch

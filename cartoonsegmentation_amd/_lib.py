@@ -46,6 +46,7 @@ def load():
         _lib.csm_autozoom_band_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_warp_tile_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_warp_tile_header_bytes.restype = ctypes.c_size_t
+        _lib.csm_warp_frames_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_percentile_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_bokeh_depth_scratch_bytes.restype = ctypes.c_size_t
         _lib.csm_kenburns_frame_scratch_bytes.restype = ctypes.c_size_t

@@ -38,7 +38,8 @@ struct SelState {            // device-resident state of the 4 concurrent select
     unsigned prefix[4];      // top 16 key bits of each order statistic (written by the last block of pass 1)
     unsigned rank[4];        // its rank among the elements that share those bits
     unsigned ticket;         // blocks of the running pass that are done (the last one finishes the pass); 0 between passes
-    unsigned pad[7];
+    unsigned poisoned;       // sticky: a pass found its tables / ticket not in the all-zero state the protocol starts from (see k_sel_top16)
+    unsigned pad[6];
 };
 struct SelInit { unsigned rank[4]; };                     // the four ranks of a call
 
@@ -183,6 +184,12 @@ __global__ __launch_bounds__(kBlock) void k_sel_top16(const float *__restrict__ 
     if (!last) return;                                   // (the reads below are coherent atomic loads of atomically written counts: no fence)
     const unsigned c = ld_bin(g, kHistWords, (unsigned)tid);
     const unsigned incl = block_scan_256(c, wsum), excl = incl - c;
+    // Poisoned-state check (ADVICE r03 / VERDICT r04): the hand-off assumes tables and ticket all-zero on entry.  If an earlier launch on
+    // these buffers was aborted between its counts and its clean-up, stale counts or a stale ticket survive: either way the coarse bins
+    // seen by the block that believes it is last do not add up to n (every element is counted exactly once).  That is detected here and
+    // made LOUD: the sticky flag turns the outputs of this and every later selection on the state into NaN until the caller re-zeroes the
+    // scratch buffer (csm_percentile_scratch_bytes documents the all-zero start).
+    if (tid == kBlock - 1 && (int64_t)incl != n) st->poisoned = 1u;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (init.rank[r] >= excl && init.rank[r] < incl) { sbin[r] = (unsigned)tid; sbefore[r] = excl; }
@@ -277,7 +284,13 @@ __global__ __launch_bounds__(kBlock) void k_sel_digit8(const float *__restrict__
         if (tid == 0) { key4[r] = (pre[r] << 8) | res2[0]; st->prefix[r] = key4[r]; st->rank[r] = res2[1]; }
         __syncthreads();
     }
-    if (tid == 0) { if (SHIFT == 0) sel_finish(key4, t_lo, t_hi, out2); st->ticket = 0u; }
+    if (tid == 0) {
+        if (SHIFT == 0) {
+            sel_finish(key4, t_lo, t_hi, out2);
+            if (st->poisoned) { out2[0] = __uint_as_float(0x7fc00000u); out2[1] = __uint_as_float(0x7fc00000u); }      // (see k_sel_top16)
+        }
+        st->ticket = 0u;
+    }
 }
 
 struct Lut256 { uint8_t v[256]; };

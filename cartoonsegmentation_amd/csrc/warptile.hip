@@ -22,6 +22,7 @@
 // chain bit for bit (min is order free; the degrid is the same Jacobi form; every comparison is the reference's expression).
 // Measured numbers per round: DESIGN.md section 4.1 and profiles/.
 #include "warp_device.h"
+#include <mutex>
 
 namespace {
 using namespace csmwarp;
@@ -683,6 +684,75 @@ extern "C" size_t csm_warp_tile_header_bytes(int H, int W) { return (H <= 0 || W
 
 // largest tile count the block-local histograms / prefix tables support (LDS: 4 B per tile); larger frames use csm_warp_frame
 extern "C" int csm_warp_tile_supported(int H, int W) { return H > 0 && W > 0 && tile_geom(H, W).nt <= 8192; }
+
+// ---- K frames of one cloud in ONE call: frame k + 1's binning and frame k - 1's hole fill run under frame k's render ------------------
+// The three kernels of a frame are a dependent chain (bin 12 us -> render 35 us -> holes 11 us at 1024^2) and each leaves most of the
+// chip idle part of the time (binning is atomic-latency bound, the hole fill walks bitmaps): one frame in isolation runs at 0.34 of the
+// HBM roof.  Frames of a video are independent, so the call deals them round-robin onto `lanes` internal streams (lane 0 = the
+// caller's stream), each with its own scratch, forked from and joined to the caller's stream with events: the caller sees one
+// asynchronous call on one stream, the GPU sees up to three chains in different phases (0.5 of the roof, profiles/).
+namespace {
+struct LaneSet { hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}; bool ready = false; };
+LaneSet g_lanes[32];
+std::mutex g_lanes_mutex;
+int get_lanes(LaneSet *&ls) {
+    int d = 0;
+    CSM_HIP(hipGetDevice(&d));
+    std::lock_guard<std::mutex> lk(g_lanes_mutex);
+    ls = &g_lanes[d & 31];
+    if (!ls->ready) {
+        for (int i = 0; i < 2; ++i) {
+            CSM_HIP(hipStreamCreateWithFlags(&ls->aux[i], hipStreamNonBlocking));
+            CSM_HIP(hipEventCreateWithFlags(&ls->join[i], hipEventDisableTiming));
+        }
+        CSM_HIP(hipEventCreateWithFlags(&ls->fork, hipEventDisableTiming));
+        ls->ready = true;
+    }
+    return CSM_OK;
+}
+}  // namespace
+
+extern "C" size_t csm_warp_frames_scratch_bytes(int H, int W, int64_t N, int lanes) {
+    const size_t one = (csm_warp_tile_scratch_bytes(H, W, N) + 255) & ~(size_t)255;
+    return one * (size_t)(lanes < 1 ? 1 : (lanes > 3 ? 3 : lanes));
+}
+
+extern "C" int csm_warp_frames_tiled(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal,
+                                     double baseline, const float *shifts_host, int K, int lanes, void *scratch, float *render_filled,
+                                     uint8_t *frames_u8, void *stream) {
+    CSM_REQUIRE(shifts_host && K >= 0 && lanes >= 1 && lanes <= 3 && scratch && frames_u8);
+    CSM_REQUIRE((((uintptr_t)scratch) & 15) == 0);
+    if (K == 0) return CSM_OK;
+    const size_t one = (csm_warp_tile_scratch_bytes(H, W, N) + 255) & ~(size_t)255;
+    const size_t frame_bytes = (size_t)H * W * 3, render_floats = (size_t)4 * H * W;
+    hipStream_t main = (hipStream_t)stream;
+    const int nl = lanes < K ? lanes : K;
+    LaneSet *ls = nullptr;
+    std::unique_lock<std::mutex> lk(g_lanes_mutex, std::defer_lock);       // (released on every return path)
+    if (nl > 1) {
+        int rc = get_lanes(ls); if (rc) return rc;
+        // the lane streams are shared by every caller on this device: one multi-frame call at a time forks from / joins to its own stream
+        lk.lock();
+        CSM_HIP(hipEventRecord(ls->fork, main));
+        for (int i = 1; i < nl; ++i) CSM_HIP(hipStreamWaitEvent(ls->aux[i - 1], ls->fork, 0));
+    }
+    int rc = CSM_OK;
+    for (int k = 0; k < K && rc == CSM_OK; ++k) {
+        const int lane = k % nl;
+        hipStream_t st = lane == 0 ? main : ls->aux[lane - 1];
+        rc = csm_warp_frame_tiled(pts, rgb, depth, N, H, W, focal, baseline, shifts_host[3 * k], shifts_host[3 * k + 1], shifts_host[3 * k + 2],
+                                  (char *)scratch + (size_t)lane * one, render_filled ? render_filled + (size_t)k * render_floats : nullptr,
+                                  frames_u8 + (size_t)k * frame_bytes, (void *)st);
+    }
+    if (nl > 1) {
+        for (int i = 1; i < nl; ++i) {
+            hipError_t e = hipEventRecord(ls->join[i - 1], ls->aux[i - 1]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(main, ls->join[i - 1], 0);
+            if (e != hipSuccess && rc == CSM_OK) { csm::set_error("csm_warp_frames_tiled join: %s", hipGetErrorString(e)); rc = CSM_ERR_HIP; }
+        }
+    }
+    return rc;
+}
 
 extern "C" int csm_warp_frame_tiled(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal,
                                     double baseline, float sx, float sy, float sz, void *scratch, float *render_filled,

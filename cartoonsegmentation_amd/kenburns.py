@@ -272,6 +272,14 @@ class KenBurnsPipeline:
         depth = self.depth_zoe.infer(img_tensor, with_flip_aug=True, pad_input=True)
         return depth_to_disparity(depth, self.cfg.focal, self.cfg.baseline)
 
+    def _depth_est_zoe_batch(self, frames_d):
+        """_depth_est_zoe for several frames of ONE size: a single DepthModel.infer over the stack (B frames + their mirrored passes = 2 B
+        samples of one core run: the layer programs are batch invariant, every frame's bits are those of a run by itself)"""
+        from .zoedepth import depth_to_disparity
+        x = torch.cat([ops.image_tensor(f) for f in frames_d], 0)
+        depth = self.depth_zoe.infer(x, with_flip_aug=True, pad_input=True)
+        return [depth_to_disparity(depth[k:k + 1].contiguous(), self.cfg.focal, self.cfg.baseline) for k in range(len(frames_d))]
+
     def _set_default_estimator(self):
         """anime_3dkenburns/models/__init__.py:33-52: Semantics (torchvision vgg19_bn) + Disparity (network-disparity.pytorch)"""
         if getattr(self, '_disp_ws', None) is None:
@@ -572,6 +580,8 @@ class KenBurnsPipeline:
             def depth_of(group, slot):
                 if batched_leres:
                     return self._depth_est_leres_batch(group, slot=slot)
+                if self._depth_est == self._depth_est_zoe and len(group) > 1 and len({tuple(f.shape) for f in group}) == 1:
+                    return self._depth_est_zoe_batch(group)
                 return [self._depth_est(None, f) for f in group]
             if self.overlap_depth:
                 # the depth CNN only needs the images: it runs on a second HIP stream while the detector / ISNet batches (and the

@@ -367,6 +367,30 @@ class WarpFrame:
                                              ptr(self.render), ptr(self.frame), st), "warp_frame")
         return self.frame, self.render
 
+    def frames(self, tenPoints, tenImage, tenDepth, fltFocal, fltBaseline, shifts, lanes=3, out=None, stream=None):
+        """K frames of one cloud in ONE call (csm_warp_frames_tiled): shifts = K x (sx, sy, sz); returns uint8 [K, H, W, 3].  The frames are
+        bit-identical to K __call__s; frame k + 1's binning and frame k - 1's hole fill overlap frame k's render on internal streams."""
+        import ctypes
+        assert self.path == 'tiled'
+        L = _lib.load()
+        N = tenPoints.shape[2]
+        K = len(shifts)
+        flat = []
+        for s in shifts:
+            flat.extend(float(v.value) for v in _f32x3(s))
+        arr = (ctypes.c_float * (3 * max(K, 1)))(*flat)
+        if getattr(self, '_multi_key', None) is None or self._multi_key[0] < N or self._multi_key[1] != lanes:
+            cap = int(N * 1.25) + 1024                         # (the point cloud grows when inpainting appends points)
+            nbytes = L.csm_warp_frames_scratch_bytes(i32(self.H), i32(self.W), i64(cap), i32(lanes))
+            self._multi = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=self.device)     # (headers must start at zero)
+            self._multi_key = (cap, lanes)
+        if out is None:
+            out = torch.empty((K, self.H, self.W, 3), dtype=torch.uint8, device=self.device)
+        st = stream_ptr() if stream is None else stream
+        check(L.csm_warp_frames_tiled(ptr(tenPoints), ptr(tenImage), ptr(tenDepth), i64(N), i32(self.H), i32(self.W), f64(fltFocal),
+                                      f64(fltBaseline), arr, i32(K), i32(lanes), ptr(self._multi), ptr(None), ptr(out), st), "warp_frames_tiled")
+        return out
+
     def frame_into(self, out_hwc, tenPoints, tenImage, tenDepth, fltFocal, fltBaseline, shift, patch_h, patch_w, center_x, center_y,
                    dof=None):
         """One output frame of the video loop in ONE library call (csm_kenburns_frame, kenburns_effect.py:1027-1072): warp

@@ -40,22 +40,39 @@ class PrefixedWeights:
 
 
 class DPTBeitCore:
-    """the MiDaS DPT-BEiT core as a callable: one compiled layer program per (batch, height, width) of the prepared input"""
+    """the MiDaS DPT-BEiT core as a callable: one compiled layer program per (batch, height, width) of the prepared input.
 
-    def __init__(self, ws, cfg=None, device=None):
+    Cost of a NEW shape (keep_aspect_ratio=True makes the prepared size follow the input's aspect ratio; the batch changes with the
+    number of frames and with the flip TTA): a host re-pack of the 345 M BEiT-L parameters plus 24 re-sampled relative-position tables
+    (seconds) and a device buffer of ~1.3 GB of packed weights + the workspace.  The packed image depends on the shape (the tables sit
+    between the layers' panels; which 3x3 layers take the Winograd panels follows the per-sample map size), so programs cannot share one
+    buffer.  The cache is therefore BOUNDED: the `max_programs` most recently used shapes stay resident (default 2, env
+    CSM_ZOE_PROGRAM_CACHE), older ones are dropped and their HBM released -- a service fed arbitrary image sizes pays the re-pack again
+    instead of leaking a gigabyte per shape.  INTEGRATION.md states the same."""
+
+    def __init__(self, ws, cfg=None, device=None, max_programs=None):
+        import collections
+        import os
         from .nets import DPTBeitConfig
         self.ws, self.cfg = ws, cfg or DPTBeitConfig()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device in (None, 'cuda') else torch.device(device)
-        self._progs, self._weights = {}, None
+        self.max_programs = max(1, int(max_programs if max_programs is not None else os.environ.get('CSM_ZOE_PROGRAM_CACHE', '2')))
+        self._progs, self._weights = collections.OrderedDict(), None
+        self.evictions = 0
 
     def program(self, n, h, w):
         from .nets import build_dpt_beit
         key = (n, h, w)
-        if key not in self._progs:
-            prog = build_dpt_beit(self.ws, n, h, w, self.cfg)
-            # every program of this core packs the same parameters except the re-sampled relative-position tables: they are small, the
-            # 1.2 GB of BEiT-L weights are not -- but the packed layout is position dependent, so each shape keeps its own buffer
-            self._progs[key] = CompiledProgram(prog, self.device)
+        if key in self._progs:
+            self._progs.move_to_end(key)
+            return self._progs[key]
+        while len(self._progs) >= self.max_programs:         # least recently used first; its weights / workspace tensors die with it
+            self._progs.popitem(last=False)
+            self.evictions += 1
+        if self.evictions:
+            torch.cuda.current_stream(self.device).synchronize()     # (the evicted program may still be executing on this stream)
+            torch.cuda.empty_cache()
+        self._progs[key] = CompiledProgram(build_dpt_beit(self.ws, n, h, w, self.cfg), self.device)
         return self._progs[key]
 
     def __call__(self, xp):

@@ -125,6 +125,17 @@ int csm_warp_frame_tiled(const float *pts, const float *rgb, const float *depth,
                          double baseline, float sx, float sy, float sz, void *scratch, float *render_filled, uint8_t *frame_u8,
                          void *stream);
 
+/* K frames of ONE cloud under K camera shifts (the frame loop of KenBurnsPipeline.process_kenburns, kenburns_effect.py:1027-1040) in one
+ * asynchronous call on `stream`: the frames are dealt round-robin onto `lanes` (1..3) internal streams (lane 0 = `stream`) with one scratch
+ * each, forked from and joined to `stream` by events, so that frame k + 1's binning and frame k - 1's hole fill run under frame k's
+ * render.  Every frame is bit-identical to csm_warp_frame_tiled with the same arguments.
+ * shifts_host: K x (sx, sy, sz) HOST floats (read before the call returns); scratch: csm_warp_frames_scratch_bytes(H, W, N, lanes) device
+ * bytes = `lanes` consecutive csm_warp_frame_tiled scratches (each rounded up to 256 B), every one with its header zeroed once by the
+ * caller -- hipMemset the whole buffer once; frames_u8 [K][H][W][3]; render_filled NULL or [K][4][H][W]. */
+size_t csm_warp_frames_scratch_bytes(int H, int W, int64_t N, int lanes);
+int csm_warp_frames_tiled(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal, double baseline,
+                          const float *shifts_host, int K, int lanes, void *scratch, float *render_filled, uint8_t *frames_u8, void *stream);
+
 /* Coverage search of process_autozoom   anime_3dkenburns/common.py:86-142, batched.
  * For each of K candidate camera shifts (sx_k, sy_k, shift_z) -- the float32 tenShift of process_shift (common.py:74) --
  * counts[k] = number of pixels with tenExisting > 0 after process_shift + render_pointcloud of pts [1,3,N]
@@ -481,7 +492,9 @@ int csm_colorize_gray_r(const float *value, uint8_t *out, int64_t n, float vmin,
 /* The same three steps without host round trips (frametail.hip) -- the per-frame tail of kenburns_effect.py:1042-1067:
  * csm_percentile_pair: out2 (DEVICE) = {np.percentile(value, q_lo), np.percentile(value, q_hi)} (method 'linear'), exact, by a
  *   3-pass (16 + 8 + 8 bit) radix select instead of a sort, three launches; scratch = csm_percentile_scratch_bytes() device bytes, ZEROED
- *   ONCE by the caller (every call leaves the counting tables it needs next time cleared) and used by one stream at a time.
+ *   ONCE by the caller (every call leaves the counting tables it needs next time cleared) and used by one stream at a time.  If a call
+ *   finds the tables NOT in that state (e.g. after an aborted launch) its counts do not add up to n: out2 becomes NaN, for that call and
+ *   every later one, until the caller zeroes the scratch again -- never a plausible wrong percentile.
  * csm_colorize_gray_r_dev: csm_colorize_gray_r with vmin / vmax read from device memory and the matplotlib byte LUT (256 HOST
  *   bytes, index -> grey level) applied in the kernel.
  * csm_bokeh_depth_auto: csm_bokeh_depth with dmax / mn / mx2 derived on the device from the histogram of depth_u8; scratch =

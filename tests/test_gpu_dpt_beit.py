@@ -114,3 +114,24 @@ def test_zoedepth_runs_on_its_builtin_core():
     img = torch.rand(1, 3, 70, 110, device='cuda')
     d = z.infer(img)
     assert d.shape == (1, 1, 70, 110) and torch.isfinite(d).all() and float(d.min()) > 0
+
+
+def test_core_program_cache_is_bounded():
+    """DPTBeitCore keeps the `max_programs` most recently used (batch, height, width) programs: a third shape evicts the least recently
+    used one (its packed weights and workspace are released), and coming back to an evicted shape rebuilds it with identical results"""
+    from cartoonsegmentation_amd.zoedepth import DPTBeitCore
+    cfg = DPTBeitConfig(**SMALL)
+    core = DPTBeitCore(SynthWeights('dptbeit_small.'), cfg, max_programs=2)
+    rng = np.random.default_rng(21)
+    x1 = torch.from_numpy(rng.normal(0, 1, (1, 3, 64, 96)).astype(np.float32)).cuda()
+    first = core(x1)[0].clone()
+    core(torch.from_numpy(rng.normal(0, 1, (1, 3, 96, 64)).astype(np.float32)).cuda())
+    assert list(core._progs) == [(1, 64, 96), (1, 96, 64)] and core.evictions == 0
+    core(x1)                                                             # touch: (1, 96, 64) becomes the least recently used
+    core(torch.from_numpy(rng.normal(0, 1, (2, 3, 64, 64)).astype(np.float32)).cuda())
+    assert list(core._progs) == [(1, 64, 96), (2, 64, 64)] and core.evictions == 1
+    core(torch.from_numpy(rng.normal(0, 1, (1, 3, 96, 64)).astype(np.float32)).cuda())
+    assert (1, 64, 96) not in core._progs and core.evictions == 2
+    again = core(x1)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(first, again) and len(core._progs) == 2

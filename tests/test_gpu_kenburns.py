@@ -397,6 +397,19 @@ def test_device_percentiles_and_bokeh_stats_are_exact():
             check(L.csm_percentile_pair(ptr(d), i64(a.size), f64(q_lo), f64(q_hi), ptr(out2), ptr(sel), stream_ptr()))
             got = out2.cpu().numpy()
             assert got[0] == okb._percentile(a, q_lo) and got[1] == okb._percentile(a, q_hi), (a.size, q_lo, q_hi, got)
+    # poisoned state (what an aborted launch could leave behind): a stale count in a pass-1 table -> the selection does not return a
+    # plausible wrong number, it returns NaN, and keeps doing so until the caller re-zeroes the scratch (the documented start state)
+    a = rng.normal(0, 1, 50000).astype(np.float32)
+    d = torch.from_numpy(a).cuda()
+    sel.view(torch.int32)[16 + 7] += 3                                # a coarse bin of XCD copy 0 (the tables follow the 64-byte state)
+    check(L.csm_percentile_pair(ptr(d), i64(a.size), f64(2.0), f64(85.0), ptr(out2), ptr(sel), stream_ptr()))
+    assert torch.isnan(out2).all()
+    check(L.csm_percentile_pair(ptr(d), i64(a.size), f64(2.0), f64(85.0), ptr(out2), ptr(sel), stream_ptr()))
+    assert torch.isnan(out2).all()                                    # sticky
+    sel.zero_()
+    check(L.csm_percentile_pair(ptr(d), i64(a.size), f64(2.0), f64(85.0), ptr(out2), ptr(sel), stream_ptr()))
+    got = out2.cpu().numpy()
+    assert got[0] == okb._percentile(a, 2.0) and got[1] == okb._percentile(a, 85.0)
     d8 = rng.integers(3, 250, (300, 400)).astype(np.uint8)
     dd = torch.from_numpy(d8).cuda()
     for fp in (0.0, 100.0, 17.25, 255.0):

@@ -289,3 +289,28 @@ def test_render_pointcloud_68_channels_tiled_vs_atomics_and_oracle(ops):
         assert close_frac(rt.cpu().numpy(), ro) >= 0.999
         rt2, et2 = ops.render_pointcloud(ps, data, W, H, sc['focal'], sc['baseline'], path='tiled')      # same scratch again
         assert torch.equal(rt, rt2) and torch.equal(et, et2)
+
+
+def test_multi_frame_call_is_bitwise_the_per_frame_calls(ops):
+    """csm_warp_frames_tiled: K frames of one cloud dealt onto 1 / 2 / 3 internal streams in ONE call == K csm_warp_frame_tiled calls, bit
+    for bit, also when the call is repeated on the same scratch (headers re-armed by every frame) and when K is not a multiple of the
+    lane count; K = 0 is a no-op"""
+    from cartoonsegmentation_amd import synth
+    H, W = 304, 416
+    sc = synth.warp_scene(H, W, 77)
+    disp = dev(sc['disp']); disp = disp / disp.max() * sc['baseline']
+    depth, _, pts, _ = ops.disparity_to_points(disp, sc['focal'], sc['baseline'])
+    pts, dep, rgb = pts.view(1, 3, -1).contiguous(), depth.view(1, 1, -1).contiguous(), dev(sc['rgb'])
+    shifts = [(3.0 * k - 9.0, 1.5 * k, 0.25 * k) for k in range(7)]
+    wf = ops.WarpFrame(H, W, 'cuda', path='tiled')
+    ref = torch.stack([wf(pts, rgb, dep, sc['focal'], sc['baseline'], s)[0].clone() for s in shifts])
+    assert not torch.equal(ref[0], ref[6])
+    for lanes in (1, 2, 3):
+        wm = ops.WarpFrame(H, W, 'cuda', path='tiled')
+        for rep in range(3):
+            got = wm.frames(pts, rgb, dep, sc['focal'], sc['baseline'], shifts, lanes=lanes)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (lanes, rep)
+        assert wm.frames(pts, rgb, dep, sc['focal'], sc['baseline'], [], lanes=lanes).shape[0] == 0
+        one = wm.frames(pts, rgb, dep, sc['focal'], sc['baseline'], shifts[2:3], lanes=lanes)
+        assert torch.equal(one[0], ref[2])
