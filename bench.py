@@ -534,7 +534,7 @@ class FrameWorkload(Workload):
             # ONE call, K frames (csm_warp_frames_tiled): the same overlap inside the library -- internal lanes forked from / joined to the
             # caller's stream by events; the caller issues one asynchronous call on one stream
             wfm = self.ops.WarpFrame(size, size, self.device, path="tiled")
-            K = 24
+            K = 60 if size == 1024 else 24
             outm = torch.empty((K, size, size, 3), dtype=torch.uint8, device=self.device)
             shifts = [shift] * K
             ms = event_time_ms(lambda: wfm.frames(pts, rgb, dep, sc['focal'], sc['baseline'], shifts, lanes=3, out=outm), 5, warm=2) / K

@@ -720,9 +720,10 @@ extern "C" size_t csm_warp_frames_scratch_bytes(int H, int W, int64_t N, int lan
 extern "C" int csm_warp_frames_tiled(const float *pts, const float *rgb, const float *depth, int64_t N, int H, int W, double focal,
                                      double baseline, const float *shifts_host, int K, int lanes, void *scratch, float *render_filled,
                                      uint8_t *frames_u8, void *stream) {
-    CSM_REQUIRE(shifts_host && K >= 0 && lanes >= 1 && lanes <= 3 && scratch && frames_u8);
-    CSM_REQUIRE((((uintptr_t)scratch) & 15) == 0);
+    CSM_REQUIRE(K >= 0 && lanes >= 1 && lanes <= 3);
     if (K == 0) return CSM_OK;
+    CSM_REQUIRE(shifts_host && scratch && frames_u8);
+    CSM_REQUIRE((((uintptr_t)scratch) & 15) == 0);
     const size_t one = (csm_warp_tile_scratch_bytes(H, W, N) + 255) & ~(size_t)255;
     const size_t frame_bytes = (size_t)H * W * 3, render_floats = (size_t)4 * H * W;
     hipStream_t main = (hipStream_t)stream;
