@@ -342,10 +342,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void k_conv_wino(ConvArgs a, int t
 //   phase A: MFMA group 0 | B fragments of group 1 | transform of group 1's window rows (R -> V[1]) | R <- group-0 rows of step s + 1
 //   barrier  (the only one: the next U stage has landed, this step's U stage and -- at q == 3 -- this channel block's patch are released)
 //   phase B: MFMA group 1 | B fragments of group 0 of step s + 1 | DMA: U stage s + 2, a third of a patch | R -> V[0] of s + 1 | R <- group-1 rows
-template <int ABL = 0>
+// GEO: block-tile geometry (speed only: an output's arithmetic does not depend on the tile it falls in).  0 = 16 x 4 Winograd tiles (32 x 8
+// output pixels), 1 = 8 x 8 tiles (16 x 16 pixels): the square tile wastes nothing on 80 x 80 maps (a 32-wide tile pads them to 96) and
+// less on 40 / 45-pixel maps; the launcher takes the geometry that covers the map with fewer block tiles.  With 8-wide tiles a
+// ds_read_b128 lane group spans four tile rows, so the slot swizzle is keyed on the patch row as well: (px/2 >> 1) ^ 4 ((py >> 1) & 1).
+template <int ABL = 0, int GEO = 0>
 __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, int tiles_y) {
     constexpr int NW = 8;
-    constexpr int OH = 8, OW = 32, PH = OH + 2, PWH = 18;
+    constexpr int OH = GEO ? 16 : 8, OW = GEO ? 16 : 32, PH = OH + 2, PWH = GEO ? 10 : 18;
     constexpr int NENT = 2 * PH * PWH, NPP = (NENT + 7) / 8;   // 360 entries, 45 pieces
     constexpr int QP = (NPP + NW - 1) / NW, QG = (QP + 2) / 3;  // 6 patch pieces per wave, 2 per third
     constexpr unsigned kPatchB = NPP * 1024u, kUB = 32768u, kU0 = 2u * kPatchB;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
         if (p > NPP - 1) p = NPP - 1;
         const int e = 8 * p + (lane >> 3);
         const int par = e / (PH * PWH), rem = e - par * (PH * PWH), py = rem / PWH, pxh = rem - py * PWH;
-        const int px = 2 * pxh + par, slot = (lane & 7) ^ ((pxh >> 1) & 7);
+        const int px = 2 * pxh + par, slot = (lane & 7) ^ (((pxh >> 1) ^ (GEO ? 4 * ((py >> 1) & 1) : 0)) & 7);
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         const bool v = px < OW + 2 && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
         offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
@@ -395,11 +399,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
         dma16s(live ? offP[q] : kOob, ra, (unsigned)cbn * 128u, lds0 + (unsigned)(cbn & 1) * kPatchB + ldsP[q]);
     };
 
-    const int tx = li & 15, ty = 2 * wm + (li >> 4);
+    const int tx = GEO ? (li & 7) : (li & 15), ty = GEO ? 4 * wm + (li >> 3) : 2 * wm + (li >> 4);
+    // window position (i, j) of the lane's tile: entry e0 + ((j & 1) PH + i) PWH + (j >> 1), slot (2 sub + lh) ^ key; the key of GEO 1
+    // carries the row bit ((2 ty + i) >> 1) & 1 = (ty + (i >> 1)) & 1: folded in here for i < 2, flipped (address bit 6) for i >= 2
     unsigned rbase[2];
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh)
-        rbase[jh] = lds0 + (unsigned)((2 * ty) * PWH + tx) * 128u + (unsigned)((lh ^ (((tx + jh) >> 1) & 7)) << 4);
+        rbase[jh] = lds0 + (unsigned)((2 * ty) * PWH + tx) * 128u + (unsigned)((lh ^ ((((tx + jh) >> 1) ^ (GEO ? 4 * (ty & 1) : 0)) & 7)) << 4);
     const unsigned ub = lds0 + kU0 + (unsigned)(lh * 64 + wn * 32 + li) * 16u;
 
     f32x16 acc[8];
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int row = p < 4 ? rowA(i) : rowB(i), j = p & 3;
-                const f32x4n v = lds_read4(b[j >> 1] + (unsigned)((((j & 1) * PH + row) * PWH + (j >> 1)) * 128));
+                const f32x4n v = lds_read4((b[j >> 1] ^ (unsigned)((GEO && row >= 2) ? 64 : 0)) + (unsigned)((((j & 1) * PH + row) * PWH + (j >> 1)) * 128));
                 R[p][0] = v.x; R[p][1] = v.y; R[p][2] = v.z; R[p][3] = v.w;
             }
         };
@@ -527,7 +533,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
         const float bias = a.bias ? a.bias[co] : 0.0f;
         const float slope = a.slope ? a.slope[co] : 0.0f;
         const int64_t ldo = a.out.ld, ldr = a.res.ld;
-        const int oyb = oy0 + 4 * wm + 2 * kfh, oxb = ox0 + 8 * lh;        // (r >> 3 == kfh for the tiles this wave finishes)
+        // the tiles this wave finishes (accumulator elements 8 kfh + rr): GEO 0: tile row kfh of the wave's two, columns (rr & 3) + 8 ((rr >> 2) & 1)
+        // + 4 lh; GEO 1: tile rows 2 kfh + (rr >> 2) of the wave's four, columns (rr & 3) + 4 lh
+        const int oyb = oy0 + (GEO ? 8 * wm + 4 * kfh : 4 * wm + 2 * kfh), oxb = ox0 + 8 * lh;
         const int64_t mb = ((int64_t)n * ho + oyb) * wo + oxb;
         float *ob = a.out.p + mb * ldo + co;
         const float *rp = a.res_mode ? a.res.p + mb * ldr + co : nullptr;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
             if constexpr (has_res)
                 static_for<32>([&](auto E) {
                     constexpr int e = decltype(E)::value, rr = e >> 2, aa = (e >> 1) & 1, b = e & 1;
-                    constexpr int dy = aa, dx = 2 * ((rr & 3) + 8 * ((rr >> 2) & 1)) + b;
+                    constexpr int dy = GEO ? 2 * (rr >> 2) + aa : aa, dx = GEO ? 2 * (rr & 3) + b : 2 * ((rr & 3) + 8 * ((rr >> 2) & 1)) + b;
                     const int64_t eo = (int64_t)dy * wo + dx;
                     if constexpr (decltype(FULL)::value) resv[e] = rp[eo * ldr];
                     else resv[e] = (oyb + dy < ho && oxb + dx < wo) ? rp[eo * ldr] : 0.0f;
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
                 }
                 static_for<4>([&](auto P) {
                     constexpr int aa = decltype(P)::value >> 1, b = decltype(P)::value & 1;
-                    constexpr int dy = aa, dx = 2 * ((rr & 3) + 8 * ((rr >> 2) & 1)) + b;
+                    constexpr int dy = GEO ? 2 * (rr >> 2) + aa : aa, dx = GEO ? 2 * (rr & 3) + b : 2 * ((rr & 3) + 8 * ((rr >> 2) & 1)) + b;
                     float v = (aa == 0 ? (sj[0][b] + sj[1][b]) + sj[2][b] : (sj[1][b] - sj[2][b]) - sj[3][b]) + bias;
                     auto finish = [&]() {
                         const int64_t eo = (int64_t)dy * wo + dx;
@@ -602,15 +610,20 @@ bool wino_eligible(const ConvArgs &a) {
 }
 
 int launch_conv_wino(const ConvArgs &a0, hipStream_t st) {
-    constexpr int WM = 2, WN = 2, OH = 4 * WM, OW = 32;
-    constexpr size_t lds = (size_t)2 * ((2 * (OH + 2) * 18 + 7) / 8) * 1024 + (size_t)2 * 32768;
+    constexpr int WM = 2, WN = 2;
+    constexpr size_t lds = (size_t)2 * ((2 * (4 * WM + 2) * 18 + 7) / 8) * 1024 + (size_t)2 * 32768;       // (360 patch entries in either geometry)
     ConvArgs a = a0;
-    const int tiles_x = (a.out.w + OW - 1) / OW, tiles_y = (a.out.h + OH - 1) / OH;
+    // block-tile geometry of the eight-wave kernel (speed only): 32 x 8 output pixels, or 16 x 16 where that covers the map with fewer tiles
+    static const int geo_force = [] { const char *e = getenv("CSM_WINO_GEO"); return e ? atoi(e) : -1; }();
+    const int tx0 = (a.out.w + 31) / 32, ty0 = (a.out.h + 7) / 8, tx1 = (a.out.w + 15) / 16, ty1 = (a.out.h + 15) / 16;
+    static const int waves = [] { const char *e = getenv("CSM_WINO_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    const int geo = waves != 8 ? 0 : (geo_force >= 0 ? (geo_force ? 1 : 0) : (tx1 * ty1 < tx0 * ty0 ? 1 : 0));
+    const int tiles_x = geo ? tx1 : tx0, tiles_y = geo ? ty1 : ty0;
     a.m_tiles = tiles_x * tiles_y * a.out.n;
     dim3 grid(a.m_tiles, a.cout_g / 64, 1);
 #ifdef CSM_WINO_DEV        // development build: CSM_WINO_VARIANT selects an ablation / option instantiation (tools/gpu/r05b.sh)
     const char *ve = getenv("CSM_WINO_VARIANT");
-    const int variant = ve ? atoi(ve) : 0;
+    int variant = ve ? atoi(ve) : 0;
     auto go = [&](auto kern) {
         static KernelPrep prep;
         (void)prep.ensure([&] { return prepare_kernel(kern, 64 * WM * WN, lds); });
@@ -623,7 +636,9 @@ int launch_conv_wino(const ConvArgs &a0, hipStream_t st) {
         kern<<<grid, 512, lds, st>>>(a, tiles_x, tiles_y);
         return csm::check_launch("k_conv_wino8");
     };
+    if (geo && variant == 0) variant = 300;
     switch (variant) {
+        case 300: return go8(&k_conv_wino8<0, 1>);
         case 200: return go8(&k_conv_wino8<0>);
         case 201: return go8(&k_conv_wino8<1>);
         case 202: return go8(&k_conv_wino8<2>);
@@ -643,7 +658,12 @@ int launch_conv_wino(const ConvArgs &a0, hipStream_t st) {
 #endif
     // two executions of the same arithmetic (same bits): the eight-wave form (two waves per SIMD) is the default; CSM_WINO_WAVES=4 selects
     // the one-wave-per-SIMD form (A/B measurements, tests)
-    static const int waves = [] { const char *e = getenv("CSM_WINO_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    if (waves == 8 && geo) {
+        static KernelPrep prep8g;
+        (void)prep8g.ensure([&] { return prepare_kernel(&k_conv_wino8<0, 1>, 512, lds); });
+        k_conv_wino8<0, 1><<<grid, 512, lds, st>>>(a, tiles_x, tiles_y);
+        return csm::check_launch("k_conv_wino8");
+    }
     if (waves == 8) {
         static KernelPrep prep8;
         (void)prep8.ensure([&] { return prepare_kernel(&k_conv_wino8<0>, 512, lds); });
