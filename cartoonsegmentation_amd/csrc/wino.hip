@@ -602,14 +602,40 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
 namespace csmconv {
 
 bool wino_eligible(const ConvArgs &a) {
-    const int64_t bytes_in = (((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4;
+    const int64_t bytes_in = (((int64_t)a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4;           // ONE sample (a launch takes as many samples as fit 2 GiB)
     const int64_t bytes_w = (int64_t)(a.cout_g / 64) * a.ncb * 4 * 32768;
     return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil == 1 && a.pad == 1 && a.groups == 1 && a.ksplit <= 1 && (a.cin_g & 31) == 0 &&
            (a.cout_g & 63) == 0 && bytes_in < (1ll << 31) && bytes_w < (1ll << 31) && !(a.in.ld & 3) && !(((uintptr_t)a.in.p | (uintptr_t)a.w) & 15) &&
            a.out.h == a.in.h && a.out.w == a.in.w;
 }
 
+static int launch_conv_wino_chunk(const ConvArgs &a0, hipStream_t st);
+
+// The kernels address the activations through a 32-bit buffer descriptor (range-checked LDS-DMA): a launch covers as many SAMPLES as fit
+// 2 GiB of input view; larger batches are split by sample (independent work: the same bits whatever the split).  CSM_WINO_MAX_BYTES lowers
+// the limit (tests).
 int launch_conv_wino(const ConvArgs &a0, hipStream_t st) {
+    const char *le = getenv("CSM_WINO_MAX_BYTES");
+    const long long lv = le ? atoll(le) : 0;
+    const int64_t limit = lv > 0 ? (int64_t)lv : (int64_t)((1ll << 31) - 1);
+    const int64_t per_sample = (int64_t)a0.in.h * a0.in.w * a0.in.ld * 4;
+    int chunk = (int)(limit / (per_sample > 0 ? per_sample : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk >= a0.in.n) return launch_conv_wino_chunk(a0, st);
+    for (int n0 = 0; n0 < a0.in.n; n0 += chunk) {
+        ConvArgs a = a0;
+        const int nn = a0.in.n - n0 < chunk ? a0.in.n - n0 : chunk;
+        a.in.n = a.out.n = nn; a.in.p = a0.in.p + (int64_t)n0 * a0.in.h * a0.in.w * a0.in.ld;
+        a.out.p = a0.out.p + (int64_t)n0 * a0.out.h * a0.out.w * a0.out.ld;
+        if (a0.res_mode) { a.res.n = nn; a.res.p = a0.res.p + (int64_t)n0 * a0.res.h * a0.res.w * a0.res.ld; }
+        a.M = nn * a.out.h * a.out.w;
+        const int rc = launch_conv_wino_chunk(a, st);
+        if (rc) return rc;
+    }
+    return CSM_OK;
+}
+
+static int launch_conv_wino_chunk(const ConvArgs &a0, hipStream_t st) {
     constexpr int WM = 2, WN = 2;
     constexpr size_t lds = (size_t)2 * ((2 * (4 * WM + 2) * 18 + 7) / 8) * 1024 + (size_t)2 * 32768;       // (360 patch entries in either geometry)
     ConvArgs a = a0;

@@ -149,3 +149,39 @@ def test_nets_with_winograd_layers_hip_equals_oracle():
             assert np.array_equal(yd.cpu().numpy(), yo), (name, wino)
             res[wino] = yo
         assert np.abs(res[True] - res[False]).max() <= 2e-4 * max(1e-3, np.abs(res[False]).max()), name
+
+
+def test_batches_beyond_the_descriptor_range_are_split_by_sample():
+    """the kernels reach the activations through a 32-bit range-checked buffer descriptor: a launch takes as many samples as fit 2 GiB of
+    input view and larger batches are split by sample.  Exercised with a lowered limit (CSM_WINO_MAX_BYTES): 5 samples in chunks of 2 / 1
+    give the bits of the single launch, with a residual and channel-slice output"""
+    from cartoonsegmentation_amd.runtime import CompiledProgram
+    rng = np.random.default_rng(31)
+    n, h, w, cin, cout = 5, 26, 40, 64, 64
+    with _forced(True):
+        p = P.Program("chunks")
+        x_ext = p.ext_nchw(n, cin, h, w); r_ext = p.ext_nchw(n, cout, h, w); y_ext = p.ext_nchw(n, 128, h, w)
+        x = p.to_nhwc(x_ext); r = p.to_nhwc(r_ext)
+        cat = p.buffer(n, h, w, 128)
+        p.conv(x, (rng.standard_normal((cout, cin, 3, 3)) / 24).astype(np.float32), rng.standard_normal(cout).astype(np.float32), pad=1,
+               act='relu', res=r, res_mode=2, out=cat.slice(64, 128))
+        p.conv(x, (rng.standard_normal((64, cin, 1, 1)) / 8).astype(np.float32), None, out=cat.slice(0, 64))
+        p.to_nchw(cat, y_ext)
+    xs = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32)).cuda()
+    rs = torch.from_numpy(rng.standard_normal((n, cout, h, w)).astype(np.float32)).cuda()
+    cp = CompiledProgram(p, 'cuda')
+    outs = []
+    per_sample = h * w * cin * 4
+    try:
+        for limit in (None, 2 * per_sample + 100, per_sample):
+            if limit is None:
+                os.environ.pop("CSM_WINO_MAX_BYTES", None)
+            else:
+                os.environ["CSM_WINO_MAX_BYTES"] = str(limit)
+            y = torch.full((n, 128, h, w), float('nan'), device='cuda')
+            cp.run(xs, rs, y)
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        os.environ.pop("CSM_WINO_MAX_BYTES", None)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

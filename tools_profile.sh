@@ -26,8 +26,8 @@ $RP -d $OUT/stats -o frame -- python /root/repo/bench.py --steps 6 --warmup 2 --
 CSM_OVERLAP_DEPTH=0 $RP -d $OUT/stats_serial -o frame -- python /root/repo/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-variants --no-roofline > $OUT/stats_serial.log 2>&1
 $RP -d $OUT/stats_warp -o warp -- python /root/repo/bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_warp.log 2>&1
 CSM_WARP_PATH=atomics $RP -d $OUT/stats_warp_atomics -o warp -- python /root/repo/bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_warp_atomics.log 2>&1
-$RP -d $OUT/stats_video -o video -- python /root/repo/tools/video_breakdown.py > $OUT/stats_video.log 2>&1
-$RP -d $OUT/stats_autozoom -o az -- python /root/repo/tools/time_autozoom.py 1024 > $OUT/stats_autozoom.log 2>&1
+[ "$2" = "full" ] && $RP -d $OUT/stats_video -o video -- python /root/repo/tools/video_breakdown.py > $OUT/stats_video.log 2>&1
+[ "$2" = "full" ] && $RP -d $OUT/stats_autozoom -o az -- python /root/repo/tools/time_autozoom.py 1024 > $OUT/stats_autozoom.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o frame -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-roofline > $OUT/pmc_$C.log 2>&1
   timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmcw_$C -o warp -- python /root/repo/bench.py --workload warp --steps 20 --warmup 2 --no-cpu-baseline > $OUT/pmcw_$C.log 2>&1
@@ -72,5 +72,6 @@ json.dump(traffic, open("$OUT/traffic.json","w"), indent=1)
 for k,v in sorted(tr.items(), key=lambda kv:-kv[1].get("fetch_KB",0))[:16]: print(k, v)
 PY
 # pipe-utilisation counters (SQ / LDS / L2) of the kernels that carry the conv time + the warp render pass: one table
-bash /root/repo/tools/gpu/r04b.sh > $OUT/pmc_sq.log 2>&1; python /root/repo/tools/pmc_table.py /root/repo/gpurun_out/r04b/summary.txt > $OUT/conv_pmc.txt 2>&1; cat $OUT/conv_pmc.txt
+# (round 5: the Winograd layers k_conv_wino8 + two direct layers + the warp render pass; tools/gpu/r05_pmc.sh)
+bash /root/repo/tools/gpu/r05_pmc.sh > $OUT/pmc_sq.log 2>&1; python /root/repo/tools/pmc_table.py /root/repo/gpurun_out/r05pmc/summary.txt > $OUT/conv_pmc.txt 2>&1; cat $OUT/conv_pmc.txt
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +1M -delete; find $OUT -name "*agent_info.csv" -delete
