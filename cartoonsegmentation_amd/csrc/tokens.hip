@@ -6,6 +6,7 @@
 // The attention kernel streams the keys with a running max / sum (no N x N matrix): see k_attention.
 #include "csm_common.h"
 #include "csm_tokens.h"
+#include <mutex>
 #include <utility>
 
 namespace {
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     int Ci = 0, yi = 0, xi = 0;
     if (tab && qi >= 1) { yi = (qi - 1) / gw; xi = (qi - 1) - yi * gw; Ci = yi * (2 * gw - 1) + xi + (gh - 1) * (2 * gw - 1) + gw - 1; }
     // bias window of this wave (see above)
-    const int W2 = 2 * gw - 1, R = 31 / gw + 2, WN = (2 * R - 1) * W2, yq0 = q0 >= 1 ? (q0 - 1) / gw : 0;
+    const int gwd = tab ? gw : 1;                                      // (no table: gh = gw = 0 -- the index arithmetic below is unused, keep it defined)
+    const int W2 = 2 * gw - 1, R = 31 / gwd + 2, WN = (2 * R - 1) * W2, yq0 = q0 >= 1 ? (q0 - 1) / gwd : 0;
     constexpr bool win = WIN;                                          // (the launcher: WIN <=> table && wcap > 0)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     float *wbuf = lds + 4 * TILE + 64 + wave_u * wcap;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         b_cp = tab[T - 3]; b_pc = tab[T - 2]; b_cc = tab[T - 1];
     }
     auto fetch_window = [&](int tl) __attribute__((always_inline)) {   // the window of key tile tl -> wbuf (asynchronous: vmcnt)
-        const int j0 = tl * 32, yk0 = j0 >= 1 ? (j0 - 1) / gw : 0;
+        const int j0 = tl * 32, yk0 = j0 >= 1 ? (j0 - 1) / gwd : 0;
         const int g0 = (yq0 - yk0 - R + gh) * W2;
         for (int u = 0; u * 64 < wcap; ++u) {
             const int e = u * 64 + lane;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int tile = kh * half + it;
         if (tile >= NT) continue;                                       // (odd tile counts: the second half has one tile fewer)
         const float *Kt = lds + 2 * kh * TILE, *Vt = Kt + TILE;
-        const int yk0 = tile >= 1 ? (tile * 32 - 1) / gw : 0;
+        const int yk0 = tile >= 1 ? (tile * 32 - 1) / gwd : 0;
         const int wbase = (yi - yq0 + yk0 + R - 1) * W2 + xi + gw - 1;  // window index of (this query, key) = wbase - kterm(key)
         // ---- s^T = K q^T
         f32x16 sacc;
@@ -236,11 +238,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const float m_new = fmaxf(m_run, mt);
         // p = 2^((s - m) log2 e) on the raw v_exp_f32 (arguments <= 0: a result below 2^-126 is 0 either way at the tolerance of this op);
         // a padded key's score is -3e38: its p is exactly 0 without a test
-        const float ms = m_new * 1.44269504088896341f;
+        // ((s - m) log2 e with the subtraction FIRST: the two products rounded separately lose |s| 6e-8 1.44 absolute -- fine for logits
+        // of a few units, 1e-3 relative for logits in the thousands, and p could exceed 1)
         float lt = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(sacc[r] * 1.44269504088896341f - ms);
+            const float pv = __builtin_amdgcn_exp2f((sacc[r] - m_new) * 1.44269504088896341f);
             sacc[r] = pv;
             lt += pv;
         }
@@ -369,11 +372,25 @@ template <int D> static int launch_attention_t(const float *qkv, int ld, float *
     if (fl < (size_t)kExchange) fl = kExchange;
     const size_t lds = sizeof(float) * fl;
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)heads, (unsigned)n);
+    // the dynamic-LDS limit is raised when a launch needs more than the kernel was last prepared for (per device; checked: an
+    // oversized request used to surface only as a generic launch error)
+    auto prepare = [&](const void *fn, size_t &have) -> int {
+        if (lds <= have) return CSM_OK;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("attention: %zu bytes of LDS requested: %s", lds, hipGetErrorString(e)); return CSM_ERR_HIP; }
+        have = lds;
+        return CSM_OK;
+    };
+    static std::mutex prep_mutex;
+    static size_t have_w[32] = {}, have_g[32] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 31;
     if (wcap > 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attention<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        { std::lock_guard<std::mutex> lk(prep_mutex); int rc = prepare(reinterpret_cast<const void *>(&k_attention<D, true>), have_w[dev]); if (rc) return rc; }
         k_attention<D, true><<<grid, 256, lds, st>>>(qkv, ld, out, out_ld, N, heads, table, gh, gw, wcap);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attention<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        { std::lock_guard<std::mutex> lk(prep_mutex); int rc = prepare(reinterpret_cast<const void *>(&k_attention<D, false>), have_g[dev]); if (rc) return rc; }
         k_attention<D, false><<<grid, 256, lds, st>>>(qkv, ld, out, out_ld, N, heads, table, gh, gw, 0);
     }
     return check_launch("k_attention");
@@ -383,6 +400,7 @@ int launch_attention(const float *qkv, int ld, float *out, int out_ld, int n, in
                      hipStream_t st) {
     if (N < 1) { set_error("attention: empty sequence"); return CSM_ERR_ARG; }
     if ((ld & 3) || (out_ld & 3) || (((uintptr_t)qkv | (uintptr_t)out) & 15)) { set_error("attention: qkv / out must be 16-byte aligned"); return CSM_ERR_ARG; }
+    if (table && (gh < 1 || gw < 1)) { set_error("attention: relative position bias needs a token grid (gh, gw >= 1), got %d x %d", gh, gw); return CSM_ERR_ARG; }
     if (table && gh * gw + 1 != N) { set_error("attention: relative position bias needs N == gh * gw + 1 (%d x %d vs %d)", gh, gw, N); return CSM_ERR_ARG; }
     switch (d) {
         case 32: return launch_attention_t<32>(qkv, ld, out, out_ld, n, N, heads, table, gh, gw, st);

@@ -375,6 +375,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
         ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
         rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
     }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned voffU = (unsigned)lane * 16u;
+    unsigned u_src = (unsigned)(ntile * nsteps) * kUB + (unsigned)(wave * UPW) * 1024u;
+    const unsigned ldsU = lds0 + kU0 + (unsigned)(wave * UPW) * 1024u;
+    auto issue_u1 = [&](int par, int k, bool live) {
+        dma16s(live ? voffU : kOob, rb, u_src + (unsigned)k * 1024u, ldsU + (unsigned)par * kUB + (unsigned)k * 1024u);
+    };
+    // the first two U stages go out before anything else is computed: their addresses are scalar, and the round trip runs under the
+    // set-up of the patch offsets and the zeroing of the accumulators (the prologue of a 64-channel tile is a tenth of its life)
+#pragma unroll
+    for (int k = 0; k < UPW; ++k) issue_u1(0, k, true);
+    u_src += kUB;
+#pragma unroll
+    for (int k = 0; k < UPW; ++k) issue_u1(1, k, nsteps > 1);
+    u_src += kUB;
     unsigned offP[QP], ldsP[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
@@ -388,16 +403,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
         offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
         ldsP[q] = (unsigned)p * 1024u;
     }
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
-    const unsigned voffU = (unsigned)lane * 16u;
-    unsigned u_src = (unsigned)(ntile * nsteps) * kUB + (unsigned)(wave * UPW) * 1024u;
-    const unsigned ldsU = lds0 + kU0 + (unsigned)(wave * UPW) * 1024u;
-    auto issue_u1 = [&](int par, int k, bool live) {
-        dma16s(live ? voffU : kOob, rb, u_src + (unsigned)k * 1024u, ldsU + (unsigned)par * kUB + (unsigned)k * 1024u);
-    };
     auto issue_patch1 = [&](int cbn, int q, bool live) {
         dma16s(live ? offP[q] : kOob, ra, (unsigned)cbn * 128u, lds0 + (unsigned)(cbn & 1) * kPatchB + ldsP[q]);
     };
+#pragma unroll
+    for (int q = 0; q < QP; ++q) issue_patch1(0, q, true);
+#pragma unroll
+    for (int q = 0; q < QG; ++q) issue_patch1(1, q, ncb > 1);
 
     const int tx = GEO ? (li & 7) : (li & 15), ty = GEO ? 4 * wm + (li >> 3) : 2 * wm + (li >> 4);
     // window position (i, j) of the lane's tile: entry e0 + ((j & 1) PH + i) PWH + (j >> 1), slot (2 sub + lh) ^ key; the key of GEO 1
@@ -491,17 +503,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino8(ConvArgs a, int tiles_x, 
             });
         };
 
-        // prologue: patch 0, U 0, U 1, the first third of patch 1; then the operands of group 0 of step 0 and the window rows of its group 1
-#pragma unroll
-        for (int q = 0; q < QP; ++q) issue_patch1(0, q, true);
-#pragma unroll
-        for (int k = 0; k < UPW; ++k) issue_u1(0, k, true);
-        u_src += kUB;
-#pragma unroll
-        for (int k = 0; k < UPW; ++k) issue_u1(1, k, nsteps > 1);
-        u_src += kUB;
-#pragma unroll
-        for (int q = 0; q < QG; ++q) issue_patch1(1, q, ncb > 1);
+        // prologue (U 0, U 1, patch 0 and the first third of patch 1 are in flight): the operands of group 0 of step 0, the window rows of its group 1
         wait_barrier<0>();
         read_b(ic<0>{}, 0);
         read_raw(ic<0>{}, 0, 0);

@@ -43,9 +43,31 @@ class FrameLanes:
         elif isinstance(res, dict):
             for v in res.values():
                 FrameLanes._record(v, stream)
-        elif isinstance(res, (list, tuple)):
+        elif isinstance(res, (list, tuple, set, frozenset)):
             for v in res:
                 FrameLanes._record(v, stream)
+        elif hasattr(res, '__dict__') or hasattr(res, '__slots__'):
+            # an object that HOLDS tensors (a dataclass, an AnimeInstances, a KenBurnsConfig): walk its attributes once -- a worker that
+            # returns such an object would otherwise keep the cross-stream allocator hazard silently
+            seen = getattr(FrameLanes._record, '_seen', None)
+            top = seen is None
+            if top:
+                seen = FrameLanes._record._seen = set()
+            try:
+                if id(res) in seen:
+                    return
+                seen.add(id(res))
+                names = list(getattr(res, '__dict__', {}).keys()) + [n for n in getattr(type(res), '__slots__', ()) if isinstance(n, str)]
+                for n in names:
+                    try:
+                        v = getattr(res, n)
+                    except AttributeError:
+                        continue
+                    if isinstance(v, (torch.Tensor, dict, list, tuple, set, frozenset)) or hasattr(v, '__dict__'):
+                        FrameLanes._record(v, stream)
+            finally:
+                if top:
+                    FrameLanes._record._seen = None
 
     def _run(self, i):
         torch.cuda.set_device(self.device)
