@@ -185,3 +185,31 @@ def test_batches_beyond_the_descriptor_range_are_split_by_sample():
     finally:
         os.environ.pop("CSM_WINO_MAX_BYTES", None)
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_winograd_random_shapes_bit_exact(seed):
+    """seeded random layers: any sample count / map size (down to 1 x 1: a single half-outside tile) / channel-block count / column-tile
+    count / activation / residual mode, both block-tile geometries decided by the launcher"""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 4))
+    h, w = (1, 1) if seed == 0 else ((2, 67) if seed == 1 else (int(rng.integers(1, 72)), int(rng.integers(1, 72))))
+    cin, cout = int(rng.choice([32, 64, 96, 160])), int(rng.choice([64, 128, 192]))
+    act = [None, 'relu', 'silu', 'prelu', 'sigmoid', 'hsigmoid'][int(rng.integers(0, 6))]
+    res_mode = int(rng.integers(0, 3))
+    with _forced(True):
+        p = P.Program("rnd")
+        x_ext = p.ext_nchw(n, cin, h, w)
+        y_ext = p.ext_nchw(n, cout, h, w)
+        x = p.to_nhwc(x_ext)
+        wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.1).astype(np.float32) if rng.integers(0, 2) else None
+        slope = rng.uniform(0.05, 0.3, cout).astype(np.float32) if act == 'prelu' else None
+        res = p.to_nhwc(p.ext_nchw(n, cout, h, w)) if res_mode else None
+        p.to_nchw(p.conv(x, wt, b, pad=1, act=act, slope=slope, res=res, res_mode=res_mode), y_ext)
+    assert [o['flags'] & P.CONV_FLAG_WINOGRAD for o in p.ops if o['kind'] == P.OP_CONV] == [P.CONV_FLAG_WINOGRAD]
+    ext_in = [rng.standard_normal((n, cin, h, w)).astype(np.float32)]
+    if res_mode:
+        ext_in.append(rng.standard_normal((n, cout, h, w)).astype(np.float32))
+    (yo,), (yd,) = _run_both(p, ext_in, [(n, cout, h, w)])
+    assert np.isfinite(yd).all() and np.array_equal(yd, yo), (n, h, w, cin, cout, act, res_mode)

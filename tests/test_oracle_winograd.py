@@ -35,6 +35,8 @@ def _layer(wino, n, h, w, cin, cout, act='relu', res_mode=0, seed=1):
     (2, 13, 37, 64, 64, 'silu', 2),            # odd height and width: the last tile row / column is half outside
     (1, 45, 45, 96, 128, 'relu', 1),
     (1, 7, 5, 256, 64, 'relu', 0),             # a map smaller than one block tile
+    (2, 1, 1, 32, 64, 'relu', 0),              # one pixel: a single Winograd tile, three quarters of it outside
+    (1, 2, 67, 64, 128, None, 0),
 ])
 def test_winograd_oracle_equals_direct_oracle_to_rounding(n, h, w, cin, cout, act, res_mode):
     """the two arithmetics compute the same convolution: they differ by fp32 rounding only (transform constants 0, +-1, +-1/2)"""
