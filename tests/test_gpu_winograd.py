@@ -213,3 +213,18 @@ def test_winograd_random_shapes_bit_exact(seed):
         ext_in.append(rng.standard_normal((n, cout, h, w)).astype(np.float32))
     (yo,), (yd,) = _run_both(p, ext_in, [(n, cout, h, w)])
     assert np.isfinite(yd).all() and np.array_equal(yd, yo), (n, h, w, cin, cout, act, res_mode)
+
+
+@pytest.mark.parametrize("env", [{"CSM_WINO_WAVES": "4"}, {"CSM_WINO_GEO": "1"}, {"CSM_WINO_GEO": "0"}],
+                         ids=["four_wave_form", "geometry_16x16_forced", "geometry_32x8_forced"])
+def test_every_kernel_form_gives_the_oracles_bits(env):
+    """the launcher's choices are speed only: the one-wave-per-SIMD form (k_conv_wino) and each block-tile geometry of k_conv_wino8, forced
+    through their environment switches (read once per process, hence a subprocess), pass the single-layer and slice tests above bit for bit"""
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "winograd_conv_bit_exact or channel_slices or random_shapes"], env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
