@@ -688,11 +688,11 @@ extern "C" int csm_warp_tile_supported(int H, int W) { return H > 0 && W > 0 && 
 // ---- K frames of one cloud in ONE call: frame k + 1's binning and frame k - 1's hole fill run under frame k's render ------------------
 // The three kernels of a frame are a dependent chain (bin 12 us -> render 35 us -> holes 11 us at 1024^2) and each leaves most of the
 // chip idle part of the time (binning is atomic-latency bound, the hole fill walks bitmaps): one frame in isolation runs at 0.34 of the
-// HBM roof.  Frames of a video are independent, so the call deals them round-robin onto `lanes` internal streams (lane 0 = the
-// caller's stream), each with its own scratch, forked from and joined to the caller's stream with events: the caller sees one
+// HBM roof.  Frames of a video are independent, so the call deals them round-robin onto `lanes` internal streams, each with its own
+// scratch, forked from and joined to the caller's stream with events: the caller sees one
 // asynchronous call on one stream, the GPU sees up to three chains in different phases (0.5 of the roof, profiles/).
 namespace {
-struct LaneSet { hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}; bool ready = false; };
+struct LaneSet { hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr}; bool ready = false; };
 LaneSet g_lanes[32];
 std::mutex g_lanes_mutex;
 int get_lanes(LaneSet *&ls) {
@@ -701,7 +701,7 @@ int get_lanes(LaneSet *&ls) {
     std::lock_guard<std::mutex> lk(g_lanes_mutex);
     ls = &g_lanes[d & 31];
     if (!ls->ready) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             CSM_HIP(hipStreamCreateWithFlags(&ls->aux[i], hipStreamNonBlocking));
             CSM_HIP(hipEventCreateWithFlags(&ls->join[i], hipEventDisableTiming));
         }
@@ -734,21 +734,23 @@ extern "C" int csm_warp_frames_tiled(const float *pts, const float *rgb, const f
         int rc = get_lanes(ls); if (rc) return rc;
         // the lane streams are shared by every caller on this device: one multi-frame call at a time forks from / joins to its own stream
         lk.lock();
+        // every lane is an internal stream; the caller's stream only forks and joins (frames issued on the caller's stream itself -- the
+        // NULL stream in a plain torch program -- overlapped worse: 47.6 us per frame against 39 for three side streams)
         CSM_HIP(hipEventRecord(ls->fork, main));
-        for (int i = 1; i < nl; ++i) CSM_HIP(hipStreamWaitEvent(ls->aux[i - 1], ls->fork, 0));
+        for (int i = 0; i < nl; ++i) CSM_HIP(hipStreamWaitEvent(ls->aux[i], ls->fork, 0));
     }
     int rc = CSM_OK;
     for (int k = 0; k < K && rc == CSM_OK; ++k) {
         const int lane = k % nl;
-        hipStream_t st = lane == 0 ? main : ls->aux[lane - 1];
+        hipStream_t st = nl == 1 ? main : ls->aux[lane];
         rc = csm_warp_frame_tiled(pts, rgb, depth, N, H, W, focal, baseline, shifts_host[3 * k], shifts_host[3 * k + 1], shifts_host[3 * k + 2],
                                   (char *)scratch + (size_t)lane * one, render_filled ? render_filled + (size_t)k * render_floats : nullptr,
                                   frames_u8 + (size_t)k * frame_bytes, (void *)st);
     }
     if (nl > 1) {
-        for (int i = 1; i < nl; ++i) {
-            hipError_t e = hipEventRecord(ls->join[i - 1], ls->aux[i - 1]);
-            if (e == hipSuccess) e = hipStreamWaitEvent(main, ls->join[i - 1], 0);
+        for (int i = 0; i < nl; ++i) {
+            hipError_t e = hipEventRecord(ls->join[i], ls->aux[i]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(main, ls->join[i], 0);
             if (e != hipSuccess && rc == CSM_OK) { csm::set_error("csm_warp_frames_tiled join: %s", hipGetErrorString(e)); rc = CSM_ERR_HIP; }
         }
     }

@@ -126,7 +126,7 @@ int csm_warp_frame_tiled(const float *pts, const float *rgb, const float *depth,
                          void *stream);
 
 /* K frames of ONE cloud under K camera shifts (the frame loop of KenBurnsPipeline.process_kenburns, kenburns_effect.py:1027-1040) in one
- * asynchronous call on `stream`: the frames are dealt round-robin onto `lanes` (1..3) internal streams (lane 0 = `stream`) with one scratch
+ * asynchronous call on `stream`: the frames are dealt round-robin onto `lanes` (1..3) internal streams (lanes = 1: `stream` itself) with one scratch
  * each, forked from and joined to `stream` by events, so that frame k + 1's binning and frame k - 1's hole fill run under frame k's
  * render.  Every frame is bit-identical to csm_warp_frame_tiled with the same arguments.
  * shifts_host: K x (sx, sy, sz) HOST floats (read before the call returns); scratch: csm_warp_frames_scratch_bytes(H, W, N, lanes) device
