@@ -739,7 +739,9 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # CSM_BENCH_FORCE_DIST=1: take the process-group path with ONE rank as well (a 1-GPU box then runs the whole multi-rank start-up --
+    # init_process_group("nccl", device_id=...), the tile-table / weight broadcasts, the all-reduces and the asynchronous gather -- on RCCL itself)
+    if world > 1 or os.environ.get("CSM_BENCH_FORCE_DIST", "0") not in ("", "0"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -827,7 +829,8 @@ def main():
                                  "frames_per_s_4_in_flight": out["variants"].get("batch1_lanes4", {}).get("frames_per_s"),
                                  "what": "BASELINE configs[1..2] literally: ONE 1024x1024 frame per step (seg + depth + warp), serial loop; "
                                          "*_in_flight: the same single-frame steps with 3 / 4 frames in flight (FrameLanes)"}
-        if world > 1:
+        if dist is not None:
+            out["process_group"] = {"backend": dist.get_backend(), "world_size": world}
             out["gather"] = wl.check_gathered()
             out["weights_broadcast_bytes"] = bcast_bytes
             out["weights_equal_after_broadcast"] = weights_equal

@@ -341,6 +341,29 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert g["records_ok"] is True and g["masks_in_first_frames"] >= 2 and g["record_bytes"] == 320 * 320 * 3 + 2 * (320 * 320 // 8) + 8
 
 
+def test_bench_process_group_path_on_rccl_with_one_rank():
+    """the same start-up with the measured backend: ONE rank (this box has one GPU) launched by torch.distributed.run with
+    CSM_BENCH_FORCE_DIST=1, so init_process_group("nccl", device_id=...), broadcast_object_list, the weight broadcasts, the MAX / MIN
+    all-reduces, the asynchronous gather on the communicator's stream and destroy_process_group all execute on RCCL (what a 1-GPU box
+    can show of SURVEY 8e; the 2-rank logic is the gloo test above)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CSM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", CSM_SYNTHETIC_WEIGHTS="1",
+               CSM_BENCH_WATCHDOG="500", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CSM_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "2", "--size", "320", "--steps", "2",
+           "--warmup", "1", "--no-variants", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert d["process_group"] == {"backend": "nccl", "world_size": 1} and d["n_gpus"] == 1
+    assert d["weights_broadcast_bytes"] > 1e8 and d["weights_equal_after_broadcast"] is True
+    assert d["gather"]["records_ok"] is True and d["value"] > 0
+
+
 def test_default_depth_estimator_pipeline():
     """depth_est='default' + default_depth_refine (the commented 'original 3dkenburns' block of configs/3dkenburns.yaml):
     VGG19-BN semantics + Disparity GridNet at <= 512, depth adjustment through the resize branch, Refine back to the frame size"""
