@@ -85,7 +85,9 @@ struct KernelPrep {
     }
 };
 template <class K> static int prepare_kernel(K kernel, int threads, size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)            // the launch that follows fails and is reported by its own check; say WHY here (once per kernel and device)
+        fprintf(stderr, "csm355: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed: %s\n", lds, hipGetErrorString(e));
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), threads, lds) != hipSuccess) nb = 0;
     return nb;
