@@ -373,14 +373,18 @@ __global__ __launch_bounds__(kBlock) void k_median(const float *__restrict__ in,
         }
     }
     // rank of each element (ties broken by index) -> the element of rank (NV - 1) / 2 is the lower median
+    // a NaN anywhere in the window gives NaN, as torch.median does (every comparison with a NaN is false: the ranks would all tie)
     float med = v[0];
+    bool any_nan = false;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int rank = 0;
+        any_nan |= v[i] != v[i];
 #pragma unroll
         for (int j = 0; j < NV; ++j) rank += (v[j] < v[i] || (v[j] == v[i] && j < i)) ? 1 : 0;
         if (rank == (NV - 1) / 2) med = v[i];
     }
+    if (any_nan) med = __int_as_float(0x7fc00000);
     out[((int64_t)blockIdx.z * H + y) * W + x] = med;
 }
 

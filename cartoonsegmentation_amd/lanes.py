@@ -34,40 +34,38 @@ class FrameLanes:
         self._ready.wait()
 
     @staticmethod
-    def _record(res, stream):
+    def _record(res, stream, seen=None):
         """results are allocated on the lane's stream and consumed on the caller's: tell the caching allocator, so that a block the
-        caller drops is not handed back to the lane while the caller's stream still has kernels reading it"""
+        caller drops is not handed back to the lane while the caller's stream still has kernels reading it.  `seen` is the cycle guard
+        of ONE top-level call (an argument, not shared state: several lane threads hand results over at the same time)"""
+        if seen is None:
+            seen = set()
         if isinstance(res, torch.Tensor):
             if res.is_cuda:
                 res.record_stream(stream)
         elif isinstance(res, dict):
             for v in res.values():
-                FrameLanes._record(v, stream)
+                FrameLanes._record(v, stream, seen)
         elif isinstance(res, (list, tuple, set, frozenset)):
             for v in res:
-                FrameLanes._record(v, stream)
+                FrameLanes._record(v, stream, seen)
         elif hasattr(res, '__dict__') or hasattr(res, '__slots__'):
             # an object that HOLDS tensors (a dataclass, an AnimeInstances, a KenBurnsConfig): walk its attributes once -- a worker that
             # returns such an object would otherwise keep the cross-stream allocator hazard silently (ADVICE r04)
-            seen = getattr(FrameLanes._record, '_seen', None)
-            top = seen is None
-            if top:
-                seen = FrameLanes._record._seen = set()
-            try:
-                if id(res) in seen:
-                    return
-                seen.add(id(res))
-                names = list(getattr(res, '__dict__', {}).keys()) + [n for n in getattr(type(res), '__slots__', ()) if isinstance(n, str)]
-                for n in names:
-                    try:
-                        v = getattr(res, n)
-                    except AttributeError:
-                        continue
-                    if isinstance(v, (torch.Tensor, dict, list, tuple, set, frozenset)) or hasattr(v, '__dict__'):
-                        FrameLanes._record(v, stream)
-            finally:
-                if top:
-                    FrameLanes._record._seen = None
+            if id(res) in seen:
+                return
+            seen.add(id(res))
+            names = list(getattr(res, '__dict__', {}).keys())
+            for klass in type(res).__mro__:                # inherited __slots__ as well
+                sl = klass.__dict__.get('__slots__', ())
+                names += [n for n in ((sl,) if isinstance(sl, str) else sl) if isinstance(n, str)]
+            for n in names:
+                try:
+                    v = getattr(res, n)
+                except AttributeError:
+                    continue
+                if isinstance(v, (torch.Tensor, dict, list, tuple, set, frozenset)) or hasattr(v, '__dict__') or hasattr(v, '__slots__'):
+                    FrameLanes._record(v, stream, seen)
 
     def _run(self, i):
         torch.cuda.set_device(self.device)

@@ -379,14 +379,25 @@ class WarpFrame:
         for s in shifts:
             flat.extend(float(v.value) for v in _f32x3(s))
         arr = (ctypes.c_float * (3 * max(K, 1)))(*flat)
+        st = stream_ptr() if stream is None else stream
         if getattr(self, '_multi_key', None) is None or self._multi_key[0] < N or self._multi_key[1] != lanes:
             cap = int(N * 1.25) + 1024                         # (the point cloud grows when inpainting appends points)
             nbytes = L.csm_warp_frames_scratch_bytes(i32(self.H), i32(self.W), i64(cap), i32(lanes))
             self._multi = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=self.device)     # (headers must start at zero)
             self._multi_key = (cap, lanes)
+            self._multi_n = N
+        elif self._multi_n != N:
+            # the library carves lane i at i * round256(csm_warp_tile_scratch_bytes(H, W, N)) with the CURRENT N: when N changes, the
+            # headers of lanes 1.. fall into bytes the previous call used as depth / entry storage, and the tile protocol needs every
+            # header zero on entry -> clear the buffer on the stream the call runs on
+            if stream is None:
+                self._multi.zero_()
+            else:
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream.value or 0), device=self.device)):
+                    self._multi.zero_()
+            self._multi_n = N
         if out is None:
             out = torch.empty((K, self.H, self.W, 3), dtype=torch.uint8, device=self.device)
-        st = stream_ptr() if stream is None else stream
         check(L.csm_warp_frames_tiled(ptr(tenPoints), ptr(tenImage), ptr(tenDepth), i64(N), i32(self.H), i32(self.W), f64(fltFocal),
                                       f64(fltBaseline), arr, i32(K), i32(lanes), ptr(self._multi), ptr(None), ptr(out), st), "warp_frames_tiled")
         return out

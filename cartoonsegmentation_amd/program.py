@@ -112,9 +112,14 @@ WINO_MIN_PIXELS = int(os.environ.get('CSM_WINO_MIN_PIXELS', '6400'))
 WINO_BN = 64
 
 
-def wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo):
+def wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=None):
+    """ld = channel pitch of the input view (None: cin_g).  The byte bounds mirror csrc/wino.hip::wino_eligible (32-bit buffer
+    descriptors: one sample's input view and the U panel under 2 GiB, pitch % 4 == 0); they depend on the shape only, so a layer
+    beyond them lowers to the direct chain instead of failing at run time"""
+    ld = cin_g if ld is None else ld
     return (kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and groups == 1 and cin_g % 32 == 0 and cout % WINO_BN == 0
-            and ho * wo >= WINO_MIN_PIXELS)
+            and ho * wo >= WINO_MIN_PIXELS and ld % 4 == 0 and ((ho * wo - 1) * ld + cin_g) * 4 < 2 ** 31
+            and (cout // WINO_BN) * (cin_g // 32) * 4 * 32768 < 2 ** 31)
 
 
 def wino_transform(w):
@@ -248,7 +253,7 @@ class Program:
             out = self.buffer(x.n, ho, wo, cout)
         assert out.shape == (x.n, ho, wo, cout), (out.shape, (x.n, ho, wo, cout))
         stem = groups == 1 and cin_g == 4 and cout > 4        # k_conv_stem: (tap, channel)-packed K, csm_op.flags bit 1
-        wino = self.winograd and wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo)
+        wino = self.winograd and wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c)
         if stem:
             packed, sg, cin_sg, cout_sg = pack_stem_weights(w), 1, 4, cout
         elif wino:

@@ -79,7 +79,8 @@ int csm_fill_disocclusion(const float *in, const float *depth, float *out, int B
 /* spatial_filter(x,'laplacian')   models/utils.py:12-24 ; x,out [BC,H,W] */
 int csm_spatial_filter_laplacian(const float *in, float *out, int BC, int H, int W, void *stream);
 
-/* spatial_filter(x,'median-5')   models/utils.py:32-36 (reflect pad, lower median of 25) ; x,out [BC,H,W] */
+/* spatial_filter(x,'median-5')   models/utils.py:32-36 (reflect pad, lower median of 25) ; x,out [BC,H,W]
+ * A window that contains a NaN yields NaN (torch.median's rule); the same holds for median-3. */
 int csm_spatial_filter_median5(const float *in, float *out, int BC, int H, int W, void *stream);
 
 /* spatial_filter(x,'median-3')   models/utils.py:26-30 (reflect pad 1, lower median of 9) ; x,out [BC,H,W] */

@@ -314,3 +314,24 @@ def test_multi_frame_call_is_bitwise_the_per_frame_calls(ops):
         assert wm.frames(pts, rgb, dep, sc['focal'], sc['baseline'], [], lanes=lanes).shape[0] == 0
         one = wm.frames(pts, rgb, dep, sc['focal'], sc['baseline'], shifts[2:3], lanes=lanes)
         assert torch.equal(one[0], ref[2])
+
+
+def test_multi_frame_call_after_the_cloud_changed_size(ops):
+    """WarpFrame.frames() keeps its multi-lane scratch for any N up to the capacity, and the library carves the lanes by the CURRENT N:
+    after N changes (inpainting appends points) the headers of lanes 1.. lie in bytes the previous call used as storage and must be
+    cleared.  N1 -> N2 < N1 -> N1 on one WarpFrame, each bitwise equal to per-frame calls"""
+    from cartoonsegmentation_amd import synth
+    H, W = 208, 272
+    sc = synth.warp_scene(H, W, 5)
+    disp = dev(sc['disp']); disp = disp / disp.max() * sc['baseline']
+    depth, _, pts, _ = ops.disparity_to_points(disp, sc['focal'], sc['baseline'])
+    pts, dep, rgb = pts.view(1, 3, -1).contiguous(), depth.view(1, 1, -1).contiguous(), dev(sc['rgb']).view(1, 3, -1)
+    shifts = [(2.5 * k - 6.0, 1.0 * k, 0.2 * k) for k in range(5)]
+    wm = ops.WarpFrame(H, W, 'cuda', path='tiled')
+    for n_pts in (H * W, H * W - 4001, H * W - 977, H * W):
+        p, d, c = pts[:, :, :n_pts].contiguous(), dep[:, :, :n_pts].contiguous(), rgb[:, :, :n_pts].contiguous()
+        wf = ops.WarpFrame(H, W, 'cuda', path='tiled')
+        ref = torch.stack([wf(p, c, d, sc['focal'], sc['baseline'], s)[0].clone() for s in shifts])
+        got = wm.frames(p, c, d, sc['focal'], sc['baseline'], shifts, lanes=3)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), n_pts
