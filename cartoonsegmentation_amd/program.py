@@ -144,6 +144,44 @@ def pack_wino_weights(w):
     return np.ascontiguousarray(U.transpose(1, 3, 4, 0, 5, 2, 6)).reshape(-1)   # nt, cb, q, f, h, co, e
 
 
+# ---- Winograd F(4x4, 3x3) (include/csm355.h "Winograd F(4x4) contract") ----------------------------------------------------------
+# Same layer class as F(2x2); 36 products per 4x4 output tile and channel pair instead of 64.  A layer takes it when it has at least
+# WINO4_MIN_PIXELS output pixels per sample (per-sample rule: batch invariant); CSM_WINO4=0 keeps every Winograd layer on F(2x2).
+CONV_FLAG_WINOGRAD4 = 8
+WINO4_ENABLE = os.environ.get('CSM_WINO4', '0') != '0'
+WINO4_MIN_PIXELS = int(os.environ.get('CSM_WINO4_MIN_PIXELS', '6400'))
+
+
+def wino4_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=None):
+    ld = cin_g if ld is None else ld
+    return (kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and groups == 1 and cin_g % 32 == 0 and cout % WINO_BN == 0
+            and ho * wo >= WINO4_MIN_PIXELS and ld % 4 == 0 and ((ho * wo - 1) * ld + cin_g) * 4 < 2 ** 31
+            and (cout // WINO_BN) * (cin_g // 4) * 36864 < 2 ** 31)
+
+
+def wino4_transform(w):
+    """w [cout, cin, 3, 3] fp32 -> U [36, cout, cin] fp32 = G g G^T (Lavin & Gray, points 0, +-1, +-2, inf), float64 arithmetic in the
+    contract's fixed order -- elementwise numpy operations only (IEEE double: the same values the oracle's C computes)"""
+    g = np.asarray(w, np.float64)
+
+    def rows(g0, g1, g2):
+        return [g0 * 0.25, -((g0 + g1) + g2) / 6.0, -((g0 - g1) + g2) / 6.0, ((g0 + 2.0 * g1) + 4.0 * g2) / 24.0,
+                ((g0 - 2.0 * g1) + 4.0 * g2) / 24.0, g2]
+    r = rows(g[:, :, 0, :], g[:, :, 1, :], g[:, :, 2, :])                 # 6 x [cout, cin, 3]
+    u = [rows(ri[:, :, 0], ri[:, :, 1], ri[:, :, 2]) for ri in r]         # u[i][j] [cout, cin]
+    return np.stack([u[i][j] for i in range(6) for j in range(6)]).astype(np.float32)
+
+
+def pack_wino4_weights(w):
+    """-> packed fp32 1-D for k_conv_wino4: [cout / 64][step s][wave 6 nh + i][piece p][lh][li][jj][t], value
+    U[6 i + 2 p + jj][64 nt + 32 nh + li][8 (s >> 1) + 4 lh + 2 (s & 1) + t]"""
+    cout, cin = w.shape[:2]
+    assert cout % WINO_BN == 0 and cin % 8 == 0
+    U = wino4_transform(w)                                                 # [36, cout, cin]
+    U = U.reshape(6, 3, 2, cout // WINO_BN, 2, 32, cin // 8, 2, 2, 2)      # i, p, jj, nt, nh, li, q8, lh, hf, t
+    return np.ascontiguousarray(U.transpose(3, 6, 8, 4, 0, 1, 7, 5, 2, 9)).reshape(-1)   # nt, q8, hf, nh, i, p, lh, li, jj, t
+
+
 class Buf:
     def __init__(self, n, h, w, c, ext=-1, nchw=False):
         self.n, self.h, self.w, self.c, self.ext, self.nchw = n, h, w, c, ext, nchw
@@ -254,8 +292,11 @@ class Program:
         assert out.shape == (x.n, ho, wo, cout), (out.shape, (x.n, ho, wo, cout))
         stem = groups == 1 and cin_g == 4 and cout > 4        # k_conv_stem: (tap, channel)-packed K, csm_op.flags bit 1
         wino = self.winograd and wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c)
+        wino4 = wino and self.winograd4 and wino4_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c)
         if stem:
             packed, sg, cin_sg, cout_sg = pack_stem_weights(w), 1, 4, cout
+        elif wino4:
+            packed, sg, cin_sg, cout_sg = pack_wino4_weights(w), 1, cin_g, cout
         elif wino:
             packed, sg, cin_sg, cout_sg = pack_wino_weights(w), 1, cin_g, cout
         else:
@@ -267,7 +308,8 @@ class Program:
         if slope is not None:
             a_h, a_n = self._w(slope, slope)
         self.flops += 2 * x.n * ho * wo * cout * cin_g * kh * kw
-        self.flops_exec += (2 * x.n * ((ho + 1) // 2) * ((wo + 1) // 2) * 16 * cout * cin_g) if wino else (2 * x.n * ho * wo * cout * cin_g * kh * kw)
+        self.flops_exec += ((2 * x.n * ((ho + 3) // 4) * ((wo + 3) // 4) * 36 * cout * cin_g) if wino4 else
+                            (2 * x.n * ((ho + 1) // 2) * ((wo + 1) // 2) * 16 * cout * cin_g) if wino else (2 * x.n * ho * wo * cout * cin_g * kh * kw))
         self.conv_bytes += 4 * (x.n * x.h * x.w * x.c + x.n * ho * wo * cout + w.size)
         ksplit, scr = (1 if stem or wino else self.choose_ksplit(ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups)), None
         if ksplit > 1:
@@ -275,11 +317,12 @@ class Program:
         return self._emit(OP_CONV, x, res, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, groups=sg, cin_g=cin_sg,
                           cout_g=cout_sg, act=ACT[act], res_mode=res_mode if res is not None else 0, w_off=w_h, b_off=b_h,
                           aux_off=a_h, ksplit=ksplit, scratch=-1 if scr is None else scr.id, scratch_view=scr,
-                          flags=CONV_FLAG_STEM if stem else (CONV_FLAG_WINOGRAD if wino else 0),
+                          flags=CONV_FLAG_STEM if stem else (CONV_FLAG_WINOGRAD4 if wino4 else (CONV_FLAG_WINOGRAD if wino else 0)),
                           nat=dict(groups=groups, cin_g=cin_g, cout_g=cout // groups, w_off=w_n, b_off=b_n, aux_off=a_n))
 
     split_k = True
     winograd = WINO_ENABLE          # (class default; a test may lower one program with / without it)
+    winograd4 = WINO4_ENABLE        # F(4x4) for the Winograd layers of at least WINO4_MIN_PIXELS pixels (else F(2x2))
 
     def choose_ksplit(self, M, N, T, groups):
         """small feature maps (M = output pixels of ONE sample): not enough 64x64 output tiles to fill 256 CUs -> cut K

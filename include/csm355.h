@@ -248,8 +248,25 @@ typedef struct csm_tensor_desc {
  *   Y = A^T M A over j first: s0 = (m0 + m1) + m2, s1 = (m1 - m2) - m3, then over i; y = Y + bias; residual / activation as usual.
  * Packed device weights (cout tile of 64, 32-channel block cb, 8-channel step q): [co / 64][cb][q][f][h][co % 64][4] with channel
  * c = 32 cb + 8 q + 4 h + e at element e -- exactly the LDS image of one pipeline step (32 KB), moved by a linear LDS-DMA copy. */
+/* Winograd F(4x4, 3x3) contract (csm_op.flags & CSM_CONV_FLAG_WINOGRAD4; restated in oracle/nets_oracle.c::orc_conv_wino4, executed by
+ * csrc/wino4.hip::k_conv_wino4): Lavin & Gray's matrices for the points 0, +-1, +-2, inf -- 36 products per 4x4 output tile and channel
+ * pair (F(2x2): 64, direct: 144).  Same layer class as F(2x2); which of the two a layer takes is the lowering's per-sample rule.
+ *   U[f = 6i + j][co][c] = fp32(G g G^T) in double, rows first: r0 = g0 * 0.25, r1 = -((g0 + g1) + g2) / 6, r2 = -((g0 - g1) + g2) / 6,
+ *                          r3 = ((g0 + 2 g1) + 4 g2) / 24, r4 = ((g0 - 2 g1) + 4 g2) / 24, r5 = g2 (IEEE double division), then the columns;
+ *   V = B^T d B on the 6 x 6 window d (origin (4 ty - 1, 4 tx - 1), zeros outside), 1-D transform in fp32 with fmaf where written:
+ *                          t0 = fmaf(4, d0, fmaf(-5, d2, d4)), t5 = fmaf(4, d1, fmaf(-5, d3, d5)),
+ *                          a = fmaf(-4, d2, d4), b = fmaf(-4, d1, d3), t1 = a + b, t2 = a - b,
+ *                          c = d4 - d2, e = d3 - d1, t3 = fmaf(2, e, c), t4 = fmaf(-2, e, c)   -- row index first, then column index;
+ *   M[f] = one fmaf chain per (f, tile, co) over the input channels from 0.0f, channel order of the direct contract;
+ *   Y = A^T M A over j first, then i, 1-D transform p = m1 + m2, q = m1 - m2, r = m3 + m4, t = m3 - m4,
+ *                          s0 = (m0 + p) + r, s1 = fmaf(2, t, q), s2 = fmaf(4, r, p), s3 = fmaf(8, t, q) + m5;
+ *   y = Y + bias; residual / activation as usual.  Output pixel (4 ty + a, 4 tx + b).
+ * Packed device weights (cout tile of 64, step s = 4 input channels: 8-block s >> 1, half s & 1):
+ *   [co / 64][s][wave = 6 nh + i][piece p][lh][li][jj][t] = U[6 i + 2 p + jj][64 (co / 64) + 32 nh + li][8 (s >> 1) + 4 lh + 2 (s & 1) + t]
+ *   -- 36 KB per (cout tile, step); a wave's 3 KB are its three LDS-DMA pieces, lane 32 lh + li reads its four values as one 16-B word. */
 #define CSM_CONV_FLAG_STEM 2
 #define CSM_CONV_FLAG_WINOGRAD 4
+#define CSM_CONV_FLAG_WINOGRAD4 8
 
 typedef struct csm_op {
     int32_t kind;
@@ -264,7 +281,9 @@ typedef struct csm_op {
                                 CONV bit 2 (CSM_CONV_FLAG_WINOGRAD): exact-fp32 Winograd F(2x2, 3x3) arithmetic (3x3, stride 1, dilation
                                 1, pad 1, dense, cin % 32 == 0, cout % 64 == 0, ksplit 1): weights are the transformed panels
                                 U = G g G^T packed for k_conv_wino; part of the NUMERICAL contract (set by the lowering from the layer's
-                                per-sample shape, never by the tuner) -- see "Winograd contract" below */
+                                per-sample shape, never by the tuner) -- see "Winograd contract" below.
+                                CONV bit 3 (CSM_CONV_FLAG_WINOGRAD4): the same layer class in the F(4x4, 3x3) arithmetic (weights = its own
+                                36-frequency panels packed for k_conv_wino4); bits 2 and 3 are exclusive */
     int32_t ksplit;          /* CONV: K is cut into `ksplit` runs of (32-channel block, tap) chunks (block-major), run s = chunks
                                 [s*T/ksplit, (s+1)*T/ksplit); each run is its own fmaf chain (run 0 starts at the bias,
                                 the others at 0) and the runs are added in order ((p0+p1)+p2)...  1 = single chain */

@@ -347,6 +347,135 @@ static void orc_conv_wino(const csm_op *op, view_t in, view_t res, view_t out, c
     free(U); free(cidx);
 }
 
+/* ---- Winograd F(4x4, 3x3) convolution (csm_op.flags bit 3, CSM_CONV_FLAG_WINOGRAD4; same layer class as F(2x2)) -------------------------
+ * 36 multiplications per 4x4 output tile and channel pair (direct: 144, F(2x2): 64).  Lavin & Gray's matrices for the points
+ * 0, +-1, +-2, inf; its OWN fixed arithmetic -- the contract csrc/wino4.hip::k_conv_wino4 executes bit for bit (include/csm355.h
+ * "Winograd F(4x4) contract"):
+ *   weights   U[f = 6 i + j][co][c] = fp32( G g G^T ) in DOUBLE, rows of G applied to the kernel's rows first, then to the columns:
+ *             r0 = g0 * 0.25, r1 = -((g0 + g1) + g2) / 6, r2 = -((g0 - g1) + g2) / 6, r3 = ((g0 + 2 g1) + 4 g2) / 24,
+ *             r4 = ((g0 - 2 g1) + 4 g2) / 24, r5 = g2  (IEEE double division by 6.0 / 24.0).
+ *   input     d[i][j] = x[4 ty - 1 + i][4 tx - 1 + j] (0 outside); the 1-D transform T6 (B^T), fp32, fmaf where written:
+ *                 t0 = fmaf(4, d0, fmaf(-5, d2, d4));            t5 = fmaf(4, d1, fmaf(-5, d3, d5));
+ *                 a = fmaf(-4, d2, d4); b = fmaf(-4, d1, d3);    t1 = a + b;  t2 = a - b;
+ *                 c = d4 - d2;          e = d3 - d1;             t3 = fmaf(2, e, c);  t4 = fmaf(-2, e, c);
+ *             over the ROW index first, then over the column index: V[i][j].
+ *   products  M[f] = one fmaf chain per (f, tile, co) over the input channels from 0.0f, channel order of the direct contract.
+ *   output    the 1-D transform O6 (A^T):  p = m1 + m2; q = m1 - m2; r = m3 + m4; t = m3 - m4;
+ *                 s0 = (m0 + p) + r;  s1 = fmaf(2, t, q);  s2 = fmaf(4, r, p);  s3 = fmaf(8, t, q) + m5
+ *             over j first (s[i][b]), then over i (Y[a][b]); y = Y + bias; residual / activation as in orc_conv.  Output pixel
+ *             (4 ty + a, 4 tx + b); tiles cover ceil(h / 4) x ceil(w / 4), the excess is dropped.
+ * Error: the transforms amplify (entries up to 8, 1/24): measured 4-5x the direct chain's fp32 error. */
+static inline void orc_t6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5, float *t, int st)
+{
+    t[0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+    t[5 * st] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+    const float a = fmaf(-4.0f, d2, d4), b = fmaf(-4.0f, d1, d3);
+    t[1 * st] = a + b; t[2 * st] = a - b;
+    const float c = d4 - d2, e = d3 - d1;
+    t[3 * st] = fmaf(2.0f, e, c); t[4 * st] = fmaf(-2.0f, e, c);
+}
+static inline void orc_o6(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5, float *s, int st)
+{
+    const float p = m1 + m2, q = m1 - m2, r = m3 + m4, t = m3 - m4;
+    s[0] = (m0 + p) + r;
+    s[1 * st] = fmaf(2.0f, t, q);
+    s[2 * st] = fmaf(4.0f, r, p);
+    s[3 * st] = fmaf(8.0f, t, q) + m5;
+}
+static inline void orc_g6(const double g0, const double g1, const double g2, double *r, int st)
+{
+    r[0] = g0 * 0.25;
+    r[1 * st] = -((g0 + g1) + g2) / 6.0;
+    r[2 * st] = -((g0 - g1) + g2) / 6.0;
+    r[3 * st] = ((g0 + 2.0 * g1) + 4.0 * g2) / 24.0;
+    r[4 * st] = ((g0 - 2.0 * g1) + 4.0 * g2) / 24.0;
+    r[5 * st] = g2;
+}
+static void orc_wino4_weights(const float *W, int cout, int cin, const int *cidx, float *U /* [cout][cin in CHAIN order][36] */)
+{
+#pragma omp parallel for schedule(static)
+    for (int co = 0; co < cout; ++co)
+        for (int k = 0; k < cin; ++k) {
+            const float *g = W + ((int64_t)co * cin + cidx[k]) * 9;
+            double r[6][3], u[6][6];
+            for (int x = 0; x < 3; ++x) orc_g6(g[x], g[3 + x], g[6 + x], &r[0][x], 3);
+            for (int i = 0; i < 6; ++i) orc_g6(r[i][0], r[i][1], r[i][2], &u[i][0], 1);
+            for (int f = 0; f < 36; ++f) U[((int64_t)co * cin + k) * 36 + f] = (float)u[f / 6][f % 6];
+        }
+}
+
+static void orc_conv_wino4(const csm_op *op, view_t in, view_t res, view_t out, const float *W, const float *bias, const float *slope)
+{
+    const int cin = op->cin_g, cout = op->cout_g, ncb = (cin + 31) / 32;
+    const int ty_n = (out.h + 3) / 4, tx_n = (out.w + 3) / 4;
+    int *cidx = (int *)malloc(sizeof(int) * (size_t)ncb * 32);
+    int K = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int kb = cb * 32; kb < cb * 32 + 32 && kb < cin; kb += 8)
+            for (int t = 0; t < 4; ++t)
+                for (int h = 0; h < 2; ++h) { int c = kb + 4 * h + t; if (c < cin) cidx[K++] = c; }
+    float *U = (float *)malloc(sizeof(float) * (size_t)36 * cout * cin);
+    orc_wino4_weights(W, cout, cin, cidx, U);
+    const int64_t T = (int64_t)out.n * ty_n * tx_n;
+#pragma omp parallel
+    {
+        float *V = (float *)malloc(sizeof(float) * (size_t)36 * cin);
+#pragma omp for schedule(dynamic, 8)
+        for (int64_t tile = 0; tile < T; ++tile) {
+            const int n = (int)(tile / ((int64_t)ty_n * tx_n)), rem = (int)(tile - (int64_t)n * ty_n * tx_n);
+            const int ty = rem / tx_n, tx = rem - ty * tx_n;
+            const float *xp[36];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    const int iy = 4 * ty - 1 + i, ix = 4 * tx - 1 + j;
+                    xp[6 * i + j] = (iy < 0 || iy >= in.h || ix < 0 || ix >= in.w) ? NULL : in.p + ((int64_t)(n * in.h + iy) * in.w + ix) * in.ld;
+                }
+            for (int k = 0; k < cin; ++k) {
+                const int c = cidx[k];
+                float d[6][6], t[6][6];
+                for (int q = 0; q < 36; ++q) d[q / 6][q % 6] = xp[q] ? xp[q][c] : 0.0f;
+                for (int j = 0; j < 6; ++j) orc_t6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], &t[0][j], 6);      /* rows */
+                for (int i = 0; i < 6; ++i) orc_t6(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], V + k * 36 + 6 * i, 1);   /* columns */
+            }
+            for (int co0 = 0; co0 < cout; co0 += 4) {
+              float m4[4][40] __attribute__((aligned(32)));
+              const int nco = cout - co0 < 4 ? cout - co0 : 4;
+              for (int q = 0; q < 4; ++q) for (int f = 0; f < 36; ++f) m4[q][f] = 0.0f;
+              const float *u0 = U + (int64_t)co0 * cin * 36, *u1 = u0 + (nco > 1 ? (int64_t)cin * 36 : 0),
+                          *u2 = u0 + (nco > 2 ? 2 * (int64_t)cin * 36 : 0), *u3 = u0 + (nco > 3 ? 3 * (int64_t)cin * 36 : 0);
+              for (int k = 0; k < cin; ++k) {
+                  const float *v = V + k * 36;
+#pragma omp simd
+                  for (int f = 0; f < 36; ++f) {
+                      m4[0][f] = fmaf(v[f], u0[k * 36 + f], m4[0][f]); m4[1][f] = fmaf(v[f], u1[k * 36 + f], m4[1][f]);
+                      m4[2][f] = fmaf(v[f], u2[k * 36 + f], m4[2][f]); m4[3][f] = fmaf(v[f], u3[k * 36 + f], m4[3][f]);
+                  }
+              }
+              for (int q = 0; q < nco; ++q) {
+                const int co = co0 + q;
+                const float *m = m4[q];
+                float s[6][4], Y[4][4];
+                for (int i = 0; i < 6; ++i) orc_o6(m[6 * i], m[6 * i + 1], m[6 * i + 2], m[6 * i + 3], m[6 * i + 4], m[6 * i + 5], &s[i][0], 1);
+                for (int b = 0; b < 4; ++b) orc_o6(s[0][b], s[1][b], s[2][b], s[3][b], s[4][b], s[5][b], &Y[0][b], 4);
+                for (int a_ = 0; a_ < 4; ++a_)
+                    for (int b = 0; b < 4; ++b) {
+                        const int oy = 4 * ty + a_, ox = 4 * tx + b;
+                        if (oy >= out.h || ox >= out.w) continue;
+                        const int64_t mrow = ((int64_t)n * out.h + oy) * out.w + ox;
+                        float acc = Y[a_][b] + (bias ? bias[co] : 0.0f);
+                        if (op->res_mode == 1 && res.p) acc += res.p[mrow * res.ld + co];
+                        acc = orc_act(acc, op->act, slope ? slope[co] : 0.0f);
+                        if (op->res_mode == 2 && res.p) acc += res.p[mrow * res.ld + co];
+                        out.p[mrow * out.ld + co] = acc;
+                    }
+              }
+            }
+        }
+        free(V);
+    }
+    free(U); free(cidx);
+}
+
 /* depthwise: weights natural [c][kh][kw] */
 static void orc_dwconv(const csm_op *op, view_t in, view_t out, const float *W, const float *bias, const float *slope)
 {
@@ -652,6 +781,11 @@ int orc_run_program(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors
                         fprintf(stderr, "orc_run_program: op %d: Winograd flag on an ineligible convolution\n", i); return 1;
                     }
                     orc_conv_wino(op, in, in1, out, W, B, S);
+                } else if (op->flags & CSM_CONV_FLAG_WINOGRAD4) {
+                    if (op->kh != 3 || op->kw != 3 || op->stride != 1 || op->dil != 1 || op->pad != 1 || op->groups != 1 || op->ksplit > 1) {
+                        fprintf(stderr, "orc_run_program: op %d: Winograd F(4x4) flag on an ineligible convolution\n", i); return 1;
+                    }
+                    orc_conv_wino4(op, in, in1, out, W, B, S);
                 } else if (e && e[0] == '1') orc_conv(op, in, in1, out, W, B, S); else orc_conv_fast(op, in, in1, out, W, B, S);
                 break;
             }
@@ -698,6 +832,15 @@ void orc_wino_transform_weights(const float *W, int cout, int cin, float *U)
     int *cidx = (int *)malloc(sizeof(int) * (size_t)cin);
     for (int c = 0; c < cin; ++c) cidx[c] = c;
     orc_wino_weights(W, cout, cin, cidx, U);
+    free(cidx);
+}
+
+/* the same hook for F(4x4): [cout][cin][36] */
+void orc_wino4_transform_weights(const float *W, int cout, int cin, float *U)
+{
+    int *cidx = (int *)malloc(sizeof(int) * (size_t)cin);
+    for (int c = 0; c < cin; ++c) cidx[c] = c;
+    orc_wino4_weights(W, cout, cin, cidx, U);
     free(cidx);
 }
 
