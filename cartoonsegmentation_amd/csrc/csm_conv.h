@@ -184,5 +184,8 @@ __device__ __forceinline__ void dma16(unsigned voff, i32x4 rsrc, unsigned lds_by
 // Winograd F(2x2, 3x3) convolution (wino.hip): launches k_conv_wino for an op that carries CSM_CONV_FLAG_WINOGRAD
 bool wino_eligible(const ConvArgs &a);
 int launch_conv_wino(const ConvArgs &a, hipStream_t st);
+// Winograd F(4x4, 3x3) convolution (wino4.hip): k_conv_wino4 for an op that carries CSM_CONV_FLAG_WINOGRAD4
+bool wino4_eligible(const ConvArgs &a);
+int launch_conv_wino4(const ConvArgs &a, hipStream_t st);
 
 }  // namespace csmconv

@@ -2537,6 +2537,12 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                     if (rc) return rc;
                     break;
                 }
+                if (op.flags & CSM_CONV_FLAG_WINOGRAD4) {     // Winograd F(4x4, 3x3): the same layer class, 36 instead of 64 products per 4x4 outputs (wino4.hip)
+                    if (!wino4_eligible(a)) { csm::set_error("op %d: Winograd F(4x4) flag on an ineligible convolution (3x3 / stride 1 / pad 1 / dense / cin %% 32 / cout %% 64 / ksplit 1)", i); return CSM_ERR_ARG; }
+                    rc = launch_conv_wino4(a, st);
+                    if (rc) return rc;
+                    break;
+                }
                 if (op.flags & 2) {      // stem: (tap, channel)-packed K (weights packed by the host for exactly this kernel)
                     if (op.groups != 1 || op.cin_g != 4 || a.ksplit != 1) { csm::set_error("op %d: stem flag needs groups 1, cin 4, ksplit 1", i); return CSM_ERR_ARG; }
                     dim3 grid((a.M + 63) / 64, (op.cout_g + 63) / 64, 1);
@@ -2742,7 +2748,7 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
     int tuned = 0, rc = CSM_OK;
     for (int i = 0; i < n_ops && rc == CSM_OK; ++i) {
         csm_op &op = ops[i];
-        if (op.kind != CSM_OP_CONV || (op.flags & (CSM_CONV_FLAG_STEM | CSM_CONV_FLAG_WINOGRAD))) continue;          // stems and Winograd layers have one dedicated kernel
+        if (op.kind != CSM_OP_CONV || (op.flags & (CSM_CONV_FLAG_STEM | CSM_CONV_FLAG_WINOGRAD | CSM_CONV_FLAG_WINOGRAD4))) continue;          // stems and Winograd layers have one dedicated kernel
         const int npad = (op.cout_g + 31) / 32 * 32;
         static const int cand_all[] = {CFG_64x64, CFG_128x32, CFG_64x16, CFG_D64x64, CFG_D128x64, CFG_D64x128, CFG_D128x128,
                                        CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32, CFG_NARROW, CFG_D96x128, CFG_D160x128,

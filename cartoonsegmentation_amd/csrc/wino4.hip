@@ -1,0 +1,398 @@
+// wino4.hip -- exact-fp32 Winograd F(4x4, 3x3) convolution on the matrix pipe (gfx950), fused in ONE kernel: input transform B^T d B
+// by rotating groups of waves through LDS, 36 frequency GEMMs on v_mfma_f32_32x32x2_f32, output transform A^T M A + bias + residual +
+// activation in the epilogue.  Arithmetic = the "Winograd F(4x4) contract" of include/csm355.h, restated independently in
+// oracle/nets_oracle.c::orc_conv_wino4; this kernel reproduces it bit for bit (every transform value is the contract's fp32 expression,
+// every product sum ONE fmaf chain in the direct contract's channel order -- fp32 MFMA is bitwise an fmaf chain over k).
+//
+// Why: F(2x2, 3x3) (wino.hip) executes 64 multiplications per 4x4 output pixels and channel pair, F(4x4, 3x3) 36 -- the 3x3 layers that
+// carry a third of a step's convolution time execute 0.56x the MFMA FLOPs again.
+//
+// Mapping (CDNA4-first; the F(2x2) kernel's in-register transform does not carry over -- 36 accumulators per (32 tiles x 32 channels)
+// are 576 registers, and a 6x6 window transformed per wave would be computed twice and read from LDS 2.25x):
+//   * block = 12 waves (three per SIMD, <= 168 registers), ONE block per CU: 8 x 4 Winograd tiles (32 x 16 output pixels) x 64 output
+//     channels.  Wave (i, nh) owns frequency ROW i (six 32x32 accumulators = 96 registers) of the 32 tiles x output channels
+//     [32 nh, 32 nh + 32).
+//   * step = 4 input channels (two MFMAs per frequency and wave).  The raw input patch ((16 + 2) x (32 + 2) pixels) is staged by LDS-DMA
+//     16 channels (= 4 steps) at a time, two stages; its 16-byte granules (pixel, 4 channels) sit at  4 psi + (slot ^ ((row >> 2) & 3)),
+//     psi = ((col >> 1) & 1) 324 + 18 row + 9 (col & 1) + (col >> 2):  the stride-4 windows of a lane group's 8 x 4 tiles are 8 consecutive
+//     64-byte pixel entries per tile row, rows alternate between the two halves of a 16-granule period, and the slot swizzle spreads
+//     a fixed slot over the four 16-byte positions -- a ds_read_b64 of one channel pair touches every bank at most twice (the minimum for
+//     8-byte reads of 16-byte granules), and four consecutive DMA lanes fetch the 64 contiguous bytes of one pixel.
+//   * transform: in step s the three waves of group s & 3 turn the raw window of step s + 1 into V[f][k-half][tile][2 channels] in LDS
+//     (unit = (tile, row pair {1,2} / {3,4} / {0,5}, k-half): row pass with the pair's shared terms, column pass, 96 VALU, 24-36
+//     ds_read_b64, 12 ds_write_b64) -- once per block, shared by both channel halves; the other waves' MFMAs cover it.
+//   * A fragments: one conflict-free ds_read_b64 per frequency and step (two k-steps); B fragments: the transformed weights are packed on
+//     the host so that a wave's share of a step is three 1-KB LDS-DMA pieces into a PRIVATE 3-KB slot (no barrier: only this wave reads
+//     them), each lane picking its four values of two frequencies with one ds_read_b128 into registers a step ahead.
+//   * ONE barrier per step; everything the next step needs has been issued a full step before it is waited for.
+//   * epilogue: column pass of A^T M A in registers (a wave holds whole frequency rows), the six waves of a channel half exchange the
+//     row-pass inputs through LDS in two rounds of eight accumulator elements, each wave finishes 2-3 tiles per lane.
+#include "csm_conv.h"
+#include <utility>
+#include <cstdlib>
+
+using namespace csmconv;
+
+namespace {
+
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef float f32x2n __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x4n *lds_f4_ptr;
+typedef __attribute__((address_space(3))) f32x2n *lds_f2_ptr;
+
+__device__ __forceinline__ f32x4n lds_read4(unsigned byte_addr) { return *(lds_f4_ptr)(size_t)byte_addr; }
+__device__ __forceinline__ f32x2n lds_read2(unsigned byte_addr) { return *(lds_f2_ptr)(size_t)byte_addr; }
+__device__ __forceinline__ void lds_write4(unsigned byte_addr, f32x4n v) { *(lds_f4_ptr)(size_t)byte_addr = v; }
+__device__ __forceinline__ void lds_write2(unsigned byte_addr, f32x2n v) { *(lds_f2_ptr)(size_t)byte_addr = v; }
+
+// LDS-DMA piece with a scalar byte offset on the global side: 64 lanes x 16 B -> LDS [lds_byte_addr, +1 KB)
+__device__ __forceinline__ void dma16s(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory");
+}
+
+template <int N> using ic = std::integral_constant<int, N>;
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// raw barrier with its waits in ONE asm block (tools/check_isa_barriers.py)
+template <int VM> __device__ __forceinline__ void wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(VM) : "memory");
+}
+
+// the contract's 1-D transforms (include/csm355.h), one component
+struct T6 { float t0, t1, t2, t3, t4, t5; };
+__device__ __forceinline__ T6 bt6(float d0, float d1, float d2, float d3, float d4, float d5) {
+    T6 o;
+    o.t0 = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+    o.t5 = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+    const float a = fmaf(-4.0f, d2, d4), b = fmaf(-4.0f, d1, d3);
+    o.t1 = a + b; o.t2 = a - b;
+    const float c = d4 - d2, e = d3 - d1;
+    o.t3 = fmaf(2.0f, e, c); o.t4 = fmaf(-2.0f, e, c);
+    return o;
+}
+__device__ __forceinline__ f32x4n at6(float m0, float m1, float m2, float m3, float m4, float m5) {
+    const float p = m1 + m2, q = m1 - m2, r = m3 + m4, t = m3 - m4;
+    f32x4n s;
+    s.x = (m0 + p) + r;
+    s.y = fmaf(2.0f, t, q);
+    s.z = fmaf(4.0f, r, p);
+    s.w = fmaf(8.0f, t, q) + m5;
+    return s;
+}
+
+constexpr int kTX = 8, kTY = 4;                              // Winograd tiles of a block
+constexpr int kOW = 4 * kTX, kOH = 4 * kTY;                  // 32 x 16 output pixels
+constexpr int kPW = kOW + 2, kPH = kOH + 2;                  // 34 x 18 patch pixels
+constexpr int kPsi = 2 * 18 * 18;                            // 648 pixel entries (64 B each) of a 16-channel stage
+constexpr int kRawPieces = (kPsi * 4 + 63) / 64;             // 41 DMA pieces
+constexpr unsigned kRawB = kRawPieces * 1024u;               // 41 984 B per stage
+constexpr unsigned kVB = 36u * 512u;                         // 18 432 B: V[f][k-half][32 tiles][2]
+constexpr unsigned kV0 = 2u * kRawB, kU0 = kV0 + 2u * kVB;   // 83 968, 120 832
+constexpr unsigned kUW = 3072u;                              // a wave's private U slot (three pieces)
+constexpr unsigned kLds = kU0 + 12u * kUW;                   // 157 696 B
+constexpr unsigned kOob = 0x80000000u;
+static_assert(kPH == 18 && kPW == 34 && kLds <= 160u * 1024u, "tile shape");
+
+// pixel entry of patch position (row r, column c) relative to the entry of (4 ty, 4 tx): compile-time part of psi
+__host__ __device__ constexpr int psi_k(int r, int c) { return ((c >> 1) & 1) * 324 + r * 18 + (c & 1) * 9 + (c >> 2); }
+
+// G: which pair of frequency rows the unit produces: 0 = {1, 2}, 1 = {3, 4}, 2 = {0, 5}
+template <int G>
+__device__ __forceinline__ void transform_unit(unsigned bx0, unsigned bx1, unsigned vdst) {
+    constexpr int r0 = G == 2 ? 0 : 1, r1 = G == 2 ? 6 : 5;
+    f32x2n T[2][6];
+    static_for<6>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        f32x2n d[6];
+        static_for<6>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            if constexpr (r >= r0 && r < r1) d[r] = lds_read2(((r >> 2) ? bx1 : bx0) + (unsigned)(psi_k(r, c) * 64));
+        });
+        if constexpr (G == 0) {
+            const float ax = fmaf(-4.0f, d[2].x, d[4].x), bx = fmaf(-4.0f, d[1].x, d[3].x);
+            const float ay = fmaf(-4.0f, d[2].y, d[4].y), by = fmaf(-4.0f, d[1].y, d[3].y);
+            T[0][c].x = ax + bx; T[1][c].x = ax - bx; T[0][c].y = ay + by; T[1][c].y = ay - by;
+        } else if constexpr (G == 1) {
+            const float cx = d[4].x - d[2].x, ex = d[3].x - d[1].x, cy = d[4].y - d[2].y, ey = d[3].y - d[1].y;
+            T[0][c].x = fmaf(2.0f, ex, cx); T[1][c].x = fmaf(-2.0f, ex, cx); T[0][c].y = fmaf(2.0f, ey, cy); T[1][c].y = fmaf(-2.0f, ey, cy);
+        } else {
+            T[0][c].x = fmaf(4.0f, d[0].x, fmaf(-5.0f, d[2].x, d[4].x)); T[1][c].x = fmaf(4.0f, d[1].x, fmaf(-5.0f, d[3].x, d[5].x));
+            T[0][c].y = fmaf(4.0f, d[0].y, fmaf(-5.0f, d[2].y, d[4].y)); T[1][c].y = fmaf(4.0f, d[1].y, fmaf(-5.0f, d[3].y, d[5].y));
+        }
+        if constexpr (c & 1) __builtin_amdgcn_sched_barrier(0);      // (keeps the loads of later columns from being hoisted: registers)
+    });
+    static_for<2>([&](auto RO) {
+        constexpr int ro = decltype(RO)::value;
+        constexpr int i = G == 0 ? 1 + ro : (G == 1 ? 3 + ro : (ro ? 5 : 0));
+        const T6 x = bt6(T[ro][0].x, T[ro][1].x, T[ro][2].x, T[ro][3].x, T[ro][4].x, T[ro][5].x);
+        const T6 y = bt6(T[ro][0].y, T[ro][1].y, T[ro][2].y, T[ro][3].y, T[ro][4].y, T[ro][5].y);
+        lds_write2(vdst + (unsigned)((i * 6 + 0) * 512), f32x2n{x.t0, y.t0});
+        lds_write2(vdst + (unsigned)((i * 6 + 1) * 512), f32x2n{x.t1, y.t1});
+        lds_write2(vdst + (unsigned)((i * 6 + 2) * 512), f32x2n{x.t2, y.t2});
+        lds_write2(vdst + (unsigned)((i * 6 + 3) * 512), f32x2n{x.t3, y.t3});
+        lds_write2(vdst + (unsigned)((i * 6 + 4) * 512), f32x2n{x.t4, y.t4});
+        lds_write2(vdst + (unsigned)((i * 6 + 5) * 512), f32x2n{x.t5, y.t5});
+    });
+}
+
+// ABL (development ablations, timing only -- results invalid): 1 = no DMA, 2 = no transform, 4 = no MFMA, 8 = no epilogue stores
+template <int ABL = 0>
+__global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(64))) float lds[];   // [raw 0][raw 1][V 0][V 1][U: 12 private slots]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nh = wave / 6, wi = wave - 6 * nh;              // channel half, frequency row
+    const int tgroup = wave / 3, tg = wave - 3 * tgroup;      // transform group (active in steps s & 3 == tgroup), row pair of its units
+    const int li = lane & 31, lh = lane >> 5;
+    int mt, ntile, zz;
+    block_to_tile(mt, ntile, zz, 1);                          // cout tile slowest: the blocks resident on an XCD share one 64-channel U panel
+    const int btx = mt % tiles_x, bty = (mt / tiles_x) % tiles_y, n = mt / (tiles_x * tiles_y);
+    const int ho = a.out.h, wo = a.out.w;
+    const int nsteps = a.cin_g >> 2, nstages = nsteps >> 2;
+    const int oy0 = bty * kOH, ox0 = btx * kOW;
+
+    i32x4 ra, rb;
+    {
+        uint64_t pa = (uint64_t)a.in.p, pb = (uint64_t)a.w;
+        unsigned na = (unsigned)((((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4);
+        unsigned nb = (unsigned)((int64_t)(a.cout_g / 64) * nsteps * (12 * kUW));
+        ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
+        rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    // ---- this wave's U stream: step s at ((ntile nsteps + s) 12 + wave) 3 KB ----
+    const unsigned voffU = (unsigned)lane * 16u;
+    unsigned u_src = (unsigned)((ntile * nsteps) * 12 + wave) * kUW;         // next step to fetch
+    const unsigned ldsU = lds0 + kU0 + (unsigned)wave * kUW;
+    auto issue_u = [&](bool live) {
+        if constexpr (!(ABL & 1)) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dma16s(live ? voffU : kOob, rb, u_src + (unsigned)p * 1024u, ldsU + (unsigned)p * 1024u);
+        }
+        u_src += 12u * kUW;
+    };
+    issue_u(true);                                            // B(0): scalar addresses, goes out before anything else is computed
+
+    // ---- raw patch loader: wave w owns pieces w, w + 12, w + 24, w + 36 of a stage ----
+    unsigned offP[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int pp = wave + 12 * q;
+        if (pp > kRawPieces - 1) pp = kRawPieces - 1;         // (a piece past the end repeats the last one: same bytes, same place)
+        const int g = 64 * pp + lane;                         // granule
+        const int psi = g >> 2, sl = g & 3;
+        const int crh = psi / 324, rem = psi - crh * 324, R = rem / 18, r2 = rem - R * 18, c1 = r2 / 9, cq = r2 - c1 * 9;
+        const int C = 4 * cq + 2 * crh + c1;
+        const int slot = sl ^ ((R >> 2) & 3);
+        const int iy = oy0 - 1 + R, ix = ox0 - 1 + C;
+        const bool v = psi < kPsi && C < kPW && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+        offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
+    }
+    auto issue_raw = [&](int stage, int q, bool live) {       // piece q of this wave, 16-channel stage `stage` -> raw buffer stage & 1
+        if constexpr (!(ABL & 1)) {
+            int pp = wave + 12 * q;
+            if (pp > kRawPieces - 1) pp = kRawPieces - 1;
+            dma16s(live ? offP[q] : kOob, ra, (unsigned)stage * 64u, lds0 + (unsigned)(stage & 1) * kRawB + (unsigned)pp * 1024u);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_raw(0, q, true);
+
+    // ---- fragment / unit addresses ----
+    const int tx = li & 7, ty = li >> 3;
+    const unsigned ubase = lds0 + (unsigned)(ty * 72 + tx) * 64u;
+    const unsigned bxA = ubase + (unsigned)((lh ^ (ty & 3)) << 4), bxB = ubase + (unsigned)((lh ^ ((ty + 1) & 3)) << 4);
+    const unsigned vlane = lds0 + kV0 + (unsigned)lh * 256u + (unsigned)li * 8u;     // + parity kVB + f 512
+    const unsigned va = vlane + (unsigned)(wi * 6) * 512u;
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    f32x4n Bq[3];
+
+    // the V image of step sn from the raw stage that holds it
+    auto transform = [&](int sn) {
+        if constexpr (!(ABL & 2)) {
+            const unsigned e5 = (unsigned)((sn >> 1) & 1) << 5, add = (unsigned)((sn >> 2) & 1) * kRawB + (unsigned)(sn & 1) * 8u;
+            const unsigned b0 = (bxA ^ e5) + add, b1 = (bxB ^ e5) + add, vd = vlane + (unsigned)(sn & 1) * kVB;
+            if (tg == 0) transform_unit<0>(b0, b1, vd);
+            else if (tg == 1) transform_unit<1>(b0, b1, vd);
+            else transform_unit<2>(b0, b1, vd);
+        }
+    };
+
+    // ---- prologue ----
+    wait_barrier<0>();                                        // raw stage 0 and B(0) have landed (B(0) is read at the top of step 0)
+    issue_raw(1, 0, nstages > 1);
+    issue_raw(1, 1, nstages > 1);
+    if (tgroup == 3) transform(0);
+    wait_barrier<2>();                                        // V[0] is complete (the two fetches just issued may stay in flight)
+
+    // ---- main loop: step s = 4 input channels.  Order inside a step: [transform of step s + 1's window, group s & 3] -> this wave's B
+    // fragments (landed: issued a step ago) and A fragments into registers -> the fetches of B(s + 1) into the slot just read and of one
+    // raw piece -> 12 MFMAs -> barrier ----
+    for (int s4 = 0; s4 < nsteps; s4 += 4) {
+        static_for<4>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            const int s = s4 + q;
+            if (tgroup == q && s + 1 < nsteps) transform(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // B(s) and this wave's older raw pieces have landed
+#pragma unroll
+            for (int p = 0; p < 3; ++p) Bq[p] = lds_read4(ldsU + (unsigned)p * 1024u + voffU);
+            f32x2n A[6];
+            const unsigned vs = va + (unsigned)(q & 1) * kVB;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) A[j] = lds_read2(vs + (unsigned)j * 512u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            issue_u(s + 1 < nsteps);                          // B(s + 1) -> the slot whose contents are in registers now
+            // raw stage r = (s + 5) >> 2: its buffer was last read by the transform at the top of step 4 r - 6 (released by that step's
+            // barrier) and is first read at the top of step 4 r - 1 (published by the barrier of step 4 r - 2, whose top waits for the
+            // pieces of step 4 r - 3): two pieces in step 4 r - 5, one each in steps 4 r - 4 and 4 r - 3, none in step 4 r - 6
+            if constexpr (q != 2) {
+                const int stg = (s + 5) >> 2;
+                if constexpr (q == 3) { issue_raw(stg, 0, stg < nstages); issue_raw(stg, 1, stg < nstages); }
+                else issue_raw(stg, q + 2, stg < nstages);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 4)) {
+                static_for<12>([&](auto M) {
+                    constexpr int m = decltype(M)::value, half = m / 6, t = (m % 6) / 3, j = 3 * half + m % 3;
+                    const f32x4n bf = Bq[j >> 1];
+                    const float bv = (j & 1) ? (t ? bf.w : bf.z) : (t ? bf.y : bf.x);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(t ? A[j].y : A[j].x, bv, acc[j], 0, 0, 0);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // everybody: V[s + 1] written, V[s] and the raw stage read; the raw pieces waited for at the top of this step are published
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        });
+    }
+    wait_barrier<0>();        // the trailing (dead) fetches have landed for every wave: raw / V / U become the exchange area
+
+    // ---- epilogue ----
+    const int co = ntile * 64 + 32 * nh + li;
+    const float bias = a.bias ? a.bias[co] : 0.0f;
+    const float slope = a.slope ? a.slope[co] : 0.0f;
+    const int64_t ldo = a.out.ld, ldr = a.res.ld;
+    const unsigned xw = lds0 + (unsigned)wave * 8192u + (unsigned)lane * 16u;
+    const unsigned xr = lds0 + (unsigned)(6 * nh) * 8192u + (unsigned)lane * 16u;
+    static_for<2>([&](auto H) {
+        constexpr int h = decltype(H)::value;
+        // column pass (over j) of this wave's frequency row for accumulator elements [8 h, 8 h + 8): s[0..3] each
+        static_for<8>([&](auto RR) {
+            constexpr int r = 8 * h + decltype(RR)::value;
+            lds_write4(xw + (unsigned)decltype(RR)::value * 1024u, at6(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r]));
+        });
+        wait_barrier<0>();
+        // row pass (over i) + bias / residual / activation: this wave finishes elements [el0, el0 + nel) of the round
+        const int el0 = h == 0 ? (wi < 2 ? 2 * wi : wi + 2) : (wi < 4 ? wi : 2 * wi - 4);
+        const int nel = h == 0 ? (wi < 2 ? 2 : 1) : (wi < 4 ? 1 : 2);
+        for (int k = 0; k < nel; ++k) {
+            const int rr = el0 + k, r = 8 * h + rr;           // element r: tile (tx, ty) = ((r & 3) + 4 lh, r >> 2) of the block's 8 x 4
+            f32x4n S[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) S[i] = lds_read4(xr + (unsigned)i * 8192u + (unsigned)rr * 1024u);
+            const int oyb = oy0 + 4 * (r >> 2), oxb = ox0 + 4 * ((r & 3) + 4 * lh);
+            const int64_t mb = ((int64_t)n * ho + oyb) * wo + oxb;
+            float *ob = a.out.p + mb * ldo + co;
+            const float *rp = a.res_mode ? a.res.p + mb * ldr + co : nullptr;
+            f32x4n Y[4];                                      // Y[b] = (y[0][b], y[1][b], y[2][b], y[3][b])
+            Y[0] = at6(S[0].x, S[1].x, S[2].x, S[3].x, S[4].x, S[5].x);
+            Y[1] = at6(S[0].y, S[1].y, S[2].y, S[3].y, S[4].y, S[5].y);
+            Y[2] = at6(S[0].z, S[1].z, S[2].z, S[3].z, S[4].z, S[5].z);
+            Y[3] = at6(S[0].w, S[1].w, S[2].w, S[3].w, S[4].w, S[5].w);
+            float resv[16];
+            if (a.res_mode) {
+                static_for<16>([&](auto E) {
+                    constexpr int e = decltype(E)::value, dy = e >> 2, dx = e & 3;
+                    resv[e] = (oyb + dy < ho && oxb + dx < wo) ? rp[((int64_t)dy * wo + dx) * ldr] : 0.0f;
+                });
+            }
+            static_for<16>([&](auto E) {
+                constexpr int e = decltype(E)::value, dy = e >> 2, dx = e & 3;
+                const f32x4n yb = Y[dx];
+                float v = (dy == 0 ? yb.x : (dy == 1 ? yb.y : (dy == 2 ? yb.z : yb.w))) + bias;
+                if (a.res_mode == 1) v += resv[e];
+                v = apply_act(v, a.act, slope);
+                if (a.res_mode == 2) v += resv[e];
+                if constexpr (!(ABL & 8)) {
+                    if (oyb + dy < ho && oxb + dx < wo) ob[((int64_t)dy * wo + dx) * ldo] = v;
+                }
+            });
+        }
+        if constexpr (h == 0) wait_barrier<0>();              // the exchange area is rewritten by the second round
+    });
+}
+
+}  // namespace
+
+namespace csmconv {
+
+bool wino4_eligible(const ConvArgs &a) {
+    const int64_t bytes_in = (((int64_t)a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4;           // ONE sample (a launch takes as many samples as fit 2 GiB)
+    const int64_t bytes_w = (int64_t)(a.cout_g / 64) * (a.cin_g / 4) * (12 * kUW);
+    return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil == 1 && a.pad == 1 && a.groups == 1 && a.ksplit <= 1 && (a.cin_g & 31) == 0 &&
+           (a.cout_g & 63) == 0 && bytes_in < (1ll << 31) && bytes_w < (1ll << 31) && !(a.in.ld & 3) && !(((uintptr_t)a.in.p | (uintptr_t)a.w) & 15) &&
+           a.out.h == a.in.h && a.out.w == a.in.w;
+}
+
+static int launch_conv_wino4_chunk(const ConvArgs &a0, hipStream_t st) {
+    ConvArgs a = a0;
+    const int tiles_x = (a.out.w + kOW - 1) / kOW, tiles_y = (a.out.h + kOH - 1) / kOH;
+    a.m_tiles = tiles_x * tiles_y * a.out.n;
+    dim3 grid(a.m_tiles, a.cout_g / 64, 1);
+#ifdef CSM_WINO_DEV
+    const char *ve = getenv("CSM_WINO4_VARIANT");
+    const int variant = ve ? atoi(ve) : 0;
+    auto go = [&](auto kern) {
+        static KernelPrep prep;
+        (void)prep.ensure([&] { return prepare_kernel(kern, 768, kLds); });
+        kern<<<grid, 768, kLds, st>>>(a, tiles_x, tiles_y);
+        return csm::check_launch("k_conv_wino4");
+    };
+    switch (variant) {
+        case 1: return go(&k_conv_wino4<1>);
+        case 2: return go(&k_conv_wino4<2>);
+        case 4: return go(&k_conv_wino4<4>);
+        case 8: return go(&k_conv_wino4<8>);
+        case 3: return go(&k_conv_wino4<3>);
+        case 11: return go(&k_conv_wino4<11>);
+        default: break;
+    }
+#endif
+    static KernelPrep prep;
+    (void)prep.ensure([&] { return prepare_kernel(&k_conv_wino4<0>, 768, kLds); });
+    k_conv_wino4<0><<<grid, 768, kLds, st>>>(a, tiles_x, tiles_y);
+    return csm::check_launch("k_conv_wino4");
+}
+
+// 32-bit buffer descriptors: a launch covers as many SAMPLES as fit 2 GiB of input view; larger batches are split by sample (independent
+// work: the same bits whatever the split).  CSM_WINO_MAX_BYTES lowers the limit (tests).
+int launch_conv_wino4(const ConvArgs &a0, hipStream_t st) {
+    const char *le = getenv("CSM_WINO_MAX_BYTES");
+    const long long lv = le ? atoll(le) : 0;
+    const int64_t limit = lv > 0 ? (int64_t)lv : (int64_t)((1ll << 31) - 1);
+    const int64_t per_sample = (int64_t)a0.in.h * a0.in.w * a0.in.ld * 4;
+    int chunk = (int)(limit / (per_sample > 0 ? per_sample : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk >= a0.in.n) return launch_conv_wino4_chunk(a0, st);
+    for (int n0 = 0; n0 < a0.in.n; n0 += chunk) {
+        ConvArgs a = a0;
+        const int nn = a0.in.n - n0 < chunk ? a0.in.n - n0 : chunk;
+        a.in.n = a.out.n = nn; a.in.p = a0.in.p + (int64_t)n0 * a0.in.h * a0.in.w * a0.in.ld;
+        a.out.p = a0.out.p + (int64_t)n0 * a0.out.h * a0.out.w * a0.out.ld;
+        if (a0.res_mode) { a.res.n = nn; a.res.p = a0.res.p + (int64_t)n0 * a0.res.h * a0.res.w * a0.res.ld; }
+        a.M = nn * a.out.h * a.out.w;
+        const int rc = launch_conv_wino4_chunk(a, st);
+        if (rc) return rc;
+    }
+    return CSM_OK;
+}
+
+}  // namespace csmconv
