@@ -99,52 +99,12 @@ static_assert(kPH == 18 && kPW == 34 && kLds <= 160u * 1024u, "tile shape");
 // pixel entry of patch position (row r, column c) relative to the entry of (4 ty, 4 tx): compile-time part of psi
 __host__ __device__ constexpr int psi_k(int r, int c) { return ((c >> 1) & 1) * 324 + r * 18 + (c & 1) * 9 + (c >> 2); }
 
-// G: which pair of frequency rows the unit produces: 0 = {1, 2}, 1 = {3, 4}, 2 = {0, 5}
-template <int G>
-__device__ __forceinline__ void transform_unit(unsigned bx0, unsigned bx1, unsigned vdst) {
-    constexpr int r0 = G == 2 ? 0 : 1, r1 = G == 2 ? 6 : 5;
-    f32x2n T[2][6];
-    static_for<6>([&](auto C) {
-        constexpr int c = decltype(C)::value;
-        f32x2n d[6];
-        static_for<6>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            if constexpr (r >= r0 && r < r1) d[r] = lds_read2(((r >> 2) ? bx1 : bx0) + (unsigned)(psi_k(r, c) * 64));
-        });
-        if constexpr (G == 0) {
-            const float ax = fmaf(-4.0f, d[2].x, d[4].x), bx = fmaf(-4.0f, d[1].x, d[3].x);
-            const float ay = fmaf(-4.0f, d[2].y, d[4].y), by = fmaf(-4.0f, d[1].y, d[3].y);
-            T[0][c].x = ax + bx; T[1][c].x = ax - bx; T[0][c].y = ay + by; T[1][c].y = ay - by;
-        } else if constexpr (G == 1) {
-            const float cx = d[4].x - d[2].x, ex = d[3].x - d[1].x, cy = d[4].y - d[2].y, ey = d[3].y - d[1].y;
-            T[0][c].x = fmaf(2.0f, ex, cx); T[1][c].x = fmaf(-2.0f, ex, cx); T[0][c].y = fmaf(2.0f, ey, cy); T[1][c].y = fmaf(-2.0f, ey, cy);
-        } else {
-            T[0][c].x = fmaf(4.0f, d[0].x, fmaf(-5.0f, d[2].x, d[4].x)); T[1][c].x = fmaf(4.0f, d[1].x, fmaf(-5.0f, d[3].x, d[5].x));
-            T[0][c].y = fmaf(4.0f, d[0].y, fmaf(-5.0f, d[2].y, d[4].y)); T[1][c].y = fmaf(4.0f, d[1].y, fmaf(-5.0f, d[3].y, d[5].y));
-        }
-        if constexpr (c & 1) __builtin_amdgcn_sched_barrier(0);      // (keeps the loads of later columns from being hoisted: registers)
-    });
-    static_for<2>([&](auto RO) {
-        constexpr int ro = decltype(RO)::value;
-        constexpr int i = G == 0 ? 1 + ro : (G == 1 ? 3 + ro : (ro ? 5 : 0));
-        const T6 x = bt6(T[ro][0].x, T[ro][1].x, T[ro][2].x, T[ro][3].x, T[ro][4].x, T[ro][5].x);
-        const T6 y = bt6(T[ro][0].y, T[ro][1].y, T[ro][2].y, T[ro][3].y, T[ro][4].y, T[ro][5].y);
-        lds_write2(vdst + (unsigned)((i * 6 + 0) * 512), f32x2n{x.t0, y.t0});
-        lds_write2(vdst + (unsigned)((i * 6 + 1) * 512), f32x2n{x.t1, y.t1});
-        lds_write2(vdst + (unsigned)((i * 6 + 2) * 512), f32x2n{x.t2, y.t2});
-        lds_write2(vdst + (unsigned)((i * 6 + 3) * 512), f32x2n{x.t3, y.t3});
-        lds_write2(vdst + (unsigned)((i * 6 + 4) * 512), f32x2n{x.t4, y.t4});
-        lds_write2(vdst + (unsigned)((i * 6 + 5) * 512), f32x2n{x.t5, y.t5});
-    });
-}
-
 // ABL (development ablations, timing only -- results invalid): 1 = no DMA, 2 = no transform, 4 = no MFMA, 8 = no epilogue stores
 template <int ABL = 0>
 __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(64))) float lds[];   // [raw 0][raw 1][V 0][V 1][U: 12 private slots]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nh = wave / 6, wi = wave - 6 * nh;              // channel half, frequency row
-    const int tgroup = wave / 3, tg = wave - 3 * tgroup;      // transform group (active in steps s & 3 == tgroup), row pair of its units
     const int li = lane & 31, lh = lane >> 5;
     int mt, ntile, zz;
     block_to_tile(mt, ntile, zz, 1);                          // cout tile slowest: the blocks resident on an XCD share one 64-channel U panel
@@ -204,8 +164,23 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     const int tx = li & 7, ty = li >> 3;
     const unsigned ubase = lds0 + (unsigned)(ty * 72 + tx) * 64u;
     const unsigned bxA = ubase + (unsigned)((lh ^ (ty & 3)) << 4), bxB = ubase + (unsigned)((lh ^ ((ty + 1) & 3)) << 4);
-    const unsigned vlane = lds0 + kV0 + (unsigned)lh * 256u + (unsigned)li * 8u;     // + parity kVB + f 512
-    const unsigned va = vlane + (unsigned)(wi * 6) * 512u;
+    const unsigned vlane = lds0 + kV0 + (unsigned)lh * 256u + (unsigned)li * 8u + (unsigned)(wi * 6) * 512u;     // + parity kVB + j 512
+    // transform unit of this lane: frequency ROW wi of tile li, k-half lh, two channels.  ONE code path for all six rows:
+    //   t = fmaf(g, fmaf(c1, dP, dQ), fmaf(c2, dR, dS))      (wave-uniform coefficients, four window rows)
+    // rows 1..4: (P, Q, R, S) = (1, 3, 2, 4), c1 = c2 = del, (g, del) = (1, -4), (-1, -4), (2, -1), (-2, -1) -- bit for bit the contract's
+    //   a + b, a - b, fmaf(2, e, c), fmaf(-2, e, c): fmaf(+-1, x, y) IS y +- x, fmaf(-1, d2, d4) IS d4 - d2;
+    // rows 0 / 5:  g = 4, c1 = 0 with P = Q = 0 / 1 (fmaf(0, d, d) IS d for every finite d, signed zeros included), c2 = -5,
+    //   (R, S) = (2, 4) / (3, 5): the contract's fmaf(4, d0, fmaf(-5, d2, d4)) / fmaf(4, d1, fmaf(-5, d3, d5)).
+    const bool rowB = wi == 0 || wi == 5;
+    const float cg = rowB ? 4.0f : (wi == 1 ? 1.0f : (wi == 2 ? -1.0f : (wi == 3 ? 2.0f : -2.0f)));
+    const float c1 = rowB ? 0.0f : (wi <= 2 ? -4.0f : -1.0f), c2 = rowB ? -5.0f : c1;
+    unsigned rowb[4];                                          // the unit's window rows P, Q, R, S (without the step-dependent part)
+    {
+        const int rP = rowB ? (wi == 0 ? 0 : 1) : 1, rQ = rowB ? rP : 3, rR = rowB ? rP + 2 : 2, rS = rR + 2;
+        const int rr[4] = {rP, rQ, rR, rS};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rowb[k] = ((rr[k] >> 2) ? bxB : bxA) + (unsigned)(rr[k] * 18 * 64);
+    }
 
     f32x16 acc[6];
 #pragma unroll
@@ -213,64 +188,112 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     f32x4n Bq[3];
+    f32x2n A[6];
+    f32x2n D[4], T[6];                                         // transform: the window column in flight, the row-pass results
+    unsigned rowa[4], vdst = 0;
 
-    // the V image of step sn from the raw stage that holds it
-    auto transform = [&](int sn) {
+    // transform of step sn, cut into 12 slices (one per MFMA slot): slices 0..5 = row pass of window column c (and the loads of column
+    // c + 1), slices 6..11 = column pass (the contract's T6 on T[0..5], two channels) + the six ds_write_b64 into V[sn & 1]
+    auto xf_begin = [&](int sn) {
         if constexpr (!(ABL & 2)) {
             const unsigned e5 = (unsigned)((sn >> 1) & 1) << 5, add = (unsigned)((sn >> 2) & 1) * kRawB + (unsigned)(sn & 1) * 8u;
-            const unsigned b0 = (bxA ^ e5) + add, b1 = (bxB ^ e5) + add, vd = vlane + (unsigned)(sn & 1) * kVB;
-            if (tg == 0) transform_unit<0>(b0, b1, vd);
-            else if (tg == 1) transform_unit<1>(b0, b1, vd);
-            else transform_unit<2>(b0, b1, vd);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rowa[k] = (rowb[k] ^ e5) + add;
+            vdst = vlane + (unsigned)(sn & 1) * kVB;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) D[k] = lds_read2(rowa[k] + (unsigned)(psi_k(0, 0) * 64));
+        }
+    };
+    auto xf_slice = [&](auto M) {
+        constexpr int m = decltype(M)::value;
+        if constexpr (ABL & 2) {
+        } else if constexpr (m < 6) {
+            T[m].x = fmaf(cg, fmaf(c1, D[0].x, D[1].x), fmaf(c2, D[2].x, D[3].x));
+            T[m].y = fmaf(cg, fmaf(c1, D[0].y, D[1].y), fmaf(c2, D[2].y, D[3].y));
+            if constexpr (m < 5) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) D[k] = lds_read2(rowa[k] + (unsigned)(psi_k(0, m + 1) * 64));
+            }
+        } else if constexpr (m == 6) {
+            lds_write2(vdst + 0u * 512u, f32x2n{fmaf(4.0f, T[0].x, fmaf(-5.0f, T[2].x, T[4].x)), fmaf(4.0f, T[0].y, fmaf(-5.0f, T[2].y, T[4].y))});
+        } else if constexpr (m == 7) {
+            lds_write2(vdst + 5u * 512u, f32x2n{fmaf(4.0f, T[1].x, fmaf(-5.0f, T[3].x, T[5].x)), fmaf(4.0f, T[1].y, fmaf(-5.0f, T[3].y, T[5].y))});
+        } else if constexpr (m == 8) {                          // a -> D[0], b -> D[1]
+            D[0].x = fmaf(-4.0f, T[2].x, T[4].x); D[0].y = fmaf(-4.0f, T[2].y, T[4].y);
+            D[1].x = fmaf(-4.0f, T[1].x, T[3].x); D[1].y = fmaf(-4.0f, T[1].y, T[3].y);
+            lds_write2(vdst + 1u * 512u, f32x2n{D[0].x + D[1].x, D[0].y + D[1].y});
+        } else if constexpr (m == 9) {
+            lds_write2(vdst + 2u * 512u, f32x2n{D[0].x - D[1].x, D[0].y - D[1].y});
+        } else if constexpr (m == 10) {                         // c -> D[0], e -> D[1]
+            D[0].x = T[4].x - T[2].x; D[0].y = T[4].y - T[2].y;
+            D[1].x = T[3].x - T[1].x; D[1].y = T[3].y - T[1].y;
+            lds_write2(vdst + 3u * 512u, f32x2n{fmaf(2.0f, D[1].x, D[0].x), fmaf(2.0f, D[1].y, D[0].y)});
+        } else {
+            lds_write2(vdst + 4u * 512u, f32x2n{fmaf(-2.0f, D[1].x, D[0].x), fmaf(-2.0f, D[1].y, D[0].y)});
         }
     };
 
-    // ---- prologue ----
-    wait_barrier<0>();                                        // raw stage 0 and B(0) have landed (B(0) is read at the top of step 0)
-    issue_raw(1, 0, nstages > 1);
+    // ---- prologue: raw stage 0 -> V[0] (waves of channel half 0) and V[1] (half 1); B(0), A(0) into registers ----
+    wait_barrier<0>();                                        // raw stage 0 and B(0) have landed
+    issue_raw(1, 0, nstages > 1);                             // (the pieces steps -2 and -1 would have sent)
     issue_raw(1, 1, nstages > 1);
-    if (tgroup == 3) transform(0);
-    wait_barrier<2>();                                        // V[0] is complete (the two fetches just issued may stay in flight)
+    xf_begin(nh);
+    static_for<12>([&](auto M) { xf_slice(M); });
+#pragma unroll
+    for (int p = 0; p < 3; ++p) Bq[p] = lds_read4(ldsU + (unsigned)p * 1024u + voffU);
+    wait_barrier<2>();                                        // V[0], V[1] complete, B(0) read (the two fetches just issued may stay in flight)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) A[j] = lds_read2(vlane + (unsigned)j * 512u);
 
-    // ---- main loop: step s = 4 input channels.  Order inside a step: [transform of step s + 1's window, group s & 3] -> this wave's B
-    // fragments (landed: issued a step ago) and A fragments into registers -> the fetches of B(s + 1) into the slot just read and of one
-    // raw piece -> 12 MFMAs -> barrier ----
+    // ---- main loop: step s = 4 input channels = 12 MFMA slots per wave.  Beside the MFMAs: slots 0-2 send B(s + 1) into the private U
+    // slot (read into registers during step s - 1), slot 3 one raw piece; the waves of channel half s & 1 transform the window of step
+    // s + 2 into V[s & 1] (whose previous image, step s, is in everybody's registers since the barrier of step s - 1); from slot 6 on the
+    // operands of step s + 1 replace the dead ones -- V[(s + 1) & 1] was published by the barrier of step s - 1, B(s + 1) has landed
+    // (vmcnt) -- so that the first MFMA of the next step can issue right behind the barrier ----
+    auto step = [&](auto Q, int s) {
+        constexpr int q = decltype(Q)::value;
+        const bool xf = nh == (q & 1) && s + 2 < nsteps;      // (wave-uniform: scalar branches)
+        if (xf) xf_begin(s + 2);
+        const unsigned vnext = vlane + (unsigned)((q + 1) & 1) * kVB;
+        static_for<12>([&](auto M) {
+            constexpr int m = decltype(M)::value, half = m / 6, t = (m % 6) / 3, j = 3 * half + m % 3;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 4)) {
+                const f32x4n bf = Bq[j >> 1];
+                const float bv = (j & 1) ? (t ? bf.w : bf.z) : (t ? bf.y : bf.x);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(t ? A[j].y : A[j].x, bv, acc[j], 0, 0, 0);
+            }
+            if constexpr (m < 3) {
+                if constexpr (!(ABL & 1)) dma16s(s + 1 < nsteps ? voffU : kOob, rb, u_src + (unsigned)m * 1024u, ldsU + (unsigned)m * 1024u);
+                if constexpr (m == 2) u_src += 12u * kUW;
+            } else if constexpr (m == 3) {
+                // raw stage r = (s + 6) >> 2: its buffer was last read in step 4 r - 7 and is first read in step 4 r - 2 (published by
+                // the barrier of step 4 r - 3): one piece in each of the steps 4 r - 6 .. 4 r - 3
+                issue_raw((s + 6) >> 2, (q + 2) & 3, ((s + 6) >> 2) < nstages);
+            }
+            if (xf) xf_slice(M);
+            if constexpr (m == 6) {
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");       // B(s + 1) has landed (the raw piece of slot 3 may stay in flight)
+                Bq[0] = lds_read4(ldsU + voffU);
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) A[jj] = lds_read2(vnext + (unsigned)jj * 512u);
+            } else if constexpr (m == 10) {
+                Bq[1] = lds_read4(ldsU + 1024u + voffU);
+            } else if constexpr (m == 11) {
+                Bq[2] = lds_read4(ldsU + 2048u + voffU);
+#pragma unroll
+                for (int jj = 3; jj < 6; ++jj) A[jj] = lds_read2(vnext + (unsigned)jj * 512u);
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        // everybody: V[s + 2] written, the operands of step s + 1 read, this step's raw piece landed
+        wait_barrier<0>();
+    };
     for (int s4 = 0; s4 < nsteps; s4 += 4) {
         static_for<4>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             const int s = s4 + q;
-            if (tgroup == q && s + 1 < nsteps) transform(s + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // B(s) and this wave's older raw pieces have landed
-#pragma unroll
-            for (int p = 0; p < 3; ++p) Bq[p] = lds_read4(ldsU + (unsigned)p * 1024u + voffU);
-            f32x2n A[6];
-            const unsigned vs = va + (unsigned)(q & 1) * kVB;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) A[j] = lds_read2(vs + (unsigned)j * 512u);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            issue_u(s + 1 < nsteps);                          // B(s + 1) -> the slot whose contents are in registers now
-            // raw stage r = (s + 5) >> 2: its buffer was last read by the transform at the top of step 4 r - 6 (released by that step's
-            // barrier) and is first read at the top of step 4 r - 1 (published by the barrier of step 4 r - 2, whose top waits for the
-            // pieces of step 4 r - 3): two pieces in step 4 r - 5, one each in steps 4 r - 4 and 4 r - 3, none in step 4 r - 6
-            if constexpr (q != 2) {
-                const int stg = (s + 5) >> 2;
-                if constexpr (q == 3) { issue_raw(stg, 0, stg < nstages); issue_raw(stg, 1, stg < nstages); }
-                else issue_raw(stg, q + 2, stg < nstages);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(ABL & 4)) {
-                static_for<12>([&](auto M) {
-                    constexpr int m = decltype(M)::value, half = m / 6, t = (m % 6) / 3, j = 3 * half + m % 3;
-                    const f32x4n bf = Bq[j >> 1];
-                    const float bv = (j & 1) ? (t ? bf.w : bf.z) : (t ? bf.y : bf.x);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(t ? A[j].y : A[j].x, bv, acc[j], 0, 0, 0);
-                });
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // everybody: V[s + 1] written, V[s] and the raw stage read; the raw pieces waited for at the top of this step are published
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            step(Q, s);
         });
     }
     wait_barrier<0>();        // the trailing (dead) fetches have landed for every wave: raw / V / U become the exchange area
