@@ -44,10 +44,16 @@ __device__ __forceinline__ f32x4n lds_read4(unsigned byte_addr) { return *(lds_f
 __device__ __forceinline__ f32x2n lds_read2(unsigned byte_addr) { return *(lds_f2_ptr)(size_t)byte_addr; }
 __device__ __forceinline__ void lds_write4(unsigned byte_addr, f32x4n v) { *(lds_f4_ptr)(size_t)byte_addr = v; }
 __device__ __forceinline__ void lds_write2(unsigned byte_addr, f32x2n v) { *(lds_f2_ptr)(size_t)byte_addr = v; }
+typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2n *lds_u2_ptr;
+__device__ __forceinline__ u32x2n lds_read2u(unsigned byte_addr) { return *(lds_u2_ptr)(size_t)byte_addr; }
+__device__ __forceinline__ void lds_write2u(unsigned byte_addr, u32x2n v) { *(lds_u2_ptr)(size_t)byte_addr = v; }
 
 // LDS-DMA piece with a scalar byte offset on the global side: 64 lanes x 16 B -> LDS [lds_byte_addr, +1 KB)
 __device__ __forceinline__ void dma16s(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_byte_addr) {
     unsigned keep;
+    soff = __builtin_amdgcn_readfirstlane(soff);              // (wave-uniform by construction; a literal constant is not a valid soffset operand)
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory");
 }
@@ -86,23 +92,25 @@ __device__ __forceinline__ f32x4n at6(float m0, float m1, float m2, float m3, fl
 constexpr int kTX = 8, kTY = 4;                              // Winograd tiles of a block
 constexpr int kOW = 4 * kTX, kOH = 4 * kTY;                  // 32 x 16 output pixels
 constexpr int kPW = kOW + 2, kPH = kOH + 2;                  // 34 x 18 patch pixels
-constexpr int kPsi = 2 * 18 * 18;                            // 648 pixel entries (64 B each) of a 16-channel stage
-constexpr int kRawPieces = (kPsi * 4 + 63) / 64;             // 41 DMA pieces
-constexpr unsigned kRawB = kRawPieces * 1024u;               // 41 984 B per stage
+constexpr int kPsi = 2 * 18 * 18;                            // 648 pixel entries (32 B = 8 channels each) of a raw stage
+constexpr int kRawPieces = (kPsi * 2 + 63) / 64;             // 21 DMA pieces
+constexpr unsigned kRawB = kRawPieces * 1024u;               // 21 504 B per stage
 constexpr unsigned kVB = 36u * 512u;                         // 18 432 B: V[f][k-half][32 tiles][2]
-constexpr unsigned kV0 = 2u * kRawB, kU0 = kV0 + 2u * kVB;   // 83 968, 120 832
-constexpr unsigned kUW = 3072u;                              // a wave's private U slot (three pieces)
-constexpr unsigned kLds = kU0 + 12u * kUW;                   // 157 696 B
+constexpr unsigned kV0 = 2u * kRawB, kU0 = kV0 + 2u * kVB;   // 43 008, 79 872
+constexpr unsigned kUW = 3072u;                              // a wave's U slot (three pieces); two slots per wave
+constexpr unsigned kLds = kU0 + 24u * kUW;                   // 153 600 B (+ 6 KB: the raw loader's offsets)
+constexpr unsigned kLdsAll = kLds + 768u * 8u;
 constexpr unsigned kOob = 0x80000000u;
-static_assert(kPH == 18 && kPW == 34 && kLds <= 160u * 1024u, "tile shape");
+static_assert(kPH == 18 && kPW == 34 && kLdsAll <= 160u * 1024u, "tile shape");
 
 // pixel entry of patch position (row r, column c) relative to the entry of (4 ty, 4 tx): compile-time part of psi
 __host__ __device__ constexpr int psi_k(int r, int c) { return ((c >> 1) & 1) * 324 + r * 18 + (c & 1) * 9 + (c >> 2); }
 
-// ABL (development ablations, timing only -- results invalid): 1 = no DMA, 2 = no transform, 4 = no MFMA, 8 = no epilogue stores
+// ABL (development ablations, timing only -- results invalid): 1 = no DMA, 2 = no transform, 4 = no MFMA, 8 = no epilogue stores,
+// 16 = no barrier in the main loop, 32 = no operand reads (A / B fragments) in the main loop
 template <int ABL = 0>
 __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, int tiles_y) {
-    extern __shared__ __attribute__((aligned(64))) float lds[];   // [raw 0][raw 1][V 0][V 1][U: 12 private slots]
+    extern __shared__ __attribute__((aligned(64))) float lds[];   // [raw 0][raw 1][V 0][V 1][U: 12 waves x 2 slots]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nh = wave / 6, wi = wave - 6 * nh;              // channel half, frequency row
     const int li = lane & 31, lh = lane >> 5;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     block_to_tile(mt, ntile, zz, 1);                          // cout tile slowest: the blocks resident on an XCD share one 64-channel U panel
     const int btx = mt % tiles_x, bty = (mt / tiles_x) % tiles_y, n = mt / (tiles_x * tiles_y);
     const int ho = a.out.h, wo = a.out.w;
-    const int nsteps = a.cin_g >> 2, nstages = nsteps >> 2;
+    const int nsteps = a.cin_g >> 2, nstages = nsteps >> 1;   // a raw stage = 8 channels = 2 steps
     const int oy0 = bty * kOH, ox0 = btx * kOW;
 
     i32x4 ra, rb;
@@ -118,53 +126,62 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
         uint64_t pa = (uint64_t)a.in.p, pb = (uint64_t)a.w;
         unsigned na = (unsigned)((((int64_t)a.in.n * a.in.h * a.in.w - 1) * a.in.ld + a.in.c) * 4);
         unsigned nb = (unsigned)((int64_t)(a.cout_g / 64) * nsteps * (12 * kUW));
-        ra = i32x4{(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)na, 0x00020000};
-        rb = i32x4{(int)(unsigned)pb, (int)(unsigned)(pb >> 32), (int)nb, 0x00020000};
+        auto sg = [](unsigned v) { return (int)__builtin_amdgcn_readfirstlane(v); };      // (pins the descriptors to SGPRs)
+        ra = i32x4{sg((unsigned)pa), sg((unsigned)(pa >> 32)), sg(na), 0x00020000};
+        rb = i32x4{sg((unsigned)pb), sg((unsigned)(pb >> 32)), sg(nb), 0x00020000};
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
-    // ---- this wave's U stream: step s at ((ntile nsteps + s) 12 + wave) 3 KB ----
+    // ---- this wave's U stream: step s at ((ntile nsteps + s) 12 + wave) 3 KB -> slot s & 1 ----
     const unsigned voffU = (unsigned)lane * 16u;
     unsigned u_src = (unsigned)((ntile * nsteps) * 12 + wave) * kUW;         // next step to fetch
-    const unsigned ldsU = lds0 + kU0 + (unsigned)wave * kUW;
-    auto issue_u = [&](bool live) {
+    const unsigned ldsU = lds0 + kU0 + (unsigned)wave * (2u * kUW);
+    const unsigned blane = ldsU + voffU;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {                             // B(0), B(1): scalar addresses, out before anything else is computed
         if constexpr (!(ABL & 1)) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) dma16s(live ? voffU : kOob, rb, u_src + (unsigned)p * 1024u, ldsU + (unsigned)p * 1024u);
+            dma16s(voffU, rb, u_src + (unsigned)p * 1024u, ldsU + (unsigned)p * 1024u);
+            dma16s(nsteps > 1 ? voffU : kOob, rb, u_src + 12u * kUW + (unsigned)p * 1024u, ldsU + kUW + (unsigned)p * 1024u);
         }
-        u_src += 12u * kUW;
-    };
-    issue_u(true);                                            // B(0): scalar addresses, goes out before anything else is computed
+    }
+    u_src += 24u * kUW;
 
-    // ---- raw patch loader: wave w owns pieces w, w + 12, w + 24, w + 36 of a stage ----
-    unsigned offP[4];
+    // ---- raw patch loader: wave w owns pieces w and w + 12 of a stage.  Granule g = 2 psi + s' sits at LDS position g; it holds channels
+    // [4 slot, 4 slot + 4) of the stage's eight, slot = s' ^ ((row >> 2) & 1) ----
+    // (the two global offsets of a lane live in LDS behind the U slots, 8 B per lane: no register is free for them in the main loop, and
+    // a scratch reload would put a vmcnt(0) in front of every raw fetch)
+    const unsigned offL = lds0 + kLds + (unsigned)tid * 8u;
+    unsigned offP[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
         int pp = wave + 12 * q;
         if (pp > kRawPieces - 1) pp = kRawPieces - 1;         // (a piece past the end repeats the last one: same bytes, same place)
-        const int g = 64 * pp + lane;                         // granule
-        const int psi = g >> 2, sl = g & 3;
+        const int g = 64 * pp + lane;
+        const int psi = g >> 1, sl = g & 1;
         const int crh = psi / 324, rem = psi - crh * 324, R = rem / 18, r2 = rem - R * 18, c1 = r2 / 9, cq = r2 - c1 * 9;
         const int C = 4 * cq + 2 * crh + c1;
-        const int slot = sl ^ ((R >> 2) & 3);
+        const int slot = sl ^ ((R >> 2) & 1);
         const int iy = oy0 - 1 + R, ix = ox0 - 1 + C;
         const bool v = psi < kPsi && C < kPW && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
         offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
     }
-    auto issue_raw = [&](int stage, int q, bool live) {       // piece q of this wave, 16-channel stage `stage` -> raw buffer stage & 1
+    lds_write2u(offL, u32x2n{offP[0], offP[1]});
+    auto issue_raw_off = [&](int stage, auto QQ, unsigned off, bool live) __attribute__((always_inline)) {     // piece q of this wave, 8-channel stage `stage` -> raw buffer stage & 1
+        constexpr int q = decltype(QQ)::value;
         if constexpr (!(ABL & 1)) {
             int pp = wave + 12 * q;
             if (pp > kRawPieces - 1) pp = kRawPieces - 1;
-            dma16s(live ? offP[q] : kOob, ra, (unsigned)stage * 64u, lds0 + (unsigned)(stage & 1) * kRawB + (unsigned)pp * 1024u);
+            dma16s(live ? off : kOob, ra, (unsigned)stage * 32u, lds0 + (unsigned)(stage & 1) * kRawB + (unsigned)pp * 1024u);
         }
     };
-#pragma unroll
-    for (int q = 0; q < 4; ++q) issue_raw(0, q, true);
+    issue_raw_off(0, ic<0>{}, offP[0], true); issue_raw_off(0, ic<1>{}, offP[1], true);
+    issue_raw_off(1, ic<0>{}, offP[0], nstages > 1); issue_raw_off(1, ic<1>{}, offP[1], nstages > 1);
 
     // ---- fragment / unit addresses ----
     const int tx = li & 7, ty = li >> 3;
-    const unsigned ubase = lds0 + (unsigned)(ty * 72 + tx) * 64u;
-    const unsigned bxA = ubase + (unsigned)((lh ^ (ty & 3)) << 4), bxB = ubase + (unsigned)((lh ^ ((ty + 1) & 3)) << 4);
+    const unsigned ubase = lds0 + (unsigned)(ty * 72 + tx) * 32u + (unsigned)nh * 8u;      // (this wave transforms steps sn = nh mod 2: half nh)
+    const unsigned bxA = ubase + (unsigned)((lh ^ (ty & 1)) << 4), bxB = ubase + (unsigned)((lh ^ ((ty + 1) & 1)) << 4);
     const unsigned vlane = lds0 + kV0 + (unsigned)lh * 256u + (unsigned)li * 8u + (unsigned)(wi * 6) * 512u;     // + parity kVB + j 512
+    const unsigned vdst = vlane + (unsigned)nh * kVB;
     // transform unit of this lane: frequency ROW wi of tile li, k-half lh, two channels.  ONE code path for all six rows:
     //   t = fmaf(g, fmaf(c1, dP, dQ), fmaf(c2, dR, dS))      (wave-uniform coefficients, four window rows)
     // rows 1..4: (P, Q, R, S) = (1, 3, 2, 4), c1 = c2 = del, (g, del) = (1, -4), (-1, -4), (2, -1), (-2, -1) -- bit for bit the contract's
@@ -174,12 +191,12 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     const bool rowB = wi == 0 || wi == 5;
     const float cg = rowB ? 4.0f : (wi == 1 ? 1.0f : (wi == 2 ? -1.0f : (wi == 3 ? 2.0f : -2.0f)));
     const float c1 = rowB ? 0.0f : (wi <= 2 ? -4.0f : -1.0f), c2 = rowB ? -5.0f : c1;
-    unsigned rowb[4];                                          // the unit's window rows P, Q, R, S (without the step-dependent part)
+    unsigned rowb[4];                                          // the unit's window rows P, Q, R, S in raw buffer 0
     {
         const int rP = rowB ? (wi == 0 ? 0 : 1) : 1, rQ = rowB ? rP : 3, rR = rowB ? rP + 2 : 2, rS = rR + 2;
         const int rr[4] = {rP, rQ, rR, rS};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rowb[k] = ((rr[k] >> 2) ? bxB : bxA) + (unsigned)(rr[k] * 18 * 64);
+        for (int k = 0; k < 4; ++k) rowb[k] = ((rr[k] >> 2) ? bxB : bxA) + (unsigned)(rr[k] * 18 * 32);
     }
 
     f32x16 acc[6];
@@ -189,72 +206,73 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     f32x4n Bq[3];
     f32x2n A[6];
-    f32x2n D[4], T[6];                                         // transform: the window column in flight, the row-pass results
-    unsigned rowa[4], vdst = 0;
+    f32x2n D[2][4], T[6];                                      // transform: two window columns in flight, the row-pass results
 
-    // transform of step sn, cut into 12 slices (one per MFMA slot): slices 0..5 = row pass of window column c (and the loads of column
-    // c + 1), slices 6..11 = column pass (the contract's T6 on T[0..5], two channels) + the six ds_write_b64 into V[sn & 1]
-    auto xf_begin = [&](int sn) {
-        if constexpr (!(ABL & 2)) {
-            const unsigned e5 = (unsigned)((sn >> 1) & 1) << 5, add = (unsigned)((sn >> 2) & 1) * kRawB + (unsigned)(sn & 1) * 8u;
+    // transform of a step out of raw buffer RB, cut into 12 slices (one per MFMA slot): slices 0..5 = row pass of window column c (and
+    // the loads of column c + 2: a load has two slots to return), slices 6..11 = column pass (the contract's T6 on T[0..5], two channels)
+    // + the six ds_write_b64 into V[nh]
+    auto xf_load = [&](auto RB, auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        constexpr unsigned imm = (unsigned)decltype(RB)::value * kRawB + (unsigned)(psi_k(0, c) * 32);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rowa[k] = (rowb[k] ^ e5) + add;
-            vdst = vlane + (unsigned)(sn & 1) * kVB;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) D[k] = lds_read2(rowa[k] + (unsigned)(psi_k(0, 0) * 64));
-        }
+        for (int k = 0; k < 4; ++k) D[c & 1][k] = lds_read2(rowb[k] + imm);
     };
-    auto xf_slice = [&](auto M) {
+    auto xf_begin = [&](auto RB) __attribute__((always_inline)) {
+        if constexpr (!(ABL & 2)) { xf_load(RB, ic<0>{}); xf_load(RB, ic<1>{}); }
+    };
+    auto xf_slice = [&](auto RB, auto M) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value;
         if constexpr (ABL & 2) {
         } else if constexpr (m < 6) {
-            T[m].x = fmaf(cg, fmaf(c1, D[0].x, D[1].x), fmaf(c2, D[2].x, D[3].x));
-            T[m].y = fmaf(cg, fmaf(c1, D[0].y, D[1].y), fmaf(c2, D[2].y, D[3].y));
-            if constexpr (m < 5) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) D[k] = lds_read2(rowa[k] + (unsigned)(psi_k(0, m + 1) * 64));
-            }
+            constexpr int b = m & 1;
+            T[m].x = fmaf(cg, fmaf(c1, D[b][0].x, D[b][1].x), fmaf(c2, D[b][2].x, D[b][3].x));
+            T[m].y = fmaf(cg, fmaf(c1, D[b][0].y, D[b][1].y), fmaf(c2, D[b][2].y, D[b][3].y));
+            if constexpr (m < 4) xf_load(RB, ic<m + 2>{});
         } else if constexpr (m == 6) {
             lds_write2(vdst + 0u * 512u, f32x2n{fmaf(4.0f, T[0].x, fmaf(-5.0f, T[2].x, T[4].x)), fmaf(4.0f, T[0].y, fmaf(-5.0f, T[2].y, T[4].y))});
         } else if constexpr (m == 7) {
             lds_write2(vdst + 5u * 512u, f32x2n{fmaf(4.0f, T[1].x, fmaf(-5.0f, T[3].x, T[5].x)), fmaf(4.0f, T[1].y, fmaf(-5.0f, T[3].y, T[5].y))});
-        } else if constexpr (m == 8) {                          // a -> D[0], b -> D[1]
-            D[0].x = fmaf(-4.0f, T[2].x, T[4].x); D[0].y = fmaf(-4.0f, T[2].y, T[4].y);
-            D[1].x = fmaf(-4.0f, T[1].x, T[3].x); D[1].y = fmaf(-4.0f, T[1].y, T[3].y);
-            lds_write2(vdst + 1u * 512u, f32x2n{D[0].x + D[1].x, D[0].y + D[1].y});
+        } else if constexpr (m == 8) {                          // a -> D[0][0], b -> D[0][1]
+            D[0][0].x = fmaf(-4.0f, T[2].x, T[4].x); D[0][0].y = fmaf(-4.0f, T[2].y, T[4].y);
+            D[0][1].x = fmaf(-4.0f, T[1].x, T[3].x); D[0][1].y = fmaf(-4.0f, T[1].y, T[3].y);
+            lds_write2(vdst + 1u * 512u, f32x2n{D[0][0].x + D[0][1].x, D[0][0].y + D[0][1].y});
         } else if constexpr (m == 9) {
-            lds_write2(vdst + 2u * 512u, f32x2n{D[0].x - D[1].x, D[0].y - D[1].y});
-        } else if constexpr (m == 10) {                         // c -> D[0], e -> D[1]
-            D[0].x = T[4].x - T[2].x; D[0].y = T[4].y - T[2].y;
-            D[1].x = T[3].x - T[1].x; D[1].y = T[3].y - T[1].y;
-            lds_write2(vdst + 3u * 512u, f32x2n{fmaf(2.0f, D[1].x, D[0].x), fmaf(2.0f, D[1].y, D[0].y)});
+            lds_write2(vdst + 2u * 512u, f32x2n{D[0][0].x - D[0][1].x, D[0][0].y - D[0][1].y});
+        } else if constexpr (m == 10) {                         // c -> D[0][0], e -> D[0][1]
+            D[0][0].x = T[4].x - T[2].x; D[0][0].y = T[4].y - T[2].y;
+            D[0][1].x = T[3].x - T[1].x; D[0][1].y = T[3].y - T[1].y;
+            lds_write2(vdst + 3u * 512u, f32x2n{fmaf(2.0f, D[0][1].x, D[0][0].x), fmaf(2.0f, D[0][1].y, D[0][0].y)});
         } else {
-            lds_write2(vdst + 4u * 512u, f32x2n{fmaf(-2.0f, D[1].x, D[0].x), fmaf(-2.0f, D[1].y, D[0].y)});
+            lds_write2(vdst + 4u * 512u, f32x2n{fmaf(-2.0f, D[0][1].x, D[0][0].x), fmaf(-2.0f, D[0][1].y, D[0][0].y)});
         }
     };
 
     // ---- prologue: raw stage 0 -> V[0] (waves of channel half 0) and V[1] (half 1); B(0), A(0) into registers ----
-    wait_barrier<0>();                                        // raw stage 0 and B(0) have landed
-    issue_raw(1, 0, nstages > 1);                             // (the pieces steps -2 and -1 would have sent)
-    issue_raw(1, 1, nstages > 1);
-    xf_begin(nh);
-    static_for<12>([&](auto M) { xf_slice(M); });
+    wait_barrier<0>();                                        // raw stages 0, 1 and B(0), B(1) have landed
+    xf_begin(ic<0>{});
+    static_for<12>([&](auto M) { xf_slice(ic<0>{}, M); });
 #pragma unroll
-    for (int p = 0; p < 3; ++p) Bq[p] = lds_read4(ldsU + (unsigned)p * 1024u + voffU);
-    wait_barrier<2>();                                        // V[0], V[1] complete, B(0) read (the two fetches just issued may stay in flight)
+    for (int p = 0; p < 3; ++p) Bq[p] = lds_read4(blane + (unsigned)p * 1024u);
+    wait_barrier<0>();                                        // V[0], V[1] complete, B(0) read
 #pragma unroll
     for (int j = 0; j < 6; ++j) A[j] = lds_read2(vlane + (unsigned)j * 512u);
+    wait_barrier<0>();                                        // A(0) read by everybody: step 0 may overwrite V[0]
 
-    // ---- main loop: step s = 4 input channels = 12 MFMA slots per wave.  Beside the MFMAs: slots 0-2 send B(s + 1) into the private U
-    // slot (read into registers during step s - 1), slot 3 one raw piece; the waves of channel half s & 1 transform the window of step
-    // s + 2 into V[s & 1] (whose previous image, step s, is in everybody's registers since the barrier of step s - 1); from slot 6 on the
-    // operands of step s + 1 replace the dead ones -- V[(s + 1) & 1] was published by the barrier of step s - 1, B(s + 1) has landed
-    // (vmcnt) -- so that the first MFMA of the next step can issue right behind the barrier ----
-    auto step = [&](auto Q, int s) {
+    // ---- main loop: step s = 4 input channels = 12 MFMA slots per wave.  Beside the MFMAs: slots 0-2 send B(s + 2) into U slot s & 1
+    // (whose contents, B(s), are in registers since step s - 1); slots 3, 4 of the EVEN steps send this wave's two pieces of raw stage
+    // s / 2 + 2 (its buffer was last read in step s - 1 and is first read in step s + 2; the pieces are waited for in step s + 1 and
+    // published by that step's barrier); the waves of channel half s & 1 transform the window of step s + 2 into V[s & 1] (whose
+    // previous image, step s, is in everybody's registers since the barrier of step s - 1); from slot 6 on the operands of step s + 1
+    // replace the dead ones -- V[(s + 1) & 1] was published by the barrier of step s - 1, B(s + 1) was sent a step ago (vmcnt leaves only
+    // this step's fetches in flight).  The barrier itself waits for LDS traffic only ----
+    // XF: this wave transforms in this step (ONE wave-uniform branch per step selects the variant: straight-line slots, so that the
+    // compiler's wait counts stay exact -- a branch per slice made every slice drain the LDS queue)
+    auto step = [&](auto Q, auto XF, int s) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value;
-        const bool xf = nh == (q & 1) && s + 2 < nsteps;      // (wave-uniform: scalar branches)
-        if (xf) xf_begin(s + 2);
-        const unsigned vnext = vlane + (unsigned)((q + 1) & 1) * kVB;
+        constexpr bool xf = decltype(XF)::value;
+        constexpr int rbuf = ((q + 2) >> 1) & 1;               // raw buffer of step s + 2: stage (s + 2) >> 1
+        unsigned offq0 = 0u, offq1 = 0u;
+        if constexpr (xf) xf_begin(ic<rbuf>{});
         static_for<12>([&](auto M) {
             constexpr int m = decltype(M)::value, half = m / 6, t = (m % 6) / 3, j = 3 * half + m % 3;
             __builtin_amdgcn_sched_barrier(0);
@@ -264,90 +282,130 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(t ? A[j].y : A[j].x, bv, acc[j], 0, 0, 0);
             }
             if constexpr (m < 3) {
-                if constexpr (!(ABL & 1)) dma16s(s + 1 < nsteps ? voffU : kOob, rb, u_src + (unsigned)m * 1024u, ldsU + (unsigned)m * 1024u);
+                if constexpr (!(ABL & 1)) dma16s(s + 2 < nsteps ? voffU : kOob, rb, u_src + (unsigned)m * 1024u, ldsU + (unsigned)(q & 1) * kUW + (unsigned)m * 1024u);
                 if constexpr (m == 2) u_src += 12u * kUW;
-            } else if constexpr (m == 3) {
-                // raw stage r = (s + 6) >> 2: its buffer was last read in step 4 r - 7 and is first read in step 4 r - 2 (published by
-                // the barrier of step 4 r - 3): one piece in each of the steps 4 r - 6 .. 4 r - 3
-                issue_raw((s + 6) >> 2, (q + 2) & 3, ((s + 6) >> 2) < nstages);
+            } else if constexpr (m == 3 && (q & 1) == 0) {
+                const u32x2n o2 = lds_read2u(offL);           // (used in slots 4 and 5)
+                offq0 = o2.x; offq1 = o2.y;
+            } else if constexpr (m == 4 && (q & 1) == 0) {
+                issue_raw_off((s >> 1) + 2, ic<0>{}, offq0, (s >> 1) + 2 < nstages);
+            } else if constexpr (m == 5 && (q & 1) == 0) {
+                issue_raw_off((s >> 1) + 2, ic<1>{}, offq1, (s >> 1) + 2 < nstages);
             }
-            if (xf) xf_slice(M);
-            if constexpr (m == 6) {
-                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");       // B(s + 1) has landed (the raw piece of slot 3 may stay in flight)
-                Bq[0] = lds_read4(ldsU + voffU);
+            if constexpr (xf) xf_slice(ic<rbuf>{}, M);
+            if constexpr (ABL & 32) {
+            } else if constexpr (m == 6) {
+                // everything sent before this step has landed: B(s + 1), and the raw pieces of step s - 1
+                if constexpr ((q & 1) == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                Bq[0] = lds_read4(blane + (unsigned)((q + 1) & 1) * kUW);
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) A[jj] = lds_read2(vnext + (unsigned)jj * 512u);
+                for (int jj = 0; jj < 3; ++jj) A[jj] = lds_read2(vlane + (unsigned)((q + 1) & 1) * kVB + (unsigned)jj * 512u);
             } else if constexpr (m == 10) {
-                Bq[1] = lds_read4(ldsU + 1024u + voffU);
+                Bq[1] = lds_read4(blane + (unsigned)((q + 1) & 1) * kUW + 1024u);
             } else if constexpr (m == 11) {
-                Bq[2] = lds_read4(ldsU + 2048u + voffU);
+                Bq[2] = lds_read4(blane + (unsigned)((q + 1) & 1) * kUW + 2048u);
 #pragma unroll
-                for (int jj = 3; jj < 6; ++jj) A[jj] = lds_read2(vnext + (unsigned)jj * 512u);
+                for (int jj = 3; jj < 6; ++jj) A[jj] = lds_read2(vlane + (unsigned)((q + 1) & 1) * kVB + (unsigned)jj * 512u);
             }
         });
         __builtin_amdgcn_sched_barrier(0);
-        // everybody: V[s + 2] written, the operands of step s + 1 read, this step's raw piece landed
-        wait_barrier<0>();
+        // everybody: V[s + 2] written, the operands of step s + 1 read, the raw pieces waited for in slot 6 landed
+        if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
-    for (int s4 = 0; s4 < nsteps; s4 += 4) {
+    // the whole loop exists twice, once per channel half (= the parity of the steps in which the wave transforms): inside a copy every
+    // step is straight-line code.  The last four steps are peeled: their steps 2 and 3 have no step s + 2 to prepare
+    auto run = [&](auto ROLE) __attribute__((always_inline)) {
+        constexpr int role = decltype(ROLE)::value;
+        int s4 = 0;
+        for (; s4 + 4 < nsteps; s4 += 4)
+            static_for<4>([&](auto Q) { step(Q, std::integral_constant<bool, (decltype(Q)::value & 1) == role>{}, s4 + decltype(Q)::value); });
         static_for<4>([&](auto Q) {
-            constexpr int q = decltype(Q)::value;
-            const int s = s4 + q;
-            step(Q, s);
+            step(Q, std::integral_constant<bool, (decltype(Q)::value & 1) == role && decltype(Q)::value < 2>{}, s4 + decltype(Q)::value);
         });
-    }
+    };
+    if (nh == 0) run(ic<0>{}); else run(ic<1>{});
     wait_barrier<0>();        // the trailing (dead) fetches have landed for every wave: raw / V / U become the exchange area
 
-    // ---- epilogue ----
-    const int co = ntile * 64 + 32 * nh + li;
+    // ---- epilogue.  Everything it needs is derived from `lane_e`, which the compiler cannot see through: the bias / slope loads and the
+    // output addresses would otherwise be hoisted above the main loop, where every register is taken ----
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e) :: "memory");
+    const int le_i = lane_e & 31, le_h = lane_e >> 5;
+    const int co = ntile * 64 + 32 * nh + le_i;
     const float bias = a.bias ? a.bias[co] : 0.0f;
     const float slope = a.slope ? a.slope[co] : 0.0f;
-    const int64_t ldo = a.out.ld, ldr = a.res.ld;
-    const unsigned xw = lds0 + (unsigned)wave * 8192u + (unsigned)lane * 16u;
-    const unsigned xr = lds0 + (unsigned)(6 * nh) * 8192u + (unsigned)lane * 16u;
+    const int ldo = a.out.ld, ldr = a.res.ld;
+    const unsigned xw = lds0 + (unsigned)wave * 8192u + (unsigned)lane_e * 16u;
+    const unsigned xr = lds0 + (unsigned)(6 * nh) * 8192u + (unsigned)lane_e * 16u;
+    // Stores and residual loads go through range-checked buffer descriptors of THIS sample's output / residual view: a pixel outside the
+    // map gets the offset 2^31 and is dropped (loads return 0) by the hardware -- no divergent control flow, one code path for
+    // interior and ragged block tiles
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out.p + (int64_t)n * ho * wo * ldo, 0,
+                                                                         (int)((((int64_t)ho * wo - 1) * ldo + a.out.c) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(a.res_mode ? a.res.p + (int64_t)n * ho * wo * ldr : a.out.p, 0,
+                                                                          a.res_mode ? (int)((((int64_t)ho * wo - 1) * ldr + a.res.c) * 4) : 0, 0x00020000);
+    // one finished element (a tile of this lane's channel): row pass, bias, residual, activation, 16 stores.
+    // ACT: compile-time activation (-1 = the run-time switch of apply_act); RES: a residual is added
+    auto finish = [&](auto ACT, auto RES, int h, int rr) __attribute__((always_inline)) {
+        constexpr int act_c = decltype(ACT)::value;
+        constexpr bool has_res = decltype(RES)::value;
+        const int r = 8 * h + rr;                              // element r: tile (tx, ty) = ((r & 3) + 4 lh, r >> 2) of the block's 8 x 4
+        f32x4n S[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) S[i] = lds_read4(xr + (unsigned)i * 8192u + (unsigned)rr * 1024u);
+        const int oyb = oy0 + 4 * (r >> 2), oxb = ox0 + 4 * ((r & 3) + 4 * le_h);
+        const int pix0 = oyb * wo + oxb;
+        f32x4n Y[4];                                          // Y[b] = (y[0][b], y[1][b], y[2][b], y[3][b])
+        Y[0] = at6(S[0].x, S[1].x, S[2].x, S[3].x, S[4].x, S[5].x);
+        Y[1] = at6(S[0].y, S[1].y, S[2].y, S[3].y, S[4].y, S[5].y);
+        Y[2] = at6(S[0].z, S[1].z, S[2].z, S[3].z, S[4].z, S[5].z);
+        Y[3] = at6(S[0].w, S[1].w, S[2].w, S[3].w, S[4].w, S[5].w);
+        static_for<16>([&](auto E) {
+            constexpr int e = decltype(E)::value, dy = e >> 2, dx = e & 3;
+            const f32x4n yb = Y[dx];
+            float v = (dy == 0 ? yb.x : (dy == 1 ? yb.y : (dy == 2 ? yb.z : yb.w))) + bias;
+            const bool ok = oyb + dy < ho && oxb + dx < wo;
+            const int pix = pix0 + dy * wo + dx;
+            if constexpr (has_res) {
+                const float rv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_, ok ? (int)(((unsigned)pix * (unsigned)ldr + (unsigned)co) * 4u) : (int)kOob, 0, 0));
+                if (a.res_mode == 1) v += rv;
+                v = apply_act(v, act_c >= 0 ? act_c : a.act, slope);
+                if (a.res_mode == 2) v += rv;
+            } else v = apply_act(v, act_c >= 0 ? act_c : a.act, slope);
+            if constexpr (!(ABL & 8))
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, ok ? (int)(((unsigned)pix * (unsigned)ldo + (unsigned)co) * 4u) : (int)kOob, 0, 0);
+        });
+    };
+    auto finish_act = [&](auto RES, int h, int rr) __attribute__((always_inline)) {
+        switch (a.act) {                                       // uniform: the common activations get a body without the per-element switch
+            case CSM_ACT_NONE: finish(ic<CSM_ACT_NONE>{}, RES, h, rr); break;
+            case CSM_ACT_RELU: finish(ic<CSM_ACT_RELU>{}, RES, h, rr); break;
+            case CSM_ACT_SILU: finish(ic<CSM_ACT_SILU>{}, RES, h, rr); break;
+            default: finish(ic<-1>{}, RES, h, rr); break;
+        }
+    };
+    // column pass (over j) of this wave's frequency row for all 16 accumulator elements FIRST (the 32x32 accumulators are register tuples:
+    // they stay allocated as long as any element is live); round 0's s[0..3] go to LDS, round 1's wait in registers
+    static_for<8>([&](auto RR) {
+        constexpr int r = decltype(RR)::value;
+        lds_write4(xw + (unsigned)r * 1024u, at6(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r]));
+    });
+    f32x4n s1[8];
+    static_for<8>([&](auto RR) {
+        constexpr int r = 8 + decltype(RR)::value;
+        s1[r - 8] = at6(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r]);
+    });
     static_for<2>([&](auto H) {
         constexpr int h = decltype(H)::value;
-        // column pass (over j) of this wave's frequency row for accumulator elements [8 h, 8 h + 8): s[0..3] each
-        static_for<8>([&](auto RR) {
-            constexpr int r = 8 * h + decltype(RR)::value;
-            lds_write4(xw + (unsigned)decltype(RR)::value * 1024u, at6(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r]));
-        });
+        if constexpr (h == 1) static_for<8>([&](auto RR) { lds_write4(xw + (unsigned)decltype(RR)::value * 1024u, s1[decltype(RR)::value]); });
         wait_barrier<0>();
         // row pass (over i) + bias / residual / activation: this wave finishes elements [el0, el0 + nel) of the round
         const int el0 = h == 0 ? (wi < 2 ? 2 * wi : wi + 2) : (wi < 4 ? wi : 2 * wi - 4);
         const int nel = h == 0 ? (wi < 2 ? 2 : 1) : (wi < 4 ? 1 : 2);
         for (int k = 0; k < nel; ++k) {
-            const int rr = el0 + k, r = 8 * h + rr;           // element r: tile (tx, ty) = ((r & 3) + 4 lh, r >> 2) of the block's 8 x 4
-            f32x4n S[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) S[i] = lds_read4(xr + (unsigned)i * 8192u + (unsigned)rr * 1024u);
-            const int oyb = oy0 + 4 * (r >> 2), oxb = ox0 + 4 * ((r & 3) + 4 * lh);
-            const int64_t mb = ((int64_t)n * ho + oyb) * wo + oxb;
-            float *ob = a.out.p + mb * ldo + co;
-            const float *rp = a.res_mode ? a.res.p + mb * ldr + co : nullptr;
-            f32x4n Y[4];                                      // Y[b] = (y[0][b], y[1][b], y[2][b], y[3][b])
-            Y[0] = at6(S[0].x, S[1].x, S[2].x, S[3].x, S[4].x, S[5].x);
-            Y[1] = at6(S[0].y, S[1].y, S[2].y, S[3].y, S[4].y, S[5].y);
-            Y[2] = at6(S[0].z, S[1].z, S[2].z, S[3].z, S[4].z, S[5].z);
-            Y[3] = at6(S[0].w, S[1].w, S[2].w, S[3].w, S[4].w, S[5].w);
-            float resv[16];
-            if (a.res_mode) {
-                static_for<16>([&](auto E) {
-                    constexpr int e = decltype(E)::value, dy = e >> 2, dx = e & 3;
-                    resv[e] = (oyb + dy < ho && oxb + dx < wo) ? rp[((int64_t)dy * wo + dx) * ldr] : 0.0f;
-                });
-            }
-            static_for<16>([&](auto E) {
-                constexpr int e = decltype(E)::value, dy = e >> 2, dx = e & 3;
-                const f32x4n yb = Y[dx];
-                float v = (dy == 0 ? yb.x : (dy == 1 ? yb.y : (dy == 2 ? yb.z : yb.w))) + bias;
-                if (a.res_mode == 1) v += resv[e];
-                v = apply_act(v, a.act, slope);
-                if (a.res_mode == 2) v += resv[e];
-                if constexpr (!(ABL & 8)) {
-                    if (oyb + dy < ho && oxb + dx < wo) ob[((int64_t)dy * wo + dx) * ldo] = v;
-                }
-            });
+            if (a.res_mode) finish_act(std::true_type{}, h, el0 + k);
+            else finish_act(std::false_type{}, h, el0 + k);
         }
         if constexpr (h == 0) wait_barrier<0>();              // the exchange area is rewritten by the second round
     });
@@ -362,7 +420,9 @@ bool wino4_eligible(const ConvArgs &a) {
     const int64_t bytes_w = (int64_t)(a.cout_g / 64) * (a.cin_g / 4) * (12 * kUW);
     return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil == 1 && a.pad == 1 && a.groups == 1 && a.ksplit <= 1 && (a.cin_g & 31) == 0 &&
            (a.cout_g & 63) == 0 && bytes_in < (1ll << 31) && bytes_w < (1ll << 31) && !(a.in.ld & 3) && !(((uintptr_t)a.in.p | (uintptr_t)a.w) & 15) &&
-           a.out.h == a.in.h && a.out.w == a.in.w;
+           a.out.h == a.in.h && a.out.w == a.in.w &&
+           (((int64_t)a.out.h * a.out.w - 1) * a.out.ld + a.out.c) * 4 < (1ll << 31) &&                   // (the epilogue's buffer descriptors: one sample)
+           (!a.res_mode || (((int64_t)a.out.h * a.out.w - 1) * a.res.ld + a.res.c) * 4 < (1ll << 31));
 }
 
 static int launch_conv_wino4_chunk(const ConvArgs &a0, hipStream_t st) {
@@ -375,8 +435,8 @@ static int launch_conv_wino4_chunk(const ConvArgs &a0, hipStream_t st) {
     const int variant = ve ? atoi(ve) : 0;
     auto go = [&](auto kern) {
         static KernelPrep prep;
-        (void)prep.ensure([&] { return prepare_kernel(kern, 768, kLds); });
-        kern<<<grid, 768, kLds, st>>>(a, tiles_x, tiles_y);
+        (void)prep.ensure([&] { return prepare_kernel(kern, 768, kLdsAll); });
+        kern<<<grid, 768, kLdsAll, st>>>(a, tiles_x, tiles_y);
         return csm::check_launch("k_conv_wino4");
     };
     switch (variant) {
@@ -386,12 +446,17 @@ static int launch_conv_wino4_chunk(const ConvArgs &a0, hipStream_t st) {
         case 8: return go(&k_conv_wino4<8>);
         case 3: return go(&k_conv_wino4<3>);
         case 11: return go(&k_conv_wino4<11>);
+        case 16: return go(&k_conv_wino4<16>);
+        case 32: return go(&k_conv_wino4<32>);
+        case 35: return go(&k_conv_wino4<35>);
+        case 51: return go(&k_conv_wino4<51>);
+        case 59: return go(&k_conv_wino4<59>);
         default: break;
     }
 #endif
     static KernelPrep prep;
-    (void)prep.ensure([&] { return prepare_kernel(&k_conv_wino4<0>, 768, kLds); });
-    k_conv_wino4<0><<<grid, 768, kLds, st>>>(a, tiles_x, tiles_y);
+    (void)prep.ensure([&] { return prepare_kernel(&k_conv_wino4<0>, 768, kLdsAll); });
+    k_conv_wino4<0><<<grid, 768, kLdsAll, st>>>(a, tiles_x, tiles_y);
     return csm::check_launch("k_conv_wino4");
 }
 

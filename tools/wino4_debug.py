@@ -84,8 +84,29 @@ def time_layer(n, h, w, cin, cout, reps=5, modes=('direct', 'f2', 'f4')):
               fl / res['f4'] / 1e9, ex4 / res['f4'] / 1e9, res.get('f2', 0) / res['f4'], res.get('direct', 0) / res['f4']), flush=True)
 
 
+def variants(shapes, vs):
+    """timing of the development instantiations of k_conv_wino4 (libcsm355_dev.so = make dev; CSM_WINO4_VARIANT: ablation bits 1 no DMA,
+    2 no transform, 4 no MFMA, 8 no epilogue stores)"""
+    for shp in shapes:
+        n, h, w, cin, cout = shp
+        p = build('f4', n, h, w, cin, cout)
+        os.environ["CSM_AUTOTUNE"] = "0"
+        cp = CompiledProgram(p, 'cuda')
+        x = torch.randn(n, cin, h, w, device='cuda'); y = torch.empty(n, cout, h, w, device='cuda')
+        ci = [i for i, o in enumerate(p.ops) if o['kind'] == 1][0]
+        ex4 = 2.0 * n * ((h + 3) // 4) * ((w + 3) // 4) * 36 * cin * cout
+        for v in vs:
+            os.environ["CSM_WINO4_VARIANT"] = str(v)
+            cp.run(x, y); cp.run(x, y)
+            ms = min(cp.profile(x, y)[ci] for _ in range(5))
+            print("%2dx%3dx%3d %4d->%4d  variant %3d  %8.1f us  executed %6.1f TF/s (%.3f of the fp32 MFMA peak)" % (n, h, w, cin, cout, v, ms * 1e3, ex4 / ms / 1e9, ex4 / ms / 1e9 / 157.3), flush=True)
+        os.environ["CSM_WINO4_VARIANT"] = "0"
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['check', 'bench']
+    if 'variants' in what:
+        variants([(8, 160, 160, 256, 256), (16, 360, 360, 64, 64)], [int(v) for v in os.environ.get('WINO4_VARIANTS', '0,1,2,4,8,3,11,7,15').split(',')])
     if 'check' in what:
         ok = True
         ok &= check(1, 16, 32, 32, 64, act=None, wkind='delta', xkind='ramp')
