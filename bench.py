@@ -375,12 +375,8 @@ class FrameWorkload(Workload):
                 ms = m if ms is None else [min(a, b) for a, b in zip(ms, m)]
             conv_ms = sum(t for t, o in zip(ms, cp.prog.ops) if o['kind'] == 1)
             att_ms = sum(t for t, o in zip(ms, cp.prog.ops) if o['kind'] == 16)
-            conv_fl = sum(2 * cp.prog.views[o['out']].n * cp.prog.views[o['out']].h * cp.prog.views[o['out']].w * o['nat']['cout_g'] *
-                          o['nat']['groups'] * o['nat']['cin_g'] * o['kh'] * o['kw'] for o in cp.prog.ops if o['kind'] == 1)
-            conv_ex = conv_fl - sum((1.0 - 16.0 * ((cp.prog.views[o['out']].h + 1) // 2) * ((cp.prog.views[o['out']].w + 1) // 2) /
-                                     (9.0 * cp.prog.views[o['out']].h * cp.prog.views[o['out']].w)) *
-                                    2 * cp.prog.views[o['out']].n * cp.prog.views[o['out']].h * cp.prog.views[o['out']].w * o['nat']['cout_g'] * o['nat']['cin_g'] * 9
-                                    for o in cp.prog.ops if o['kind'] == 1 and o['flags'] & 4)       # Winograd layers execute 16 / 36 of their natural FLOPs
+            conv_fl = sum(conv_op_flops(cp.prog, o)[0] for o in cp.prog.ops if o['kind'] == 1)
+            conv_ex = sum(conv_op_flops(cp.prog, o)[1] for o in cp.prog.ops if o['kind'] == 1)       # Winograd layers execute 16 / 36 (F(2x2)) or 9 / 36 (F(4x4)) of their natural FLOPs
             res["core_%dx%d_n%d" % (h, w, n)] = {"all_ops_ms": round(sum(ms), 3), "conv_ms": round(conv_ms, 3), "attention_ms": round(att_ms, 3),
                                                  "gflop": round(cp.prog.flops / 1e9, 1), "conv_tflops": round(conv_ex / conv_ms / 1e9, 1),
                                                  "conv_frac_of_mfma_peak": round(conv_ex / conv_ms / 1e9 / MFMA_F32_PEAK_TF, 4),
@@ -622,7 +618,7 @@ class FrameWorkload(Workload):
     def roofline(self):
         """dominant kernel = the implicit-GEMM conv (k_conv_dma tiles + k_conv_mfma fallback): algorithmic conv FLOPs / summed launch
         durations (HIP events around every op on the launch stream)"""
-        tot_ms, tot_fl, tot_ex, wino_ms, n_wino, per_net = 0.0, 0.0, 0.0, 0.0, 0, {}
+        tot_ms, tot_fl, tot_ex, wino_ms, n_wino, per_net, per_class = 0.0, 0.0, 0.0, 0.0, 0, {}, {}
         progs = self._programs()
         before = [cp.runs for _, cp, _ in progs]
         self.step(); torch.cuda.synchronize()                      # how often each program runs in one step (ISNet: once per 8 instances)
@@ -638,8 +634,13 @@ class FrameWorkload(Workload):
                 ms = m if ms is None else [min(a, b) for a, b in zip(ms, m)]
             cms = sum(t for t, o in zip(ms, cp.prog.ops) if o['kind'] == 1)
             nconv = sum(1 for o in cp.prog.ops if o['kind'] == 1)
-            wms = sum(t for t, o in zip(ms, cp.prog.ops) if o['kind'] == 1 and o['flags'] & 4)       # Winograd F(2x2, 3x3) layers (k_conv_wino)
-            nw = sum(1 for o in cp.prog.ops if o['kind'] == 1 and o['flags'] & 4)
+            wms = sum(t for t, o in zip(ms, cp.prog.ops) if o['kind'] == 1 and o['flags'] & 12)      # Winograd layers: F(2x2) k_conv_wino8 (flag 4), F(4x4) k_conv_wino4 (flag 8)
+            nw = sum(1 for o in cp.prog.ops if o['kind'] == 1 and o['flags'] & 12)
+            for t, o in zip(ms, cp.prog.ops):                     # per-class table: where the step's conv time goes and at what rate
+                if o['kind'] == 1:
+                    c = per_class.setdefault(conv_op_class(cp.prog, o), [0, 0.0, 0.0, 0.0])
+                    fn, fe = conv_op_flops(cp.prog, o)
+                    c[0] += per_step; c[1] += t * per_step; c[2] += fe * per_step; c[3] += fn * per_step
             per_net[name] = {"conv_ms": round(cms, 3), "all_ops_ms": round(sum(ms), 3), "gflop": round(cp.prog.flops / 1e9, 1),
                              "gflop_executed": round(cp.prog.flops_exec / 1e9, 1), "conv_launches": nconv, "winograd_launches": nw,
                              "winograd_ms": round(wms, 3), "runs_per_step": per_step}
@@ -656,10 +657,10 @@ class FrameWorkload(Workload):
         ach_nat = tot_fl / (tot_ms * 1e-3) / 1e12
         tot_fl /= self.frames_per_step
         tot_ex /= self.frames_per_step
-        return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_wino+k_conv_mfma (fp32 implicit GEMM / Winograd F(2x2,3x3), all conv launches of one step = %d frames)" % self.frames_per_step,
+        return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_wino4+k_conv_wino8+k_conv_mfma (fp32 implicit GEMM / Winograd F(4x4,3x3) and F(2x2,3x3), all conv launches of one step = %d frames)" % self.frames_per_step,
                 "vendor_fp32_gemm_context": self._vendor_gemm_context() if self.frames_per_step == 8 else None,
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
-                "flops_basis": "executed MFMA FLOPs (Winograd layers: 16 products per 2x2 output tile and channel pair)",
+                "flops_basis": "executed MFMA FLOPs (Winograd layers: F(4x4) 36 products per 4x4 output tile and channel pair, F(2x2) 16 per 2x2)",
                 "direct_equivalent_tflops": round(ach_nat, 2), "direct_equivalent_frac": round(ach_nat / MFMA_F32_PEAK_TF, 4),
                 "executed_flops_per_frame": tot_ex, "winograd_launches_per_step": n_wino, "winograd_ms_per_step": round(wino_ms, 3),
                 "traffic": load_traffic("k_conv"), "traffic_source": TRAFFIC_SOURCE,
@@ -667,7 +668,10 @@ class FrameWorkload(Workload):
                 "algorithmic_flops_per_frame": tot_fl,
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2), "launches_per_step": n_launch, "conv_ms_per_step": round(tot_ms, 3),
                 "note": "a launch = one conv op of a layer program (a mixed-tile or split-K op issues two kernels: rocprofv3's per-kernel "
-                        "average is lower, its k_conv_* total per step is the comparable figure -- profiles/README.md)", "per_net": per_net}
+                        "average is lower, its k_conv_* total per step is the comparable figure -- profiles/README.md)", "per_net": per_net,
+                "per_class": {k: {"launches_per_step": v[0], "ms_per_step": round(v[1], 3), "executed_tflops": round(v[2] / v[1] / 1e9, 1),
+                                  "frac_of_mfma_peak": round(v[2] / v[1] / 1e9 / MFMA_F32_PEAK_TF, 4), "direct_equivalent_tflops": round(v[3] / v[1] / 1e9, 1)}
+                              for k, v in sorted(per_class.items(), key=lambda kv: -kv[1][1]) if v[1] > 0}}
 
     def _vendor_gemm_context(self):
         """context for `frac`, measured in this run: what the vendor library's fp32 GEMM (torch.mm -> hipBLASLt / rocBLAS, TF32 off, the
@@ -709,6 +713,35 @@ def make_workload(kind, size, rank, device, world, dist, batch=8):
 
 TRAFFIC_SOURCE = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed by the builder; "
                   "NOT re-measured inside this run (PMC collection needs its own rocprofv3 passes)")
+
+
+def conv_op_flops(prog, o):
+    """(natural, executed) FLOPs of one CONV op of a lowered program: a Winograd layer executes 16 products per 2x2 (F(2x2), flag 4) or 36
+    per 4x4 (F(4x4), flag 8) output tile and channel pair instead of 9 per pixel"""
+    vo, nat = prog.views[o['out']], o['nat']
+    cc = nat['cout_g'] * nat['groups'] * nat['cin_g']
+    natural = 2.0 * vo.n * vo.h * vo.w * cc * o['kh'] * o['kw']
+    if o['flags'] & 8:
+        return natural, 2.0 * vo.n * ((vo.h + 3) // 4) * ((vo.w + 3) // 4) * 36 * cc
+    if o['flags'] & 4:
+        return natural, 2.0 * vo.n * ((vo.h + 1) // 2) * ((vo.w + 1) // 2) * 16 * cc
+    return natural, natural
+
+
+def conv_op_class(prog, o):
+    """coarse class of a CONV op for the per-class roofline table"""
+    vo, nat = prog.views[o['out']], o['nat']
+    if o['flags'] & 8:
+        return "winograd_f4x4"
+    if o['flags'] & 4:
+        return "winograd_f2x2"
+    if o['flags'] & 2:
+        return "stem"
+    if nat['groups'] > 1:
+        return "grouped"
+    if o['kh'] == 1 and o['kw'] == 1:
+        return "pointwise_map_ge_80x80" if vo.h * vo.w >= 6400 else "pointwise_map_lt_80x80"
+    return "direct_kxk_map_ge_80x80" if vo.h * vo.w >= 6400 else "direct_kxk_map_lt_80x80"
 
 
 def load_traffic(kernel_key):

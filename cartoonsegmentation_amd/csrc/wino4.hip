@@ -67,6 +67,25 @@ template <int VM> __device__ __forceinline__ void wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(VM) : "memory");
 }
 
+// packed fp32 on the transform's channel pairs: v_pk_fma_f32 / v_pk_add_f32 are the same IEEE operations per component at half the VALU
+// issue (the compiler splits __builtin_elementwise_fma back into two v_fma_f32 here, hence the asm).  The coefficient is a wave-uniform
+// scalar: an SGPR pair whose LOW half feeds both components (op_sel_hi:[0,1,1])
+__device__ __forceinline__ f32x2n pk_fma(f32x2n coef, f32x2n b, f32x2n c) {
+    f32x2n d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(coef), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2n pk_add(f32x2n a, f32x2n b) {
+    f32x2n d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2n pk_sub(f32x2n a, f32x2n b) {      // a + (-b): exact negation
+    f32x2n d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // the contract's 1-D transforms (include/csm355.h), one component
 struct T6 { float t0, t1, t2, t3, t4, t5; };
 __device__ __forceinline__ T6 bt6(float d0, float d1, float d2, float d3, float d4, float d5) {
@@ -199,6 +218,9 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
         for (int k = 0; k < 4; ++k) rowb[k] = ((rr[k] >> 2) ? bxB : bxA) + (unsigned)(rr[k] * 18 * 32);
     }
 
+    auto sgf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, v))); };
+    const f32x2n cg2 = {sgf(cg), 0.0f}, c12 = {sgf(c1), 0.0f}, c22 = {sgf(c2), 0.0f};      // (SGPR pairs: only the low half is read)
+    const f32x2n k4 = {sgf(4.0f), 0.0f}, km5 = {sgf(-5.0f), 0.0f}, km4 = {sgf(-4.0f), 0.0f}, k2 = {sgf(2.0f), 0.0f}, km2 = {sgf(-2.0f), 0.0f};
     f32x16 acc[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j)
@@ -225,25 +247,25 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
         if constexpr (ABL & 2) {
         } else if constexpr (m < 6) {
             constexpr int b = m & 1;
-            T[m].x = fmaf(cg, fmaf(c1, D[b][0].x, D[b][1].x), fmaf(c2, D[b][2].x, D[b][3].x));
-            T[m].y = fmaf(cg, fmaf(c1, D[b][0].y, D[b][1].y), fmaf(c2, D[b][2].y, D[b][3].y));
+            // (two channels per lane: v_pk_fma_f32 -- the same IEEE fma per component, half the VALU issue)
+            T[m] = pk_fma(cg2, pk_fma(c12, D[b][0], D[b][1]), pk_fma(c22, D[b][2], D[b][3]));
             if constexpr (m < 4) xf_load(RB, ic<m + 2>{});
         } else if constexpr (m == 6) {
-            lds_write2(vdst + 0u * 512u, f32x2n{fmaf(4.0f, T[0].x, fmaf(-5.0f, T[2].x, T[4].x)), fmaf(4.0f, T[0].y, fmaf(-5.0f, T[2].y, T[4].y))});
+            lds_write2(vdst + 0u * 512u, pk_fma(k4, T[0], pk_fma(km5, T[2], T[4])));
         } else if constexpr (m == 7) {
-            lds_write2(vdst + 5u * 512u, f32x2n{fmaf(4.0f, T[1].x, fmaf(-5.0f, T[3].x, T[5].x)), fmaf(4.0f, T[1].y, fmaf(-5.0f, T[3].y, T[5].y))});
+            lds_write2(vdst + 5u * 512u, pk_fma(k4, T[1], pk_fma(km5, T[3], T[5])));
         } else if constexpr (m == 8) {                          // a -> D[0][0], b -> D[0][1]
-            D[0][0].x = fmaf(-4.0f, T[2].x, T[4].x); D[0][0].y = fmaf(-4.0f, T[2].y, T[4].y);
-            D[0][1].x = fmaf(-4.0f, T[1].x, T[3].x); D[0][1].y = fmaf(-4.0f, T[1].y, T[3].y);
-            lds_write2(vdst + 1u * 512u, f32x2n{D[0][0].x + D[0][1].x, D[0][0].y + D[0][1].y});
+            D[0][0] = pk_fma(km4, T[2], T[4]);
+            D[0][1] = pk_fma(km4, T[1], T[3]);
+            lds_write2(vdst + 1u * 512u, pk_add(D[0][0], D[0][1]));
         } else if constexpr (m == 9) {
-            lds_write2(vdst + 2u * 512u, f32x2n{D[0][0].x - D[0][1].x, D[0][0].y - D[0][1].y});
+            lds_write2(vdst + 2u * 512u, pk_sub(D[0][0], D[0][1]));
         } else if constexpr (m == 10) {                         // c -> D[0][0], e -> D[0][1]
-            D[0][0].x = T[4].x - T[2].x; D[0][0].y = T[4].y - T[2].y;
-            D[0][1].x = T[3].x - T[1].x; D[0][1].y = T[3].y - T[1].y;
-            lds_write2(vdst + 3u * 512u, f32x2n{fmaf(2.0f, D[0][1].x, D[0][0].x), fmaf(2.0f, D[0][1].y, D[0][0].y)});
+            D[0][0] = pk_sub(T[4], T[2]);
+            D[0][1] = pk_sub(T[3], T[1]);
+            lds_write2(vdst + 3u * 512u, pk_fma(k2, D[0][1], D[0][0]));
         } else {
-            lds_write2(vdst + 4u * 512u, f32x2n{fmaf(-2.0f, D[0][1].x, D[0][0].x), fmaf(-2.0f, D[0][1].y, D[0][0].y)});
+            lds_write2(vdst + 4u * 512u, pk_fma(km2, D[0][1], D[0][0]));
         }
     };
 
@@ -300,12 +322,13 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
                 Bq[0] = lds_read4(blane + (unsigned)((q + 1) & 1) * kUW);
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) A[jj] = lds_read2(vlane + (unsigned)((q + 1) & 1) * kVB + (unsigned)jj * 512u);
-            } else if constexpr (m == 10) {
+            } else if constexpr (m == 10) {                     // (dead by now: B of j = 2, 3 since slot 9, A of j = 3, 4 since slots 9, 10)
                 Bq[1] = lds_read4(blane + (unsigned)((q + 1) & 1) * kUW + 1024u);
+#pragma unroll
+                for (int jj = 3; jj < 5; ++jj) A[jj] = lds_read2(vlane + (unsigned)((q + 1) & 1) * kVB + (unsigned)jj * 512u);
             } else if constexpr (m == 11) {
                 Bq[2] = lds_read4(blane + (unsigned)((q + 1) & 1) * kUW + 2048u);
-#pragma unroll
-                for (int jj = 3; jj < 6; ++jj) A[jj] = lds_read2(vlane + (unsigned)((q + 1) & 1) * kVB + (unsigned)jj * 512u);
+                A[5] = lds_read2(vlane + (unsigned)((q + 1) & 1) * kVB + 5u * 512u);
             }
         });
         __builtin_amdgcn_sched_barrier(0);

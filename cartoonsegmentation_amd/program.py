@@ -148,7 +148,7 @@ def pack_wino_weights(w):
 # Same layer class as F(2x2); 36 products per 4x4 output tile and channel pair instead of 64.  A layer takes it when it has at least
 # WINO4_MIN_PIXELS output pixels per sample (per-sample rule: batch invariant); CSM_WINO4=0 keeps every Winograd layer on F(2x2).
 CONV_FLAG_WINOGRAD4 = 8
-WINO4_ENABLE = os.environ.get('CSM_WINO4', '0') != '0'
+WINO4_ENABLE = os.environ.get('CSM_WINO4', '1') != '0'
 WINO4_MIN_PIXELS = int(os.environ.get('CSM_WINO4_MIN_PIXELS', '6400'))
 
 

@@ -20,11 +20,12 @@ class _forced:
         self.new = (wino, min_pixels)
 
     def __enter__(self):
-        self.old = (P.Program.winograd, P.WINO_MIN_PIXELS)
+        self.old = (P.Program.winograd, P.WINO_MIN_PIXELS, P.Program.winograd4)
         P.Program.winograd, P.WINO_MIN_PIXELS = self.new
+        P.Program.winograd4 = False                # (this file is about F(2x2): tests/test_gpu_winograd4.py covers F(4x4))
 
     def __exit__(self, *a):
-        P.Program.winograd, P.WINO_MIN_PIXELS = self.old
+        P.Program.winograd, P.WINO_MIN_PIXELS, P.Program.winograd4 = self.old
 
 
 def _run_both(prog, ext_in, out_shapes):

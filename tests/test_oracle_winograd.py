@@ -11,8 +11,8 @@ from oracle import nets as onets
 
 def _layer(wino, n, h, w, cin, cout, act='relu', res_mode=0, seed=1):
     rng = np.random.default_rng(seed)
-    old = (P.Program.winograd, P.WINO_MIN_PIXELS)
-    P.Program.winograd, P.WINO_MIN_PIXELS = wino, 0
+    old = (P.Program.winograd, P.WINO_MIN_PIXELS, P.Program.winograd4)
+    P.Program.winograd, P.WINO_MIN_PIXELS, P.Program.winograd4 = wino, 0, False       # (F(2x2) here; F(4x4): test_oracle_winograd4.py)
     try:
         p = P.Program('t')
         x_ext = p.ext_nchw(n, cin, h, w)
@@ -26,7 +26,7 @@ def _layer(wino, n, h, w, cin, cout, act='relu', res_mode=0, seed=1):
         y = p.conv(x, wt, b, pad=1, act=act, res=res, res_mode=res_mode)
         p.to_nchw(y, y_ext)
     finally:
-        P.Program.winograd, P.WINO_MIN_PIXELS = old
+        P.Program.winograd, P.WINO_MIN_PIXELS, P.Program.winograd4 = old
     return p
 
 
@@ -86,6 +86,7 @@ def test_winograd_rule_is_per_sample_and_switchable():
         p.conv(x, np.zeros((cout, cin // groups, k, k), np.float32), None, stride=stride, pad=pad, dil=dil, groups=groups)
         return p.ops[-1]['flags'], p.ops[-1]['ksplit']
     assert P.WINO_ENABLE and P.Program.winograd
+    old4, P.Program.winograd4 = P.Program.winograd4, False
     big = int(np.ceil(np.sqrt(P.WINO_MIN_PIXELS)))
     assert flags(1, big, big, 64, 64) == (P.CONV_FLAG_WINOGRAD, 1) and flags(8, big, big, 64, 64) == (P.CONV_FLAG_WINOGRAD, 1)
     small = max(2, big // 2 - 1)
@@ -99,3 +100,4 @@ def test_winograd_rule_is_per_sample_and_switchable():
         assert flags(1, big, big, 64, 64)[0] == 0
     finally:
         P.Program.winograd = P.WINO_ENABLE
+        P.Program.winograd4 = old4

@@ -35,7 +35,7 @@ def prof(name, prog, ext, top=TOP):
         if o['kind'] == 1:
             nat = o['nat']
             fl = 2 * v_out.n * v_out.h * v_out.w * nat['cout_g'] * nat['groups'] * nat['cin_g'] * o['kh'] * o['kw']
-        rows.append((t, k, "%dx%dx%dx%d->%dx%dx%d k%d s%d d%d g%d S%d T%d" % (v_in.n, v_in.h, v_in.w, v_in.c, v_out.h, v_out.w, v_out.c, o['kh'], o['stride'], o['dil'], o['groups'], o.get('ksplit', 1), cp.ops[len(rows)].tile - 1) + (" WINO" if o['kind'] == 1 and o['flags'] & 4 else ""), fl))
+        rows.append((t, k, "%dx%dx%dx%d->%dx%dx%d k%d s%d d%d g%d S%d T%d" % (v_in.n, v_in.h, v_in.w, v_in.c, v_out.h, v_out.w, v_out.c, o['kh'], o['stride'], o['dil'], o['groups'], o.get('ksplit', 1), cp.ops[len(rows)].tile - 1) + (" WINO4" if o['kind'] == 1 and o['flags'] & 8 else (" WINO" if o['kind'] == 1 and o['flags'] & 4 else "")), fl))
     tot = sum(ms)
     print("== %s: %.3f ms total (event-bracketed), %.1f GFLOP -> %.1f TF/s ; by kind: %s" % (name, tot, prog.flops / 1e9, prog.flops / tot / 1e9,
           ", ".join("%s %.2f" % kv for kv in sorted(by_kind.items(), key=lambda kv: -kv[1]))))

@@ -11,6 +11,7 @@ from oracle import nets as onets
 
 def build(wino, n, h, w, cin, cout, act='relu', res_mode=0, wkind='rand', seed=0):
     P.Program.winograd = wino
+    old4, P.Program.winograd4 = P.Program.winograd4, False
     old = P.WINO_MIN_PIXELS; P.WINO_MIN_PIXELS = 0
     rng = np.random.default_rng(seed)
     p = P.Program('t')
@@ -32,6 +33,7 @@ def build(wino, n, h, w, cin, cout, act='relu', res_mode=0, wkind='rand', seed=0
     p.to_nchw(y, y_ext)
     P.WINO_MIN_PIXELS = old
     P.Program.winograd = P.WINO_ENABLE
+    P.Program.winograd4 = old4
     return p
 
 
