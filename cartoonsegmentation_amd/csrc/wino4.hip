@@ -126,8 +126,9 @@ static_assert(kPH == 18 && kPW == 34 && kLdsAll <= 160u * 1024u, "tile shape");
 __host__ __device__ constexpr int psi_k(int r, int c) { return ((c >> 1) & 1) * 324 + r * 18 + (c & 1) * 9 + (c >> 2); }
 
 // ABL (development ablations, timing only -- results invalid): 1 = no DMA, 2 = no transform, 4 = no MFMA, 8 = no epilogue stores,
-// 16 = no barrier in the main loop, 32 = no operand reads (A / B fragments) in the main loop
-template <int ABL = 0>
+// 16 = no barrier in the main loop, 32 = no operand reads (A / B fragments) in the main loop, 64 = every block stores into the first
+// 256 KB of the output (same instructions, no HBM write traffic: is the epilogue's time arithmetic or the write burst?)
+template <int ABL = 0, int DMA_STAGGER = 0>
 __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(64))) float lds[];   // [raw 0][raw 1][V 0][V 1][U: 12 waves x 2 slots]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,9 +290,10 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     // this step's fetches in flight).  The barrier itself waits for LDS traffic only ----
     // XF: this wave transforms in this step (ONE wave-uniform branch per step selects the variant: straight-line slots, so that the
     // compiler's wait counts stay exact -- a branch per slice made every slice drain the LDS queue)
-    auto step = [&](auto Q, auto XF, int s) __attribute__((always_inline)) {
+    auto step = [&](auto Q, auto XF, auto ROLE, int s) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value;
         constexpr bool xf = decltype(XF)::value;
+        constexpr int u0 = (DMA_STAGGER && decltype(ROLE)::value) ? 6 : 0;     // slots of the three U pieces: the two channel halves do not issue in the same slots
         constexpr int rbuf = ((q + 2) >> 1) & 1;               // raw buffer of step s + 2: stage (s + 2) >> 1
         unsigned offq0 = 0u, offq1 = 0u;
         if constexpr (xf) xf_begin(ic<rbuf>{});
@@ -303,10 +305,11 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
                 const float bv = (j & 1) ? (t ? bf.w : bf.z) : (t ? bf.y : bf.x);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(t ? A[j].y : A[j].x, bv, acc[j], 0, 0, 0);
             }
-            if constexpr (m < 3) {
-                if constexpr (!(ABL & 1)) dma16s(s + 2 < nsteps ? voffU : kOob, rb, u_src + (unsigned)m * 1024u, ldsU + (unsigned)(q & 1) * kUW + (unsigned)m * 1024u);
-                if constexpr (m == 2) u_src += 12u * kUW;
-            } else if constexpr (m == 3 && (q & 1) == 0) {
+            if constexpr (m >= u0 && m < u0 + 3) {
+                if constexpr (!(ABL & 1)) dma16s(s + 2 < nsteps ? voffU : kOob, rb, u_src + (unsigned)(m - u0) * 1024u, ldsU + (unsigned)(q & 1) * kUW + (unsigned)(m - u0) * 1024u);
+                if constexpr (m == u0 + 2) u_src += 12u * kUW;
+            }
+            if constexpr (m == 3 && (q & 1) == 0) {
                 const u32x2n o2 = lds_read2u(offL);           // (used in slots 4 and 5)
                 offq0 = o2.x; offq1 = o2.y;
             } else if constexpr (m == 4 && (q & 1) == 0) {
@@ -318,7 +321,9 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
             if constexpr (ABL & 32) {
             } else if constexpr (m == 6) {
                 // everything sent before this step has landed: B(s + 1), and the raw pieces of step s - 1
-                if constexpr ((q & 1) == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                // (issued in this step before this point: the U pieces of slots [u0, 6] and, in even steps, two raw pieces)
+                constexpr int mine = (u0 == 0 ? 3 : 1) + ((q & 1) == 0 ? 2 : 0);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(mine) : "memory");
                 Bq[0] = lds_read4(blane + (unsigned)((q + 1) & 1) * kUW);
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) A[jj] = lds_read2(vlane + (unsigned)((q + 1) & 1) * kVB + (unsigned)jj * 512u);
@@ -342,9 +347,9 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
         constexpr int role = decltype(ROLE)::value;
         int s4 = 0;
         for (; s4 + 4 < nsteps; s4 += 4)
-            static_for<4>([&](auto Q) { step(Q, std::integral_constant<bool, (decltype(Q)::value & 1) == role>{}, s4 + decltype(Q)::value); });
+            static_for<4>([&](auto Q) { step(Q, std::integral_constant<bool, (decltype(Q)::value & 1) == role>{}, ROLE, s4 + decltype(Q)::value); });
         static_for<4>([&](auto Q) {
-            step(Q, std::integral_constant<bool, (decltype(Q)::value & 1) == role && decltype(Q)::value < 2>{}, s4 + decltype(Q)::value);
+            step(Q, std::integral_constant<bool, (decltype(Q)::value & 1) == role && decltype(Q)::value < 2>{}, ROLE, s4 + decltype(Q)::value);
         });
     };
     if (nh == 0) run(ic<0>{}); else run(ic<1>{});
@@ -359,76 +364,92 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     const float bias = a.bias ? a.bias[co] : 0.0f;
     const float slope = a.slope ? a.slope[co] : 0.0f;
     const int ldo = a.out.ld, ldr = a.res.ld;
-    const unsigned xw = lds0 + (unsigned)wave * 8192u + (unsigned)lane_e * 16u;
-    const unsigned xr = lds0 + (unsigned)(6 * nh) * 8192u + (unsigned)lane_e * 16u;
+    const unsigned xw = lds0 + (unsigned)wave * 8192u + (unsigned)lane_e * 8u;
+    const unsigned xr = lds0 + (unsigned)(6 * nh) * 8192u + (unsigned)lane_e * 8u;
     // Stores and residual loads go through range-checked buffer descriptors of THIS sample's output / residual view: a pixel outside the
-    // map gets the offset 2^31 and is dropped (loads return 0) by the hardware -- no divergent control flow, one code path for
-    // interior and ragged block tiles
+    // map gets the offset 2^31 and is dropped (loads return 0) by the hardware -- no divergent control flow on ragged block tiles
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out.p + (int64_t)n * ho * wo * ldo, 0,
                                                                          (int)((((int64_t)ho * wo - 1) * ldo + a.out.c) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(a.res_mode ? a.res.p + (int64_t)n * ho * wo * ldr : a.out.p, 0,
                                                                           a.res_mode ? (int)((((int64_t)ho * wo - 1) * ldr + a.res.c) * 4) : 0, 0x00020000);
-    // one finished element (a tile of this lane's channel): row pass, bias, residual, activation, 16 stores.
-    // ACT: compile-time activation (-1 = the run-time switch of apply_act); RES: a residual is added
-    auto finish = [&](auto ACT, auto RES, int h, int rr) __attribute__((always_inline)) {
+    const bool full = oy0 + kOH <= ho && ox0 + kOW <= wo;     // block-uniform: interior block tiles skip the per-pixel range tests
+    const f32x2n k8 = {sgf(8.0f), 0.0f};
+    // the contract's output transform O6 on PAIRS (v_pk_*: the same IEEE operations per component): components = two accumulator
+    // elements (column pass) / two tiles (row pass)
+    auto at6p = [&](f32x2n m0, f32x2n m1, f32x2n m2, f32x2n m3, f32x2n m4, f32x2n m5, f32x2n (&o)[4]) __attribute__((always_inline)) {
+        const f32x2n p = pk_add(m1, m2), q = pk_sub(m1, m2), r = pk_add(m3, m4), t = pk_sub(m3, m4);
+        o[0] = pk_add(pk_add(m0, p), r);
+        o[1] = pk_fma(k2, t, q);
+        o[2] = pk_fma(k4, r, p);
+        o[3] = pk_add(pk_fma(k8, t, q), m5);
+    };
+    // exchange area of a round: [wave][element pair p of the round's four][b][lane][2] (8 KB per wave).  A unit of the row pass = (pair p,
+    // output column b): six ds_read_b64, one packed O6 over the frequency rows, eight outputs (two tiles x four output rows a).
+    // ACT: compile-time activation (-1 = the run-time switch of apply_act); FULL: interior block; RES: a residual is added
+    auto finish = [&](auto ACT, auto FULL, auto RES, int h, int u) __attribute__((always_inline)) {
         constexpr int act_c = decltype(ACT)::value;
-        constexpr bool has_res = decltype(RES)::value;
-        const int r = 8 * h + rr;                              // element r: tile (tx, ty) = ((r & 3) + 4 lh, r >> 2) of the block's 8 x 4
-        f32x4n S[6];
+        constexpr bool has_res = decltype(RES)::value, is_full = decltype(FULL)::value;
+        const int pr = u >> 2, b = u & 3;
+        f32x2n S[6], Y[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) S[i] = lds_read4(xr + (unsigned)i * 8192u + (unsigned)rr * 1024u);
-        const int oyb = oy0 + 4 * (r >> 2), oxb = ox0 + 4 * ((r & 3) + 4 * le_h);
-        const int pix0 = oyb * wo + oxb;
-        f32x4n Y[4];                                          // Y[b] = (y[0][b], y[1][b], y[2][b], y[3][b])
-        Y[0] = at6(S[0].x, S[1].x, S[2].x, S[3].x, S[4].x, S[5].x);
-        Y[1] = at6(S[0].y, S[1].y, S[2].y, S[3].y, S[4].y, S[5].y);
-        Y[2] = at6(S[0].z, S[1].z, S[2].z, S[3].z, S[4].z, S[5].z);
-        Y[3] = at6(S[0].w, S[1].w, S[2].w, S[3].w, S[4].w, S[5].w);
-        static_for<16>([&](auto E) {
-            constexpr int e = decltype(E)::value, dy = e >> 2, dx = e & 3;
-            const f32x4n yb = Y[dx];
-            float v = (dy == 0 ? yb.x : (dy == 1 ? yb.y : (dy == 2 ? yb.z : yb.w))) + bias;
-            const bool ok = oyb + dy < ho && oxb + dx < wo;
-            const int pix = pix0 + dy * wo + dx;
+        for (int i = 0; i < 6; ++i) S[i] = lds_read2(xr + (unsigned)i * 8192u + (unsigned)u * 512u);
+        const int r0 = 8 * h + 2 * pr;                         // elements r0, r0 + 1: tiles (tx, ty) = ((r0 & 3) + 4 lh + e, r0 >> 2) of the block's 8 x 4
+        const int oyb = oy0 + 4 * (r0 >> 2), oxb = ox0 + 4 * ((r0 & 3) + 4 * le_h) + b;
+        const unsigned pix = (unsigned)(oyb * wo + oxb);
+        unsigned vb = (pix * (unsigned)ldo + (unsigned)co) * 4u;
+        const unsigned vbr = (pix * (unsigned)ldr + (unsigned)co) * 4u;
+        if constexpr (ABL & 64) vb &= 0x3ffffu;
+        at6p(S[0], S[1], S[2], S[3], S[4], S[5], Y);
+        static_for<8>([&](auto E) {
+            constexpr int e = decltype(E)::value & 1, aa = decltype(E)::value >> 1;
+            float v = (e ? Y[aa].y : Y[aa].x) + bias;
+            const bool ok = is_full || (oyb + aa < ho && oxb + 4 * e < wo);
+            const int so = (ABL & 64) ? 0 : (aa * wo + 4 * e) * ldo * 4;
             if constexpr (has_res) {
-                const float rv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_, ok ? (int)(((unsigned)pix * (unsigned)ldr + (unsigned)co) * 4u) : (int)kOob, 0, 0));
+                const float rv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_, ok ? (int)vbr : (int)kOob, (aa * wo + 4 * e) * ldr * 4, 0));
                 if (a.res_mode == 1) v += rv;
                 v = apply_act(v, act_c >= 0 ? act_c : a.act, slope);
                 if (a.res_mode == 2) v += rv;
             } else v = apply_act(v, act_c >= 0 ? act_c : a.act, slope);
-            if constexpr (!(ABL & 8))
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, ok ? (int)(((unsigned)pix * (unsigned)ldo + (unsigned)co) * 4u) : (int)kOob, 0, 0);
+            if constexpr (!(ABL & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, ok ? (int)vb : (int)kOob, so, 0);
         });
     };
-    auto finish_act = [&](auto RES, int h, int rr) __attribute__((always_inline)) {
+    auto finish_act = [&](auto FULL, auto RES, int h, int u) __attribute__((always_inline)) {
         switch (a.act) {                                       // uniform: the common activations get a body without the per-element switch
-            case CSM_ACT_NONE: finish(ic<CSM_ACT_NONE>{}, RES, h, rr); break;
-            case CSM_ACT_RELU: finish(ic<CSM_ACT_RELU>{}, RES, h, rr); break;
-            case CSM_ACT_SILU: finish(ic<CSM_ACT_SILU>{}, RES, h, rr); break;
-            default: finish(ic<-1>{}, RES, h, rr); break;
+            case CSM_ACT_NONE: finish(ic<CSM_ACT_NONE>{}, FULL, RES, h, u); break;
+            case CSM_ACT_RELU: finish(ic<CSM_ACT_RELU>{}, FULL, RES, h, u); break;
+            case CSM_ACT_SILU: finish(ic<CSM_ACT_SILU>{}, FULL, RES, h, u); break;
+            default: finish(ic<-1>{}, FULL, RES, h, u); break;
         }
     };
     // column pass (over j) of this wave's frequency row for all 16 accumulator elements FIRST (the 32x32 accumulators are register tuples:
-    // they stay allocated as long as any element is live); round 0's s[0..3] go to LDS, round 1's wait in registers
-    static_for<8>([&](auto RR) {
-        constexpr int r = decltype(RR)::value;
-        lds_write4(xw + (unsigned)r * 1024u, at6(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r]));
-    });
-    f32x4n s1[8];
-    static_for<8>([&](auto RR) {
-        constexpr int r = 8 + decltype(RR)::value;
-        s1[r - 8] = at6(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r]);
+    // they stay allocated as long as any element is live), two elements per packed operation; round 0's s values go to LDS, round 1's
+    // wait in registers
+    f32x2n sv[8][4];                                           // [element pair][b]
+    static_for<8>([&](auto PP) {
+        constexpr int r = 2 * decltype(PP)::value;
+        at6p(__builtin_shufflevector(acc[0], acc[0], r, r + 1), __builtin_shufflevector(acc[1], acc[1], r, r + 1),
+             __builtin_shufflevector(acc[2], acc[2], r, r + 1), __builtin_shufflevector(acc[3], acc[3], r, r + 1),
+             __builtin_shufflevector(acc[4], acc[4], r, r + 1), __builtin_shufflevector(acc[5], acc[5], r, r + 1), sv[decltype(PP)::value]);
+        if constexpr (decltype(PP)::value < 4) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) lds_write2(xw + (unsigned)(decltype(PP)::value * 4 + b) * 512u, sv[decltype(PP)::value][b]);
+        }
     });
     static_for<2>([&](auto H) {
         constexpr int h = decltype(H)::value;
-        if constexpr (h == 1) static_for<8>([&](auto RR) { lds_write4(xw + (unsigned)decltype(RR)::value * 1024u, s1[decltype(RR)::value]); });
+        if constexpr (h == 1) {
+            static_for<4>([&](auto PP) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) lds_write2(xw + (unsigned)(decltype(PP)::value * 4 + b) * 512u, sv[4 + decltype(PP)::value][b]);
+            });
+        }
         wait_barrier<0>();
-        // row pass (over i) + bias / residual / activation: this wave finishes elements [el0, el0 + nel) of the round
-        const int el0 = h == 0 ? (wi < 2 ? 2 * wi : wi + 2) : (wi < 4 ? wi : 2 * wi - 4);
-        const int nel = h == 0 ? (wi < 2 ? 2 : 1) : (wi < 4 ? 1 : 2);
-        for (int k = 0; k < nel; ++k) {
-            if (a.res_mode) finish_act(std::true_type{}, h, el0 + k);
-            else finish_act(std::false_type{}, h, el0 + k);
+        // row pass (over i) + bias / residual / activation: this wave finishes units wi, wi + 6, wi + 12 (< 16) of the round
+        for (int u = wi; u < 16; u += 6) {
+            if (a.res_mode) { if (full) finish_act(std::true_type{}, std::true_type{}, h, u); else finish_act(std::false_type{}, std::true_type{}, h, u); }
+            else if (full) finish_act(std::true_type{}, std::false_type{}, h, u);
+            else finish_act(std::false_type{}, std::false_type{}, h, u);
         }
         if constexpr (h == 0) wait_barrier<0>();              // the exchange area is rewritten by the second round
     });
@@ -474,6 +495,8 @@ static int launch_conv_wino4_chunk(const ConvArgs &a0, hipStream_t st) {
         case 35: return go(&k_conv_wino4<35>);
         case 51: return go(&k_conv_wino4<51>);
         case 59: return go(&k_conv_wino4<59>);
+        case 100: return go(&k_conv_wino4<0, 1>);
+        case 64: return go(&k_conv_wino4<64>);
         default: break;
     }
 #endif
