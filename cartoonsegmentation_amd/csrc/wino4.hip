@@ -128,7 +128,7 @@ __host__ __device__ constexpr int psi_k(int r, int c) { return ((c >> 1) & 1) * 
 // ABL (development ablations, timing only -- results invalid): 1 = no DMA, 2 = no transform, 4 = no MFMA, 8 = no epilogue stores,
 // 16 = no barrier in the main loop, 32 = no operand reads (A / B fragments) in the main loop, 64 = every block stores into the first
 // 256 KB of the output (same instructions, no HBM write traffic: is the epilogue's time arithmetic or the write burst?)
-template <int ABL = 0, int DMA_STAGGER = 0>
+template <int ABL = 0>
 __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(64))) float lds[];   // [raw 0][raw 1][V 0][V 1][U: 12 waves x 2 slots]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     auto step = [&](auto Q, auto XF, auto ROLE, int s) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value;
         constexpr bool xf = decltype(XF)::value;
-        constexpr int u0 = (DMA_STAGGER && decltype(ROLE)::value) ? 6 : 0;     // slots of the three U pieces: the two channel halves do not issue in the same slots
+        constexpr int u0 = 0;                                  // slots [u0, u0 + 3) send the three U pieces (issuing the two channel halves in different slots measured equal)
         constexpr int rbuf = ((q + 2) >> 1) & 1;               // raw buffer of step s + 2: stage (s + 2) >> 1
         unsigned offq0 = 0u, offq1 = 0u;
         if constexpr (xf) xf_begin(ic<rbuf>{});
@@ -495,7 +495,6 @@ static int launch_conv_wino4_chunk(const ConvArgs &a0, hipStream_t st) {
         case 35: return go(&k_conv_wino4<35>);
         case 51: return go(&k_conv_wino4<51>);
         case 59: return go(&k_conv_wino4<59>);
-        case 100: return go(&k_conv_wino4<0, 1>);
         case 64: return go(&k_conv_wino4<64>);
         default: break;
     }
