@@ -12,21 +12,32 @@
 //   * block = 12 waves (three per SIMD, <= 168 registers), ONE block per CU: 8 x 4 Winograd tiles (32 x 16 output pixels) x 64 output
 //     channels.  Wave (i, nh) owns frequency ROW i (six 32x32 accumulators = 96 registers) of the 32 tiles x output channels
 //     [32 nh, 32 nh + 32).
-//   * step = 4 input channels (two MFMAs per frequency and wave).  The raw input patch ((16 + 2) x (32 + 2) pixels) is staged by LDS-DMA
-//     16 channels (= 4 steps) at a time, two stages; its 16-byte granules (pixel, 4 channels) sit at  4 psi + (slot ^ ((row >> 2) & 3)),
-//     psi = ((col >> 1) & 1) 324 + 18 row + 9 (col & 1) + (col >> 2):  the stride-4 windows of a lane group's 8 x 4 tiles are 8 consecutive
-//     64-byte pixel entries per tile row, rows alternate between the two halves of a 16-granule period, and the slot swizzle spreads
-//     a fixed slot over the four 16-byte positions -- a ds_read_b64 of one channel pair touches every bank at most twice (the minimum for
-//     8-byte reads of 16-byte granules), and four consecutive DMA lanes fetch the 64 contiguous bytes of one pixel.
-//   * transform: in step s the three waves of group s & 3 turn the raw window of step s + 1 into V[f][k-half][tile][2 channels] in LDS
-//     (unit = (tile, row pair {1,2} / {3,4} / {0,5}, k-half): row pass with the pair's shared terms, column pass, 96 VALU, 24-36
-//     ds_read_b64, 12 ds_write_b64) -- once per block, shared by both channel halves; the other waves' MFMAs cover it.
-//   * A fragments: one conflict-free ds_read_b64 per frequency and step (two k-steps); B fragments: the transformed weights are packed on
-//     the host so that a wave's share of a step is three 1-KB LDS-DMA pieces into a PRIVATE 3-KB slot (no barrier: only this wave reads
-//     them), each lane picking its four values of two frequencies with one ds_read_b128 into registers a step ahead.
-//   * ONE barrier per step; everything the next step needs has been issued a full step before it is waited for.
-//   * epilogue: column pass of A^T M A in registers (a wave holds whole frequency rows), the six waves of a channel half exchange the
-//     row-pass inputs through LDS in two rounds of eight accumulator elements, each wave finishes 2-3 tiles per lane.
+//   * step = 4 input channels = two MFMAs per frequency = 12 MFMA slots per wave; ONE barrier per step, and it waits for LDS traffic
+//     only: every fetch is waited for (vmcnt) a step after it was sent, by the wave that sent it.
+//   * raw input patch ((16 + 2) x (32 + 2) pixels): LDS-DMA, 8 channels (= 2 steps) per stage, two stages.  A pixel entry is 32 B (two
+//     16-byte granules = the channels of k-half 0 / 1) at  psi = ((col >> 1) & 1) 324 + 18 row + 9 (col & 1) + (col >> 2), granule
+//     slot ^ ((row >> 2) & 1):  the stride-4 windows of a lane group's 8 x 4 tiles are 8 consecutive entries per tile row, and a
+//     ds_read_b64 of one channel pair touches every bank at most twice (the minimum for 8-byte reads of 16-byte granules); two
+//     consecutive DMA lanes fetch the 32 contiguous bytes of a pixel.  The loader's two global offsets per lane live in LDS (no
+//     register is free for them in the main loop).
+//   * transform B^T d B: ONCE per block, through LDS, by the waves of channel half s & 1 during step s for step s + 2 (each wave
+//     transforms every other step).  Unit = (tile, frequency row = the wave's own row, k-half): row pass over the six window columns
+//     (four ds_read_b64 and three v_pk_fma_f32 per column -- the two channels of a lane are the two halves of a packed operation;
+//     ONE code path for all six rows with wave-uniform coefficients), column pass (the contract's T6, packed), six ds_write_b64 into
+//     V[f][k-half][tile][2].  The work is cut into twelve slices placed behind the wave's MFMAs; loads run two slices ahead.
+//   * A fragments: one conflict-free ds_read_b64 per frequency and step; B fragments: the transformed weights are packed on the host so
+//     that a wave's share of a step is three 1-KB LDS-DMA pieces into one of its TWO private 3-KB slots (no barrier: only this wave
+//     reads them), sent two steps ahead; a lane picks its four values of two frequencies with one ds_read_b128.  The operands of step
+//     s + 1 replace the dead ones of step s from slot 6 on, so the first MFMA of a step issues right behind the barrier.
+//   * the main loop exists twice (one copy per channel half = per parity of the steps in which a wave transforms): inside a copy every
+//     step is straight-line code, and the compiler's wait counts are exact (a branch per slice made every slice drain the LDS queue).
+//   * epilogue: column pass of A^T M A in registers, two accumulator elements per packed operation; the six waves of a channel half
+//     exchange the row-pass inputs through LDS in two rounds of four element pairs; unit of the row pass = (tile pair, output column);
+//     stores and residual loads go through range-checked buffer descriptors (ragged block tiles need no divergent control flow).
+// Measured (profiles/r06_*): 1.3-1.5x k_conv_wino8 on the 128/256-channel layers at batch 8, 1.1-1.2x on the 32/64-channel ones; where
+// the time goes (ablations): the matrix pipe alone 450 us of 700-770 at 160^2 256->256; fp32 MFMA shares its issue with the
+// transform's VALU and the DMA issue (they add up instead of overlapping), the 12-wave barrier costs ~15 %, and the epilogue's
+// output leaves as one synchronized burst per round (stores into a 256-KB window cost nothing).
 #include "csm_conv.h"
 #include <utility>
 #include <cstdlib>
@@ -317,7 +328,9 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
             } else if constexpr (m == 5 && (q & 1) == 0) {
                 issue_raw_off((s >> 1) + 2, ic<1>{}, offq1, (s >> 1) + 2 < nstages);
             }
-            if constexpr (xf) xf_slice(ic<rbuf>{}, M);
+            // (slice k runs one slot late: the first window column's loads, sent at the top of the step, return under slot 0's MFMA)
+            if constexpr (xf && m >= 1) xf_slice(ic<rbuf>{}, ic<m - 1>{});
+            if constexpr (xf && m == 11) xf_slice(ic<rbuf>{}, ic<11>{});
             if constexpr (ABL & 32) {
             } else if constexpr (m == 6) {
                 // everything sent before this step has landed: B(s + 1), and the raw pieces of step s - 1
