@@ -72,6 +72,6 @@ json.dump(traffic, open("$OUT/traffic.json","w"), indent=1)
 for k,v in sorted(tr.items(), key=lambda kv:-kv[1].get("fetch_KB",0))[:16]: print(k, v)
 PY
 # pipe-utilisation counters (SQ / LDS / L2) of the kernels that carry the conv time + the warp render pass: one table
-# (round 5: the Winograd layers k_conv_wino8 + two direct layers + the warp render pass; tools/gpu/r05_pmc.sh)
-bash /root/repo/tools/gpu/r05_pmc.sh > $OUT/pmc_sq.log 2>&1; python /root/repo/tools/pmc_table.py /root/repo/gpurun_out/r05pmc/summary.txt > $OUT/conv_pmc.txt 2>&1; cat $OUT/conv_pmc.txt
+# (the Winograd layers -- round 6: k_conv_wino4 -- + two direct layers + the warp render pass; tools/gpu/pmc_layers.sh)
+bash /root/repo/tools/gpu/pmc_layers.sh > $OUT/pmc_sq.log 2>&1; python /root/repo/tools/pmc_table.py /root/repo/gpurun_out/r06pmc/summary.txt > $OUT/conv_pmc.txt 2>&1; cat $OUT/conv_pmc.txt
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +1M -delete; find $OUT -name "*agent_info.csv" -delete
