@@ -787,11 +787,17 @@ def main():
         # rank 0 saved (CSM_TUNE_CACHE: no tuning launches on 7 of 8 ranks) and with PLACEHOLDER weights (zeros of the right shapes):
         # what they compute with arrives through the RCCL broadcast below, like a checkpoint read by rank 0 would
         # (the table travels through the process group -- broadcast_object_list -- not through a shared file: every rank keeps a PRIVATE copy)
-        os.environ["CSM_TUNE_CACHE"] = "/tmp/csm_tune_%s_%s_rank%d.txt" % (os.environ.get("MASTER_PORT", "0"), a.size, rank)
+        # the file is private to THIS process (pid in the name, removed at exit): a table left behind by another run -- another build of the
+        # library, another port reuse -- can never be picked up
+        import atexit
+        import tempfile
+        tune_path = os.path.join(tempfile.gettempdir(), "csm_tune_%s_%s_rank%d_pid%d.txt" % (os.environ.get("MASTER_PORT", "0"), a.size, rank, os.getpid()))
+        os.environ["CSM_TUNE_CACHE"] = tune_path
+        if os.path.exists(tune_path):
+            os.remove(tune_path)
+        atexit.register(lambda: os.path.exists(tune_path) and os.remove(tune_path))
         if rank != 0:
             os.environ["CSM_WEIGHTS_PLACEHOLDER"] = "1"
-            if os.path.exists(os.environ["CSM_TUNE_CACHE"]):
-                os.remove(os.environ["CSM_TUNE_CACHE"])
     wl = make_workload(a.workload, a.size, rank, device, world, dist, a.batch)
 
     weights_equal = None
