@@ -276,9 +276,18 @@ class KenBurnsPipeline:
         """_depth_est_zoe for several frames of ONE size: a single DepthModel.infer over the stack (B frames + their mirrored passes = 2 B
         samples of one core run: the layer programs are batch invariant, every frame's bits are those of a run by itself)"""
         from .zoedepth import depth_to_disparity
-        x = torch.cat([ops.image_tensor(f) for f in frames_d], 0)
+        n = len(frames_d)
+        # The core keeps one compiled program per (2 B, prepared size) and a new one costs a host re-pack of 345 M parameters: a tail
+        # group (fewer frames than the group before it, same frame size) is PADDED to the resident batch with copies of its last frame
+        # instead of building a second program -- the layer programs are batch invariant, so the kept frames' bits do not change
+        key = tuple(frames_d[0].shape)
+        resident = getattr(self, '_zoe_group', None)
+        pad = resident[1] - n if resident is not None and resident[0] == key and resident[1] > n else 0
+        x = torch.cat([ops.image_tensor(f) for f in frames_d] + [ops.image_tensor(frames_d[-1])] * pad, 0)
+        if pad == 0:
+            self._zoe_group = (key, n)
         depth = self.depth_zoe.infer(x, with_flip_aug=True, pad_input=True)
-        return [depth_to_disparity(depth[k:k + 1].contiguous(), self.cfg.focal, self.cfg.baseline) for k in range(len(frames_d))]
+        return [depth_to_disparity(depth[k:k + 1].contiguous(), self.cfg.focal, self.cfg.baseline) for k in range(n)]
 
     def _set_default_estimator(self):
         """anime_3dkenburns/models/__init__.py:33-52: Semantics (torchvision vgg19_bn) + Disparity (network-disparity.pytorch)"""

@@ -400,3 +400,36 @@ def test_zoe_depth_estimation_is_wired_into_the_pipeline():
     assert len(frames) == 2 and frames[0].shape == (320, 352, 3)
     kcs = pipe.generate_kenburns_configs([img, synth.image_u8(320, 352, 92)])        # batched API dispatches on the selected estimator
     assert torch.equal(kcs[0]['tenRawPoints'], kc['tenRawPoints'])
+
+
+def test_zoe_tail_group_is_padded_to_the_resident_batch():
+    """the DPT-BEiT core keeps one program per (2 B, prepared size) and a new one costs a host re-pack of 345 M parameters.
+    A tail group (fewer frames than the group before it, same frame size) is padded to the resident batch with copies of its last
+    frame: the core sees the SAME batch again, and the kept frames' results are those of the frames by themselves"""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import zoe_stub_core as stub
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from anime_3dkenburns import KenBurnsConfig, KenBurnsPipeline
+    from cartoonsegmentation_amd import synth
+    cfg = KenBurnsConfig(det_ckpt='synthetic', depth_est='zoe', max_size=512, refine_crf=False, focal=176.0, num_frame=2,
+                         mask_refine_kwargs={'refine_method': 'none'})
+    pipe = KenBurnsPipeline(cfg)
+    seen = []
+
+    def core(x, *a, **k):
+        seen.append(int(x.shape[0]))
+        return stub.core(x, *a, **k)
+    pipe.set_zoe_core(core)
+    frames = [torch.from_numpy(synth.image_u8(160, 192, 300 + i)).cuda() for i in range(5)]
+    alone = [pipe._depth_est_zoe_batch([f])[0].clone() for f in frames]
+    pipe._zoe_group = None
+    seen.clear()
+    first = pipe._depth_est_zoe_batch(frames[:3])
+    tail = pipe._depth_est_zoe_batch(frames[3:])
+    torch.cuda.synchronize()
+    assert len(set(seen)) == 1, seen                       # the core ran the same batch (3 frames + their mirrored passes) both times
+    for got, ref in zip(first + tail, alone):
+        assert torch.equal(got, ref)
+    other = pipe._depth_est_zoe_batch([torch.from_numpy(synth.image_u8(128, 160, 9)).cuda()] * 2)     # another frame size: no padding
+    assert len(other) == 2
