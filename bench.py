@@ -576,15 +576,15 @@ class FrameWorkload(Workload):
         import math
         a, pipe = self.pipe.animeinsseg, self.pipe
         nb, S = self.frames_per_step, a.default_det_size
-        a._detector(S, nb)
+        bufs = [a._detector(S, nb)[1].weights]
         if a.refine_method == 'refinenet_isnet':
-            a._refiner(min(a.refine_batch, nb * self.INSTANCES), a.refine_size)
+            bufs.append(a._refiner(min(a.refine_batch, nb * self.INSTANCES), a.refine_size).weights)
         from cartoonsegmentation_amd.segmentation import scaledown_size
         h, w = scaledown_size(self.H, self.W, pipe.cfg.depth_est_size)
-        pipe._leres_prog(int(math.ceil(h / 32) * 32), int(math.ceil(w / 32) * 32), nb)
-        bufs = [a._det_weights, a._refine_weights, pipe._leres_weights]
-        assert all(b is not None for b in bufs[:1] + bufs[2:]), "weight buffers missing"
-        return [b for b in bufs if b is not None]
+        bufs.append(pipe._leres_prog(int(math.ceil(h / 32) * 32), int(math.ceil(w / 32) * 32), nb).weights)
+        # (the packed images of the headline programs: a program of another shape shares them only where its packing is the same --
+        # CompiledProgram's `shared` registry -- and would otherwise pack its own copy from the rank's own weight source)
+        return bufs
 
     def broadcast_weights(self):
         """one RCCL broadcast per packed weight buffer (RTMDet 0.37 GB, ISNet 0.18 GB, LeReS 0.63 GB), start-up only"""

@@ -186,6 +186,7 @@ bool wino_eligible(const ConvArgs &a);
 int launch_conv_wino(const ConvArgs &a, hipStream_t st);
 // Winograd F(4x4, 3x3) convolution (wino4.hip): k_conv_wino4 for an op that carries CSM_CONV_FLAG_WINOGRAD4
 bool wino4_eligible(const ConvArgs &a);
+int64_t wino4_scratch_floats(int n, int h, int w, int cout);      // scratch of the row-split forms: 24 floats per 4x4 tile and channel
 int launch_conv_wino4(const ConvArgs &a, hipStream_t st);
 
 }  // namespace csmconv

@@ -2538,6 +2538,14 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                     break;
                 }
                 if (op.flags & CSM_CONV_FLAG_WINOGRAD4) {     // Winograd F(4x4, 3x3): the same layer class, 36 instead of 64 products per 4x4 outputs (wino4.hip)
+                    if (op.scratch >= 0) {                    // optional scratch of the row-split execution forms (small launches): speed only
+                        View sc{};
+                        rc = make_view(tensors, n_tensors, op.scratch, workspace, ext, n_ext, sc); if (rc) return rc;
+                        if ((int64_t)sc.n * sc.h * sc.w * sc.c < wino4_scratch_floats(out.n, out.h, out.w, op.cout_g) || sc.ld != sc.c || (((uintptr_t)sc.p) & 15)) {
+                            csm::set_error("op %d: Winograd F(4x4) scratch tensor too small or not contiguous", i); return CSM_ERR_ARG;
+                        }
+                        a.partial = sc.p;
+                    }
                     if (!wino4_eligible(a)) { csm::set_error("op %d: Winograd F(4x4) flag on an ineligible convolution (3x3 / stride 1 / pad 1 / dense / cin %% 32 / cout %% 64 / ksplit 1)", i); return CSM_ERR_ARG; }
                     rc = launch_conv_wino4(a, st);
                     if (rc) return rc;

@@ -125,13 +125,20 @@ constexpr int kPW = kOW + 2, kPH = kOH + 2;                  // 34 x 18 patch pi
 constexpr int kPsi = 2 * 18 * 18;                            // 648 pixel entries (32 B = 8 channels each) of a raw stage
 constexpr int kRawPieces = (kPsi * 2 + 63) / 64;             // 21 DMA pieces
 constexpr unsigned kRawB = kRawPieces * 1024u;               // 21 504 B per stage
-constexpr unsigned kVB = 36u * 512u;                         // 18 432 B: V[f][k-half][32 tiles][2]
-constexpr unsigned kV0 = 2u * kRawB, kU0 = kV0 + 2u * kVB;   // 43 008, 79 872
+constexpr unsigned kV0 = 2u * kRawB;                         // 43 008
 constexpr unsigned kUW = 3072u;                              // a wave's U slot (three pieces); two slots per wave
-constexpr unsigned kLds = kU0 + 24u * kUW;                   // 153 600 B (+ 6 KB: the raw loader's offsets)
-constexpr unsigned kLdsAll = kLds + 768u * 8u;
 constexpr unsigned kOob = 0x80000000u;
-static_assert(kPH == 18 && kPW == 34 && kLdsAll <= 160u * 1024u, "tile shape");
+// LDS map of a block that owns RPB of the six frequency rows (2 RPB waves): [raw 0][raw 1][V 0][V 1][U: 2 RPB waves x 2 slots][raw loader's offsets]
+//   RPB = 6: the fused form (12 waves, one block per CU, 156 KB);  RPB = 1 / 2 / 3: the row-split forms (2 / 4 / 6 waves, 61 / 79 / 98 KB)
+constexpr unsigned vb_of(int rpb) { return (unsigned)rpb * 6u * 512u; }                         // V[row][j][k-half][32 tiles][2] of one step
+constexpr unsigned u0_of(int rpb) { return kV0 + 2u * vb_of(rpb); }
+constexpr unsigned lds_of(int rpb) { return u0_of(rpb) + (unsigned)(2 * rpb) * 2u * kUW; }
+constexpr int ppw_of(int rpb) { return (kRawPieces + 2 * rpb - 1) / (2 * rpb); }                // raw pieces per wave and stage
+constexpr int ppe_of(int rpb) { return (ppw_of(rpb) + 1) & ~1; }                                // ... rounded up to pairs (read as 8-byte words)
+// (the fused form has no register left for the loader's offsets and parks them in LDS; the row-split forms keep them in registers --
+// two blocks of RPB = 2 then fit a CU)
+constexpr unsigned lds_all_of(int rpb) { return lds_of(rpb) + (rpb == 6 ? (unsigned)(2 * rpb) * 64u * (unsigned)ppe_of(rpb) * 4u : 0u); }
+static_assert(kPH == 18 && kPW == 34 && lds_all_of(6) <= 160u * 1024u, "tile shape");
 
 // pixel entry of patch position (row r, column c) relative to the entry of (4 ty, 4 tx): compile-time part of psi
 __host__ __device__ constexpr int psi_k(int r, int c) { return ((c >> 1) & 1) * 324 + r * 18 + (c & 1) * 9 + (c >> 2); }
@@ -139,14 +146,23 @@ __host__ __device__ constexpr int psi_k(int r, int c) { return ((c >> 1) & 1) * 
 // ABL (development ablations, timing only -- results invalid): 1 = no DMA, 2 = no transform, 4 = no MFMA, 8 = no epilogue stores,
 // 16 = no barrier in the main loop, 32 = no operand reads (A / B fragments) in the main loop, 64 = every block stores into the first
 // 256 KB of the output (same instructions, no HBM write traffic: is the epilogue's time arithmetic or the write burst?)
-template <int ABL = 0>
-__global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, int tiles_y) {
-    extern __shared__ __attribute__((aligned(64))) float lds[];   // [raw 0][raw 1][V 0][V 1][U: 12 waves x 2 slots]
+// RPB: frequency rows per block.  6 = the FUSED form (a block owns all 36 frequencies of its tile and finishes the outputs itself).
+// 1 / 2 / 3 = the ROW-SPLIT forms for launches with fewer block tiles than CUs (single frames, small maps): gridDim.y = cout tiles x 6 / RPB,
+// a block owns RPB rows (2 RPB waves, several blocks per CU), does the column pass of A^T M A on them and writes s[i][b] (four values per
+// row, tile and channel) to a scratch buffer; k_wino4_rowpass finishes.  Same expressions on the same values: the forms give the same bits.
+template <int ABL = 0, int RPB = 6>
+__global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void k_conv_wino4(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int NW = 2 * RPB, PPW = ppw_of(RPB), PPE = ppe_of(RPB);
+    constexpr unsigned kVB = vb_of(RPB), kU0 = u0_of(RPB), kLds = lds_of(RPB);
+    extern __shared__ __attribute__((aligned(64))) float lds[];   // [raw 0][raw 1][V 0][V 1][U: NW waves x 2 slots][offsets]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nh = wave / 6, wi = wave - 6 * nh;              // channel half, frequency row
+    const int nh = wave / RPB, rl = wave - RPB * nh;          // channel half, frequency row inside the block
     const int li = lane & 31, lh = lane >> 5;
     int mt, ntile, zz;
     block_to_tile(mt, ntile, zz, 1);                          // cout tile slowest: the blocks resident on an XCD share one 64-channel U panel
+    const int rg = RPB == 6 ? 0 : ntile % (6 / RPB);          // row group of a row-split block
+    if constexpr (RPB != 6) ntile /= (6 / RPB);
+    const int wi = rg * RPB + rl;                             // frequency row
     const int btx = mt % tiles_x, bty = (mt / tiles_x) % tiles_y, n = mt / (tiles_x * tiles_y);
     const int ho = a.out.h, wo = a.out.w;
     const int nsteps = a.cin_g >> 2, nstages = nsteps >> 1;   // a raw stage = 8 channels = 2 steps
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     // ---- this wave's U stream: step s at ((ntile nsteps + s) 12 + wave) 3 KB -> slot s & 1 ----
     const unsigned voffU = (unsigned)lane * 16u;
-    unsigned u_src = (unsigned)((ntile * nsteps) * 12 + wave) * kUW;         // next step to fetch
+    unsigned u_src = (unsigned)((ntile * nsteps) * 12 + 6 * nh + wi) * kUW;  // next step to fetch
     const unsigned ldsU = lds0 + kU0 + (unsigned)wave * (2u * kUW);
     const unsigned blane = ldsU + voffU;
 #pragma unroll
@@ -176,42 +192,48 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     }
     u_src += 24u * kUW;
 
-    // ---- raw patch loader: wave w owns pieces w and w + 12 of a stage.  Granule g = 2 psi + s' sits at LDS position g; it holds channels
+    // ---- raw patch loader: wave w owns pieces w, w + NW, ... of a stage.  Granule g = 2 psi + s' sits at LDS position g; it holds channels
     // [4 slot, 4 slot + 4) of the stage's eight, slot = s' ^ ((row >> 2) & 1) ----
-    // (the two global offsets of a lane live in LDS behind the U slots, 8 B per lane: no register is free for them in the main loop, and
-    // a scratch reload would put a vmcnt(0) in front of every raw fetch)
-    const unsigned offL = lds0 + kLds + (unsigned)tid * 8u;
-    unsigned offP[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int pp = wave + 12 * q;
+    // (a lane's global offsets live in LDS behind the U slots: no register is free for them in the main loop, and a scratch reload
+    // would put a vmcnt(0) in front of every raw fetch)
+    const unsigned offL = lds0 + kLds + (unsigned)tid * (unsigned)(PPE * 4);
+    auto raw_lds = [&](int stage, int q) __attribute__((always_inline)) {
+        int pp = wave + NW * q;
         if (pp > kRawPieces - 1) pp = kRawPieces - 1;         // (a piece past the end repeats the last one: same bytes, same place)
-        const int g = 64 * pp + lane;
-        const int psi = g >> 1, sl = g & 1;
-        const int crh = psi / 324, rem = psi - crh * 324, R = rem / 18, r2 = rem - R * 18, c1 = r2 / 9, cq = r2 - c1 * 9;
-        const int C = 4 * cq + 2 * crh + c1;
-        const int slot = sl ^ ((R >> 2) & 1);
-        const int iy = oy0 - 1 + R, ix = ox0 - 1 + C;
-        const bool v = psi < kPsi && C < kPW && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
-        offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
-    }
-    lds_write2u(offL, u32x2n{offP[0], offP[1]});
-    auto issue_raw_off = [&](int stage, auto QQ, unsigned off, bool live) __attribute__((always_inline)) {     // piece q of this wave, 8-channel stage `stage` -> raw buffer stage & 1
-        constexpr int q = decltype(QQ)::value;
-        if constexpr (!(ABL & 1)) {
-            int pp = wave + 12 * q;
-            if (pp > kRawPieces - 1) pp = kRawPieces - 1;
-            dma16s(live ? off : kOob, ra, (unsigned)stage * 32u, lds0 + (unsigned)(stage & 1) * kRawB + (unsigned)pp * 1024u);
-        }
+        return lds0 + (unsigned)(stage & 1) * kRawB + (unsigned)pp * 1024u;
     };
-    issue_raw_off(0, ic<0>{}, offP[0], true); issue_raw_off(0, ic<1>{}, offP[1], true);
-    issue_raw_off(1, ic<0>{}, offP[0], nstages > 1); issue_raw_off(1, ic<1>{}, offP[1], nstages > 1);
+    unsigned offP[PPE];
+    {
+#pragma unroll
+        for (int q = 0; q < PPE; ++q) {
+            int pp = wave + NW * q;
+            if (pp > kRawPieces - 1) pp = kRawPieces - 1;
+            const int g = 64 * pp + lane;
+            const int psi = g >> 1, sl = g & 1;
+            const int crh = psi / 324, rem = psi - crh * 324, R = rem / 18, r2 = rem - R * 18, c1 = r2 / 9, cq = r2 - c1 * 9;
+            const int C = 4 * cq + 2 * crh + c1;
+            const int slot = sl ^ ((R >> 2) & 1);
+            const int iy = oy0 - 1 + R, ix = ox0 - 1 + C;
+            const bool v = psi < kPsi && C < kPW && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+            offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
+        }
+        if constexpr (RPB == 6) {
+#pragma unroll
+            for (int q = 0; q < PPE; q += 2) lds_write2u(offL + (unsigned)q * 4u, u32x2n{offP[q], offP[q + 1]});
+        }
+        if constexpr (!(ABL & 1)) {
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) dma16s(offP[q], ra, 0u, raw_lds(0, q));
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) dma16s(nstages > 1 ? offP[q] : kOob, ra, 32u, raw_lds(1, q));
+        }
+    }
 
     // ---- fragment / unit addresses ----
     const int tx = li & 7, ty = li >> 3;
     const unsigned ubase = lds0 + (unsigned)(ty * 72 + tx) * 32u + (unsigned)nh * 8u;      // (this wave transforms steps sn = nh mod 2: half nh)
     const unsigned bxA = ubase + (unsigned)((lh ^ (ty & 1)) << 4), bxB = ubase + (unsigned)((lh ^ ((ty + 1) & 1)) << 4);
-    const unsigned vlane = lds0 + kV0 + (unsigned)lh * 256u + (unsigned)li * 8u + (unsigned)(wi * 6) * 512u;     // + parity kVB + j 512
+    const unsigned vlane = lds0 + kV0 + (unsigned)lh * 256u + (unsigned)li * 8u + (unsigned)(rl * 6) * 512u;     // + parity kVB + j 512
     const unsigned vdst = vlane + (unsigned)nh * kVB;
     // transform unit of this lane: frequency ROW wi of tile li, k-half lh, two channels.  ONE code path for all six rows:
     //   t = fmaf(g, fmaf(c1, dP, dQ), fmaf(c2, dR, dS))      (wave-uniform coefficients, four window rows)
@@ -320,13 +342,14 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
                 if constexpr (!(ABL & 1)) dma16s(s + 2 < nsteps ? voffU : kOob, rb, u_src + (unsigned)(m - u0) * 1024u, ldsU + (unsigned)(q & 1) * kUW + (unsigned)(m - u0) * 1024u);
                 if constexpr (m == u0 + 2) u_src += 12u * kUW;
             }
-            if constexpr (m == 3 && (q & 1) == 0) {
-                const u32x2n o2 = lds_read2u(offL);           // (used in slots 4 and 5)
+            // raw stage s / 2 + 2 (EVEN steps): piece k of this wave goes out in slot k + 1, its offset pair is read in slot k & ~1
+            if constexpr ((q & 1) == 0 && m >= 1 && m <= PPW) {
+                if constexpr (!(ABL & 1))
+                    dma16s((s >> 1) + 2 < nstages ? (RPB != 6 ? offP[m - 1] : (((m - 1) & 1) ? offq1 : offq0)) : kOob, ra, (unsigned)((s >> 1) + 2) * 32u, raw_lds((s >> 1) + 2, m - 1));
+            }
+            if constexpr (RPB == 6 && (q & 1) == 0 && (m & 1) == 0 && m < PPW) {
+                const u32x2n o2 = lds_read2u(offL + (unsigned)m * 4u);
                 offq0 = o2.x; offq1 = o2.y;
-            } else if constexpr (m == 4 && (q & 1) == 0) {
-                issue_raw_off((s >> 1) + 2, ic<0>{}, offq0, (s >> 1) + 2 < nstages);
-            } else if constexpr (m == 5 && (q & 1) == 0) {
-                issue_raw_off((s >> 1) + 2, ic<1>{}, offq1, (s >> 1) + 2 < nstages);
             }
             // (slice k runs one slot late: the first window column's loads, sent at the top of the step, return under slot 0's MFMA)
             if constexpr (xf && m >= 1) xf_slice(ic<rbuf>{}, ic<m - 1>{});
@@ -334,8 +357,8 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
             if constexpr (ABL & 32) {
             } else if constexpr (m == 6) {
                 // everything sent before this step has landed: B(s + 1), and the raw pieces of step s - 1
-                // (issued in this step before this point: the U pieces of slots [u0, 6] and, in even steps, two raw pieces)
-                constexpr int mine = (u0 == 0 ? 3 : 1) + ((q & 1) == 0 ? 2 : 0);
+                // (issued in this step before this point: the three U pieces and, in even steps, the raw pieces of slots 1..6)
+                constexpr int mine = 3 + ((q & 1) == 0 ? (PPW < 6 ? PPW : 6) : 0);
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(mine) : "memory");
                 Bq[0] = lds_read4(blane + (unsigned)((q + 1) & 1) * kUW);
 #pragma unroll
@@ -376,6 +399,20 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     const int co = ntile * 64 + 32 * nh + le_i;
     const float bias = a.bias ? a.bias[co] : 0.0f;
     const float slope = a.slope ? a.slope[co] : 0.0f;
+    if constexpr (RPB != 6) {
+        // ---- row-split form: column pass (over j) of this wave's frequency row, s[0..3] per (tile, channel) -> scratch[tile][row][channel][4]
+        // (tiles numbered (sample, tile row, tile column) over the whole map; k_wino4_rowpass finishes) ----
+        const int tx_n = (wo + 3) >> 2, ty_n = (ho + 3) >> 2;
+        float *sp = a.partial + ((int64_t)wi * a.cout_g + co) * 4;
+        static_for<16>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            const f32x4n sv = at6(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r]);
+            const int txg = btx * kTX + (r & 3) + 4 * le_h, tyg = bty * kTY + (r >> 2);
+            if (txg < tx_n && tyg < ty_n)
+                *reinterpret_cast<f32x4n *>(sp + (((int64_t)n * ty_n + tyg) * tx_n + txg) * (int64_t)(24 * a.cout_g)) = sv;
+        });
+        return;
+    }
     const int ldo = a.out.ld, ldr = a.res.ld;
     const unsigned xw = lds0 + (unsigned)wave * 8192u + (unsigned)lane_e * 8u;
     const unsigned xr = lds0 + (unsigned)(6 * nh) * 8192u + (unsigned)lane_e * 8u;
@@ -468,6 +505,42 @@ __global__ __launch_bounds__(768, 1) void k_conv_wino4(ConvArgs a, int tiles_x, 
     });
 }
 
+// Second kernel of the row-split forms: the row pass (over i) of A^T M A on the six rows' s[i][b] a row-split launch left in the scratch
+// buffer, + bias / residual / activation: the same expressions on the same values as the fused epilogue.  One thread per (tile, output
+// channel), channel fastest: 16-byte coalesced reads, 128-byte segments per pixel on the way out.
+__global__ __launch_bounds__(256) void k_wino4_rowpass(ConvArgs a, int tx_n, int ty_n) {
+    const int cout = a.cout_g;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)a.out.n * ty_n * tx_n * cout;
+    if (idx >= total) return;
+    const int co = (int)(idx % cout);
+    const int64_t tile = idx / cout;
+    const int txg = (int)(tile % tx_n), tyg = (int)((tile / tx_n) % ty_n), n = (int)(tile / ((int64_t)tx_n * ty_n));
+    const float *sp = a.partial + tile * (int64_t)(24 * cout) + (int64_t)co * 4;
+    f32x4n S[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S[i] = *reinterpret_cast<const f32x4n *>(sp + (int64_t)i * cout * 4);
+    f32x4n Y[4];                                              // Y[b] = (y[0][b], y[1][b], y[2][b], y[3][b])
+    Y[0] = at6(S[0].x, S[1].x, S[2].x, S[3].x, S[4].x, S[5].x);
+    Y[1] = at6(S[0].y, S[1].y, S[2].y, S[3].y, S[4].y, S[5].y);
+    Y[2] = at6(S[0].z, S[1].z, S[2].z, S[3].z, S[4].z, S[5].z);
+    Y[3] = at6(S[0].w, S[1].w, S[2].w, S[3].w, S[4].w, S[5].w);
+    const float bias = a.bias ? a.bias[co] : 0.0f, slope = a.slope ? a.slope[co] : 0.0f;
+    const int ho = a.out.h, wo = a.out.w;
+    static_for<16>([&](auto E) {
+        constexpr int e = decltype(E)::value, dy = e >> 2, dx = e & 3;
+        const int oy = 4 * tyg + dy, ox = 4 * txg + dx;
+        if (oy < ho && ox < wo) {
+            const int64_t m = ((int64_t)n * ho + oy) * wo + ox;
+            const f32x4n yb = Y[dx];
+            float v = (dy == 0 ? yb.x : (dy == 1 ? yb.y : (dy == 2 ? yb.z : yb.w))) + bias;
+            if (a.res_mode == 1) v += a.res.p[m * a.res.ld + co];
+            v = apply_act(v, a.act, slope);
+            if (a.res_mode == 2) v += a.res.p[m * a.res.ld + co];
+            a.out.p[m * a.out.ld + co] = v;
+        }
+    });
+}
+
 }  // namespace
 
 namespace csmconv {
@@ -482,40 +555,71 @@ bool wino4_eligible(const ConvArgs &a) {
            (!a.res_mode || (((int64_t)a.out.h * a.out.w - 1) * a.res.ld + a.res.c) * 4 < (1ll << 31));
 }
 
+// scratch floats a row-split launch needs for `n` samples of an h x w map with cout channels (24 per tile and channel)
+int64_t wino4_scratch_floats(int n, int h, int w, int cout) { return (int64_t)n * ((h + 3) / 4) * ((w + 3) / 4) * 24 * cout; }
+
+template <int ABL, int RPB>
+static int launch_form(const ConvArgs &a, int tiles_x, int tiles_y, hipStream_t st) {
+    static KernelPrep prep;
+    const auto kern = &k_conv_wino4<ABL, RPB>;
+    (void)prep.ensure([&] { return prepare_kernel(kern, 128 * RPB, lds_all_of(RPB)); });
+    dim3 grid(a.m_tiles, (a.cout_g / 64) * (6 / RPB), 1);
+    kern<<<grid, 128 * RPB, lds_all_of(RPB), st>>>(a, tiles_x, tiles_y);
+    int rc = csm::check_launch("k_conv_wino4");
+    if (rc || RPB == 6) return rc;
+    const int tx_n = (a.out.w + 3) / 4, ty_n = (a.out.h + 3) / 4;
+    const int64_t total = (int64_t)a.out.n * ty_n * tx_n * a.cout_g;
+    k_wino4_rowpass<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a, tx_n, ty_n);
+    return csm::check_launch("k_wino4_rowpass");
+}
+
+// Which execution form (speed only: the forms give the same bits).  The fused form needs about one block tile per CU to be worth its
+// 12-wave blocks; with fewer (one sample of an 80 x 80 map is 15 x 4 block tiles) the K loop of ONE block tile is the launch's whole
+// duration, and the row-split forms cut it: 6 / RPB x the blocks of 2 RPB waves.  Times in us from the measured block times
+// (profiles/r06_wino4_forms.txt: fused 12 + 1.40 per 4-channel step; RPB = 3 (one block per CU) 8 + 1.03; RPB = 2: 7 + 0.75 alone on a
+// CU, 7 + 1.2 when two blocks share it; RPB = 1 never won and is not offered) + the row-pass kernel's round trip.
+// CSM_WINO4_FORM = 6 / 3 / 2 / 1 forces a form (tests, measurements).
+static int choose_form(const ConvArgs &a) {
+    static const int forced = [] { const char *e = getenv("CSM_WINO4_FORM"); return e ? atoi(e) : 0; }();
+    if (!a.partial) return 6;
+    if (forced == 6 || forced == 3 || forced == 2 || forced == 1) return forced;
+    const double ns = a.cin_g / 4, blocks = (double)a.m_tiles * (a.cout_g / 64);
+    const double t_row = 3.0 + 2.5 * 4.0 * (double)a.M * a.cout_g / 3.0e6;
+    auto ceil_div = [](double b, double s) { return (double)(int64_t)((b + s - 1) / s); };
+    const double t6 = ceil_div(blocks, 256) * (12.0 + 1.40 * ns);
+    const double t3 = ceil_div(2 * blocks, 256) * (8.0 + 1.03 * ns) + t_row;
+    const double b2 = 3 * blocks, full2 = (double)(int64_t)(b2 / 512), rem2 = b2 - 512 * full2;
+    const double t2 = full2 * (7.0 + 1.2 * ns) + (rem2 > 256 ? 7.0 + 1.2 * ns : (rem2 > 0 ? 7.0 + 0.75 * ns : 0.0)) + t_row;
+    return t6 <= t3 && t6 <= t2 ? 6 : (t2 <= t3 ? 2 : 3);
+}
+
 static int launch_conv_wino4_chunk(const ConvArgs &a0, hipStream_t st) {
     ConvArgs a = a0;
     const int tiles_x = (a.out.w + kOW - 1) / kOW, tiles_y = (a.out.h + kOH - 1) / kOH;
     a.m_tiles = tiles_x * tiles_y * a.out.n;
-    dim3 grid(a.m_tiles, a.cout_g / 64, 1);
 #ifdef CSM_WINO_DEV
     const char *ve = getenv("CSM_WINO4_VARIANT");
     const int variant = ve ? atoi(ve) : 0;
-    auto go = [&](auto kern) {
-        static KernelPrep prep;
-        (void)prep.ensure([&] { return prepare_kernel(kern, 768, kLdsAll); });
-        kern<<<grid, 768, kLdsAll, st>>>(a, tiles_x, tiles_y);
-        return csm::check_launch("k_conv_wino4");
-    };
     switch (variant) {
-        case 1: return go(&k_conv_wino4<1>);
-        case 2: return go(&k_conv_wino4<2>);
-        case 4: return go(&k_conv_wino4<4>);
-        case 8: return go(&k_conv_wino4<8>);
-        case 3: return go(&k_conv_wino4<3>);
-        case 11: return go(&k_conv_wino4<11>);
-        case 16: return go(&k_conv_wino4<16>);
-        case 32: return go(&k_conv_wino4<32>);
-        case 35: return go(&k_conv_wino4<35>);
-        case 51: return go(&k_conv_wino4<51>);
-        case 59: return go(&k_conv_wino4<59>);
-        case 64: return go(&k_conv_wino4<64>);
+        case 1: return launch_form<1, 6>(a, tiles_x, tiles_y, st);
+        case 2: return launch_form<2, 6>(a, tiles_x, tiles_y, st);
+        case 4: return launch_form<4, 6>(a, tiles_x, tiles_y, st);
+        case 8: return launch_form<8, 6>(a, tiles_x, tiles_y, st);
+        case 3: return launch_form<3, 6>(a, tiles_x, tiles_y, st);
+        case 16: return launch_form<16, 6>(a, tiles_x, tiles_y, st);
+        case 32: return launch_form<32, 6>(a, tiles_x, tiles_y, st);
+        case 35: return launch_form<35, 6>(a, tiles_x, tiles_y, st);
+        case 59: return launch_form<59, 6>(a, tiles_x, tiles_y, st);
+        case 64: return launch_form<64, 6>(a, tiles_x, tiles_y, st);
         default: break;
     }
 #endif
-    static KernelPrep prep;
-    (void)prep.ensure([&] { return prepare_kernel(&k_conv_wino4<0>, 768, kLdsAll); });
-    k_conv_wino4<0><<<grid, 768, kLdsAll, st>>>(a, tiles_x, tiles_y);
-    return csm::check_launch("k_conv_wino4");
+    switch (choose_form(a)) {
+        case 1: return launch_form<0, 1>(a, tiles_x, tiles_y, st);
+        case 2: return launch_form<0, 2>(a, tiles_x, tiles_y, st);
+        case 3: return launch_form<0, 3>(a, tiles_x, tiles_y, st);
+        default: return launch_form<0, 6>(a, tiles_x, tiles_y, st);
+    }
 }
 
 // 32-bit buffer descriptors: a launch covers as many SAMPLES as fit 2 GiB of input view; larger batches are split by sample (independent
@@ -534,6 +638,7 @@ int launch_conv_wino4(const ConvArgs &a0, hipStream_t st) {
         a.in.n = a.out.n = nn; a.in.p = a0.in.p + (int64_t)n0 * a0.in.h * a0.in.w * a0.in.ld;
         a.out.p = a0.out.p + (int64_t)n0 * a0.out.h * a0.out.w * a0.out.ld;
         if (a0.res_mode) { a.res.n = nn; a.res.p = a0.res.p + (int64_t)n0 * a0.res.h * a0.res.w * a0.res.ld; }
+        if (a0.partial) a.partial = a0.partial + wino4_scratch_floats(n0, a0.out.h, a0.out.w, a0.cout_g);
         a.M = nn * a.out.h * a.out.w;
         const int rc = launch_conv_wino4_chunk(a, st);
         if (rc) return rc;

@@ -189,7 +189,7 @@ class KenBurnsPipeline:
             raise _lib.CsmError("KenBurnsPipeline needs an MI355X: libcsm355 has no CPU path")
         self.device = torch.device('cuda:%d' % torch.cuda.current_device()) if device in (None, 'cuda') else torch.device(device)
         self.animeinsseg = None
-        self._leres, self._leres_weights, self._leres_ws = {}, None, None
+        self._leres, self._leres_weights, self._leres_ws = {}, {}, None
         self._refine_ws, self._refine_progs = None, {}
         self.max_instances = 100                 # AnimeInsSeg.infer default (animeinsseg/__init__.py:417)
         self.overlap_depth = True                # MI355X: LeReS runs on a second HIP stream next to the segmentation nets
@@ -455,8 +455,7 @@ class KenBurnsPipeline:
     def _leres_prog(self, h, w, n=1, slot=0):
         """slot: programs that may run concurrently on different streams need their own workspace (weights are shared)"""
         if (h, w, n, slot) not in self._leres:
-            cp = CompiledProgram(build_leres(self._leres_ws, n, h, w), self.device, weights=self._leres_weights)
-            self._leres_weights = cp.weights
+            cp = CompiledProgram(build_leres(self._leres_ws, n, h, w), self.device, shared=self._leres_weights)
             self._leres[(h, w, n, slot)] = cp
         return self._leres[(h, w, n, slot)]
 

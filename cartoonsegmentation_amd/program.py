@@ -150,13 +150,25 @@ def pack_wino_weights(w):
 CONV_FLAG_WINOGRAD4 = 8
 WINO4_ENABLE = os.environ.get('CSM_WINO4', '1') != '0'
 WINO4_MIN_PIXELS = int(os.environ.get('CSM_WINO4_MIN_PIXELS', '6400'))
+WINO4_SPLIT_BELOW = int(os.environ.get('CSM_WINO4_SPLIT_BELOW', '1024'))      # block tiles of a launch below which the scratch for the row-split forms is planned (speed only)
+
+
+WINO4_SMALL_MIN_PIXELS = int(os.environ.get('CSM_WINO4_SMALL_MIN_PIXELS', '500'))
+WINO4_SMALL_MAX_CIN = int(os.environ.get('CSM_WINO4_SMALL_MAX_CIN', '512'))
+WINO4_SMALL_MIN_CH = int(os.environ.get('CSM_WINO4_SMALL_MIN_CH', '128'))      # narrower layers on small maps gain nothing at any batch
 
 
 def wino4_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=None):
+    """the F(2x2) layer class (3x3 / stride 1 / pad 1 / dense, cin % 32 == 0, cout % 64 == 0, 32-bit descriptor ranges) on maps of at
+    least WINO4_MIN_PIXELS output pixels per sample -- and, round 6b, on SMALLER maps down to WINO4_SMALL_MIN_PIXELS (23 x 23) when
+    128 <= cin <= WINO4_SMALL_MAX_CIN and cout >= 128: at batch 8 those layers run 1.4-1.8 x the direct kernels, and the K loop of one block tile
+    (cin / 4 steps) stays short enough for the row-split forms at batch 1 (profiles/r06_wino4_forms.txt).  Per-sample: batch invariant."""
     ld = cin_g if ld is None else ld
+    px = ho * wo
     return (kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and groups == 1 and cin_g % 32 == 0 and cout % WINO_BN == 0
-            and ho * wo >= WINO4_MIN_PIXELS and ld % 4 == 0 and ((ho * wo - 1) * ld + cin_g) * 4 < 2 ** 31
-            and (cout // WINO_BN) * (cin_g // 4) * 36864 < 2 ** 31)
+            and (px >= WINO4_MIN_PIXELS or (px >= WINO4_SMALL_MIN_PIXELS and WINO4_SMALL_MIN_CH <= cin_g <= WINO4_SMALL_MAX_CIN
+                                            and cout >= WINO4_SMALL_MIN_CH))
+            and ld % 4 == 0 and ((px - 1) * ld + cin_g) * 4 < 2 ** 31 and (cout // WINO_BN) * (cin_g // 4) * 36864 < 2 ** 31)
 
 
 def wino4_transform(w):
@@ -291,8 +303,8 @@ class Program:
             out = self.buffer(x.n, ho, wo, cout)
         assert out.shape == (x.n, ho, wo, cout), (out.shape, (x.n, ho, wo, cout))
         stem = groups == 1 and cin_g == 4 and cout > 4        # k_conv_stem: (tap, channel)-packed K, csm_op.flags bit 1
-        wino = self.winograd and wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c)
-        wino4 = wino and self.winograd4 and wino4_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c)
+        wino4 = self.winograd and self.winograd4 and wino4_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c)
+        wino = wino4 or (self.winograd and wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c))
         if stem:
             packed, sg, cin_sg, cout_sg = pack_stem_weights(w), 1, 4, cout
         elif wino4:
@@ -314,6 +326,10 @@ class Program:
         ksplit, scr = (1 if stem or wino else self.choose_ksplit(ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups)), None
         if ksplit > 1:
             scr = self.buffer(x.n, ho, wo, ksplit * cout)
+        elif wino4 and x.n * ((ho + 15) // 16) * ((wo + 31) // 32) * (cout // WINO_BN) < WINO4_SPLIT_BELOW:
+            # fewer 32 x 16-pixel block tiles than would fill the chip: the library may run a ROW-SPLIT form of the same arithmetic
+            # (csrc/wino4.hip, speed only) and needs 24 floats of scratch per 4x4 tile and channel for it
+            scr = self.buffer(x.n, (ho + 3) // 4, (wo + 3) // 4, 24 * cout)
         return self._emit(OP_CONV, x, res, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, groups=sg, cin_g=cin_sg,
                           cout_g=cout_sg, act=ACT[act], res_mode=res_mode if res is not None else 0, w_off=w_h, b_off=b_h,
                           aux_off=a_h, ksplit=ksplit, scratch=-1 if scr is None else scr.id, scratch_view=scr,

@@ -13,11 +13,24 @@ class CompiledProgram:
     (no allocation, no host sync -> capturable in a hipGraph via torch.cuda.graph; the first run() tunes the conv tiles)."""
     _cache_loaded = False
 
-    def __init__(self, prog, device, weights=None):
+    def __init__(self, prog, device, weights=None, shared=None):
+        """`shared`: a dict owned by the caller in which programs of ONE net at different shapes / batch sizes share their packed weight
+        image on the device -- but only when the images are the same: the packing is part of the lowering (a layer's weights are
+        Winograd panels or direct tiles depending on its map size), so two shapes may pack the same checkpoint differently.  The key is
+        the packed image's own signature (length + per-op packing); a program with another packing gets its own copy.
+        (`weights`: an already uploaded image, trusted as is.)"""
         self.prog = prog
         self.ops, self.tensors, w = prog.serialise(oracle=False)
         self.device = torch.device(device)
-        self.weights = torch.from_numpy(w).to(self.device) if weights is None else weights
+        if weights is not None:
+            self.weights = weights
+        elif shared is not None:
+            sig = (int(w.size),) + tuple((o['kind'], o['flags'], o['w_off'], o['b_off'], o['aux_off']) for o in prog.ops)
+            if sig not in shared:
+                shared[sig] = torch.from_numpy(w).to(self.device)
+            self.weights = shared[sig]
+        else:
+            self.weights = torch.from_numpy(w).to(self.device)
         self.workspace = torch.empty(max(prog.workspace_floats, 64), dtype=torch.float32, device=self.device)
         self.n_ext = prog.n_ext
         self._ext = (ctypes.c_void_p * max(self.n_ext, 1))()

@@ -106,8 +106,8 @@ class AnimeInsSeg:
             blob = torch.load(ckpt, map_location='cpu', weights_only=False)
             self.cfg = config_from_ckpt_cfg(blob['meta']['cfg'])
             self._det_ws = StateDictWeights(blob['state_dict'])
-        self._det_programs, self._det_weights = {}, None
-        self._refine_programs, self._refine_weights, self._refine_ws = {}, None, None
+        self._det_programs, self._det_weights = {}, {}          # (weights: packed images on the device by packing signature)
+        self._refine_programs, self._refine_weights, self._refine_ws = {}, {}, None
         self.refine_method = None
         self.refine_batch = int(os.environ.get('CSM_REFINE_BATCH', '16'))   # instances per ISNet run when frames are batched
         self.det_batch = max(1, int(os.environ.get('CSM_DET_BATCH', '16')))  # frames per detector run (longer lists are chunked)
@@ -145,16 +145,14 @@ class AnimeInsSeg:
     def _detector(self, S, n=1):
         if (S, n) not in self._det_programs:
             rp, _ = build_rtmdet(self._det_ws, n, S, S, self.cfg)
-            cp = CompiledProgram(rp.prog, self.device, weights=self._det_weights)
-            self._det_weights = cp.weights
+            cp = CompiledProgram(rp.prog, self.device, shared=self._det_weights)     # (shared between shapes only where the packing is the same)
             self._det_programs[(S, n)] = (rp, cp)
         return self._det_programs[(S, n)]
 
     def _refiner(self, n, T):
         if (n, T) not in self._refine_programs:
             prog = build_isnet(self._refine_ws, n, T, T)
-            cp = CompiledProgram(prog, self.device, weights=self._refine_weights)
-            self._refine_weights = cp.weights
+            cp = CompiledProgram(prog, self.device, shared=self._refine_weights)
             self._refine_programs[(n, T)] = cp
         return self._refine_programs[(n, T)]
 

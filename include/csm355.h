@@ -287,7 +287,10 @@ typedef struct csm_op {
     int32_t ksplit;          /* CONV: K is cut into `ksplit` runs of (32-channel block, tap) chunks (block-major), run s = chunks
                                 [s*T/ksplit, (s+1)*T/ksplit); each run is its own fmaf chain (run 0 starts at the bias,
                                 the others at 0) and the runs are added in order ((p0+p1)+p2)...  1 = single chain */
-    int32_t scratch;         /* tensor id of the [n,h,w,ksplit*cout] partial-sum buffer when ksplit > 1, else -1 */
+    int32_t scratch;         /* tensor id of the [n,h,w,ksplit*cout] partial-sum buffer when ksplit > 1, else -1.  CONV with
+                                CSM_CONV_FLAG_WINOGRAD4: optional (-1 = none) contiguous tensor of >= n * ceil(h/4) * ceil(w/4) * 24 * cout
+                                floats; with it the library may run launches of few block tiles in a row-split execution form of
+                                the same arithmetic (speed only: same bits) */
     int32_t tile;            /* CONV: 0 = built-in tile rule; low 6 bits k > 0 = tile configuration k-1, bit 6 (64) = split-K runs
                                 walked serially by one block instead of ksplit blocks + reduce, bit 7 (128) = mixed-tile launch (the
                                 configuration's tiles cover whole rounds of the grid, 64 x 64 tiles the remaining rows).  Speed only:

@@ -204,3 +204,28 @@ def test_device_decode_matches_filter_then_topk_with_ties_and_classes():
             assert np.array_equal(kk[b, j].cpu().numpy(), kern[l][b].reshape(-1, G)[p])
             assert kp[b, j].cpu().numpy().tolist() == [float((p % hw[l][1]) * strides[l]), float((p // hw[l][1]) * strides[l]), float(strides[l]), float(strides[l])]
             assert float(ks[b, j]) == float(sc[r]) and np.array_equal(kb[b, j].cpu().numpy(), bx[r]) and int(kl[b, j]) == int(lb[r])
+
+
+def test_detector_programs_of_different_sizes_do_not_share_a_mismatched_weight_image():
+    """the packed weight image is part of the lowering (a layer's weights are Winograd panels or direct tiles depending on its map size):
+    det 640 and det 1024 lower stride-32 layers differently (20 x 20 direct, 32 x 32 Winograd F(4x4)), so the second program must not run
+    on the first one's image (round 6: a shared image made the det-1024 program read panels that were never packed -- memory fault).
+    Both sizes against the oracle pipeline."""
+    import os
+    os.environ["CSM_SYNTHETIC_WEIGHTS"] = "1"
+    from animeinsseg import AnimeInsSeg
+    from cartoonsegmentation_amd import synth
+    from cartoonsegmentation_amd.nets import build_rtmdet
+    from cartoonsegmentation_amd.weights import SynthWeights
+    from oracle import segment as oseg
+    img = synth.image_u8(200, 264, 17)
+    net = AnimeInsSeg('synthetic', default_det_size=640, refine_kwargs={'refine_method': 'none'})
+    for S in (640, 1024, 640):
+        inst = net.infer(img, pred_score_thr=0.3, max_instances=2, output_type='numpy', det_size=S)
+        rp, cfg = build_rtmdet(SynthWeights('rtmdet.'), 1, S, S)
+        cfg.max_per_img = 2
+        d = oseg.detect(img, rp, cfg, S, 0.3)
+        assert d['n'] == len(inst) and np.array_equal(d['bboxes'], inst.bboxes) and np.array_equal(d['scores'], inst.scores), S
+    packings = {id(cp.weights) for _, cp in net._det_programs.values()}
+    flags = {S: tuple(o['flags'] for o in rp_.prog.ops if o['kind'] == 1) for (S, _), (rp_, _) in net._det_programs.items()}
+    assert (len(packings) == 2) == (flags[640] != flags[1024])

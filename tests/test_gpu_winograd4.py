@@ -188,3 +188,20 @@ def test_winograd4_random_shapes_bit_exact(seed):
     res_mode = int(rng.integers(0, 3))
     yo, yd = _one_layer(rng, n, h, w, cin, cout, act, res_mode, bias=bool(rng.integers(0, 2)))
     assert np.isfinite(yd).all() and np.array_equal(yd, yo), (n, h, w, cin, cout, act, res_mode)
+
+
+@pytest.mark.parametrize("form", ["1", "2", "3", "6"])
+def test_every_execution_form_gives_the_oracles_bits(form):
+    """the launcher's choice between the fused form (a block owns all 36 frequencies and finishes its outputs) and the row-split forms
+    (6 / RPB x the blocks of 2 RPB waves + k_wino4_rowpass, for launches with fewer block tiles than CUs) is speed only: each form,
+    forced through CSM_WINO4_FORM (read once per process, hence a subprocess), passes the single-layer, slice, chunking and
+    random-shape tests above bit for bit"""
+    import subprocess
+    import sys
+    e = dict(os.environ, CSM_WINO4_FORM=form)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "winograd4_conv_bit_exact or channel_slices or random_shapes or descriptor_range"], env=e,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -117,8 +117,11 @@ def test_winograd4_rule_is_per_sample_and_switchable():
     try:
         big = int(np.ceil(np.sqrt(max(P.WINO4_MIN_PIXELS, P.WINO_MIN_PIXELS))))
         assert flags(1, big, big, 64, 64) == (P.CONV_FLAG_WINOGRAD4, 1) and flags(8, big, big, 64, 64) == (P.CONV_FLAG_WINOGRAD4, 1)
-        small = max(2, int(np.sqrt(P.WINO_MIN_PIXELS)) // 2 - 1)
-        assert flags(1, small, small, 64, 64)[0] == 0
+        # smaller maps (round 6b): F(4x4) down to 23 x 23 when cin <= 512; below that, or with a long K loop, the direct chain
+        assert flags(1, 40, 40, 256, 256) == (P.CONV_FLAG_WINOGRAD4, 1) and flags(8, 40, 40, 256, 256) == (P.CONV_FLAG_WINOGRAD4, 1)
+        assert flags(1, 23, 23, 512, 512)[0] == P.CONV_FLAG_WINOGRAD4
+        assert flags(1, 40, 40, 1024, 256)[0] == 0 and flags(1, 22, 22, 256, 256)[0] == 0 and flags(1, 12, 12, 512, 512)[0] == 0
+        assert flags(1, 45, 45, 64, 64)[0] == 0 and flags(1, 45, 45, 128, 64)[0] == 0            # narrow layers on small maps: direct
         assert flags(1, big, big, 64, 32)[0] == 0 and flags(1, big, big, 48, 64)[0] == 0
         P.Program.winograd4 = False
         assert flags(1, big, big, 64, 64) == (P.CONV_FLAG_WINOGRAD, 1)

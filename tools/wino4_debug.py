@@ -117,6 +117,11 @@ if __name__ == '__main__':
         ok &= check(1, 45, 45, 96, 64, act='relu', res_mode=1)
         ok &= check(3, 23, 70, 256, 256)
         print("ALL OK" if ok else "SOME FAILED", flush=True)
+    if 'forms' in what:           # one process per form: CSM_WINO4_FORM=6|3|2|1 python tools/wino4_debug.py forms
+        for shp in [(1, 80, 80, 256, 256), (1, 80, 80, 128, 128), (1, 160, 160, 256, 256), (2, 360, 360, 64, 64), (2, 90, 90, 128, 256), (2, 180, 180, 64, 128),
+                    (1, 40, 40, 256, 256), (2, 45, 45, 256, 512), (2, 23, 23, 512, 512), (8, 40, 40, 256, 256), (16, 23, 23, 512, 512), (16, 45, 45, 256, 512),
+                    (8, 20, 20, 512, 512), (16, 45, 45, 1024, 256), (8, 80, 80, 256, 256), (8, 160, 160, 256, 256)]:
+            time_layer(*shp, modes=('direct', 'f2', 'f4'))
     if 'bench' in what:
         for shp in [(8, 160, 160, 256, 256), (8, 320, 320, 256, 128), (16, 360, 360, 64, 64), (16, 360, 360, 128, 64), (16, 360, 360, 32, 64),
                     (16, 180, 180, 64, 128), (16, 180, 180, 256, 64), (8, 80, 80, 256, 256), (16, 90, 90, 128, 256), (16, 90, 90, 512, 128),
