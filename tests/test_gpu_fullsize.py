@@ -156,6 +156,7 @@ def test_conv_splitk_modes_and_batches_agree_on_single_layers():
         outs = {}
         for n in (1, 3):
             p = Program("sk")
+            p.winograd = False          # this test is about the DIRECT kernels' split-K executions (a 40 x 40 256 -> 256 layer lowers to Winograd F(4x4) since round 6)
             x_ext = p.ext_nchw(n, cin, h, w); y_ext = p.ext_nchw(n, cout, h, w)
             y = p.conv(p.to_nhwc(x_ext), rnd('skw%d%d' % (cin, k), (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k)), rnd('skb', (cout,), 0.1),
                        pad=k // 2, act='silu')
