@@ -34,6 +34,9 @@
 //   * epilogue: column pass of A^T M A in registers, two accumulator elements per packed operation; the six waves of a channel half
 //     exchange the row-pass inputs through LDS in two rounds of four element pairs; unit of the row pass = (tile pair, output column);
 //     stores and residual loads go through range-checked buffer descriptors (ragged block tiles need no divergent control flow).
+//   * execution forms: the above is the FUSED form (RPB = 6).  Launches with fewer block tiles than CUs (single frames, 23^2-45^2 maps)
+//     run ROW-SPLIT (RPB = 3 / 2 frequency rows per block, 2 RPB waves, 6 / RPB x the blocks): same main loop, the epilogue leaves the
+//     column-passed s[i][b] in a scratch tensor and k_wino4_rowpass finishes -- the same expressions on the same values, same bits.
 // Measured (profiles/r06_*): 1.3-1.5x k_conv_wino8 on the 128/256-channel layers at batch 8, 1.1-1.2x on the 32/64-channel ones; where
 // the time goes (ablations): the matrix pipe alone 450 us of 700-770 at 160^2 256->256; fp32 MFMA shares its issue with the
 // transform's VALU and the DMA issue (they add up instead of overlapping), the 12-wave barrier costs ~15 %, and the epilogue's
