@@ -18,7 +18,7 @@
 //     16-byte granules = the channels of k-half 0 / 1) at  psi = ((col >> 1) & 1) 324 + 18 row + 9 (col & 1) + (col >> 2), granule
 //     slot ^ ((row >> 2) & 1):  the stride-4 windows of a lane group's 8 x 4 tiles are 8 consecutive entries per tile row, and a
 //     ds_read_b64 of one channel pair touches every bank at most twice (the minimum for 8-byte reads of 16-byte granules); two
-//     consecutive DMA lanes fetch the 32 contiguous bytes of a pixel.  The loader's two global offsets per lane live in LDS (no
+//     consecutive DMA lanes fetch the 32 contiguous bytes of a pixel.  The fused form's two global offsets per lane live in LDS (no
 //     register is free for them in the main loop).
 //   * transform B^T d B: ONCE per block, through LDS, by the waves of channel half s & 1 during step s for step s + 2 (each wave
 //     transforms every other step).  Unit = (tile, frequency row = the wave's own row, k-half): row pass over the six window columns
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
 
     // ---- raw patch loader: wave w owns pieces w, w + NW, ... of a stage.  Granule g = 2 psi + s' sits at LDS position g; it holds channels
     // [4 slot, 4 slot + 4) of the stage's eight, slot = s' ^ ((row >> 2) & 1) ----
-    // (a lane's global offsets live in LDS behind the U slots: no register is free for them in the main loop, and a scratch reload
-    // would put a vmcnt(0) in front of every raw fetch)
+    // (fused form: a lane's global offsets live in LDS behind the U slots -- no register is free for them in the main loop, and a scratch
+    // reload would put a vmcnt(0) in front of every raw fetch; the row-split forms keep them in registers)
     const unsigned offL = lds0 + kLds + (unsigned)tid * (unsigned)(PPE * 4);
     auto raw_lds = [&](int stage, int q) __attribute__((always_inline)) {
         int pp = wave + NW * q;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
     wait_barrier<0>();                                        // A(0) read by everybody: step 0 may overwrite V[0]
 
     // ---- main loop: step s = 4 input channels = 12 MFMA slots per wave.  Beside the MFMAs: slots 0-2 send B(s + 2) into U slot s & 1
-    // (whose contents, B(s), are in registers since step s - 1); slots 3, 4 of the EVEN steps send this wave's two pieces of raw stage
+    // (whose contents, B(s), are in registers since step s - 1); slots 1 .. PPW of the EVEN steps send this wave's pieces of raw stage
     // s / 2 + 2 (its buffer was last read in step s - 1 and is first read in step s + 2; the pieces are waited for in step s + 1 and
     // published by that step's barrier); the waves of channel half s & 1 transform the window of step s + 2 into V[s & 1] (whose
     // previous image, step s, is in everybody's registers since the barrier of step s - 1); from slot 6 on the operands of step s + 1
