@@ -9,17 +9,18 @@
 //
 // Mapping (CDNA4-first; the F(2x2) kernel's in-register transform does not carry over -- 36 accumulators per (32 tiles x 32 channels)
 // are 576 registers, and a 6x6 window transformed per wave would be computed twice and read from LDS 2.25x):
-//   * block = 12 waves (three per SIMD, <= 168 registers), ONE block per CU: 8 x 4 Winograd tiles (32 x 16 output pixels) x 64 output
-//     channels.  Wave (i, nh) owns frequency ROW i (six 32x32 accumulators = 96 registers) of the 32 tiles x output channels
-//     [32 nh, 32 nh + 32).
+//   * block = 12 waves (three per SIMD, <= 168 registers), ONE block per CU: 32 Winograd tiles = TWO SQUARES of 4 x 4 tiles (16 x 16 output
+//     pixels each, consecutive in the launch's list of squares -- they need not be neighbours: a 40 x 40 map is 4.5 blocks per sample
+//     where 32 x 16-pixel rectangles need 6) x 64 output channels.  Wave (i, nh) owns frequency ROW i (six 32x32 accumulators = 96
+//     registers) of the 32 tiles x output channels [32 nh, 32 nh + 32).
 //   * step = 4 input channels = two MFMAs per frequency = 12 MFMA slots per wave; ONE barrier per step, and it waits for LDS traffic
 //     only: every fetch is waited for (vmcnt) a step after it was sent, by the wave that sent it.
-//   * raw input patch ((16 + 2) x (32 + 2) pixels): LDS-DMA, 8 channels (= 2 steps) per stage, two stages.  A pixel entry is 32 B (two
-//     16-byte granules = the channels of k-half 0 / 1) at  psi = ((col >> 1) & 1) 324 + 18 row + 9 (col & 1) + (col >> 2), granule
-//     slot ^ ((row >> 2) & 1):  the stride-4 windows of a lane group's 8 x 4 tiles are 8 consecutive entries per tile row, and a
-//     ds_read_b64 of one channel pair touches every bank at most twice (the minimum for 8-byte reads of 16-byte granules); two
-//     consecutive DMA lanes fetch the 32 contiguous bytes of a pixel.  The fused form's two global offsets per lane live in LDS (no
-//     register is free for them in the main loop).
+//   * raw input patches (two of (16 + 2)^2 pixels): LDS-DMA, 8 channels (= 2 steps) per stage, two stages.  A pixel entry is 32 B (two
+//     16-byte granules = the channels of k-half 0 / 1) at  psi = 342 square + 19 row + colpos(col)  (columns de-interleaved by col mod 4),
+//     granule slot ^ ((row >> 3) & 1):  the stride-4 windows of a tile row are consecutive entries, the odd row pitch alternates the tile
+//     rows between the two halves of a 256-byte bank period, and a ds_read_b64 of one channel pair touches every bank at most twice
+//     (the minimum for 8-byte reads of 16-byte granules); two consecutive DMA lanes fetch the 32 contiguous bytes of a pixel.  The fused
+//     form's two global offsets per lane live in LDS (no register is free for them in the main loop).
 //   * transform B^T d B: ONCE per block, through LDS, by the waves of channel half s & 1 during step s for step s + 2 (each wave
 //     transforms every other step).  Unit = (tile, frequency row = the wave's own row, k-half): row pass over the six window columns
 //     (four ds_read_b64 and three v_pk_fma_f32 per column -- the two channels of a lane are the two halves of a packed operation;
@@ -122,11 +123,15 @@ __device__ __forceinline__ f32x4n at6(float m0, float m1, float m2, float m3, fl
     return s;
 }
 
-constexpr int kTX = 8, kTY = 4;                              // Winograd tiles of a block
-constexpr int kOW = 4 * kTX, kOH = 4 * kTY;                  // 32 x 16 output pixels
-constexpr int kPW = kOW + 2, kPH = kOH + 2;                  // 34 x 18 patch pixels
-constexpr int kPsi = 2 * 18 * 18;                            // 648 pixel entries (32 B = 8 channels each) of a raw stage
-constexpr int kRawPieces = (kPsi * 2 + 63) / 64;             // 21 DMA pieces
+// A block's 32 Winograd tiles are TWO SQUARES of 4 x 4 tiles (16 x 16 output pixels each), consecutive in the launch's list of squares
+// (sample, square row, square column): the squares of a block need not be neighbours -- a 40 x 40 map is 9 squares = 4.5 blocks per sample
+// where 32 x 16-pixel rectangles need 6, an 80 x 80 map 12.5 instead of 15.
+constexpr int kSQ = 16;                                      // output pixels of a square's side
+constexpr int kPS = kSQ + 2;                                 // 18 x 18 patch pixels per square
+constexpr int kPitch = 19;                                   // pixel entries per patch row (18 + 1: an ODD pitch spreads the tile rows over the banks)
+constexpr int kSqEnt = kPS * kPitch;                         // 342 entries per square
+constexpr int kPsi = 2 * kSqEnt;                             // 684 pixel entries (32 B = 8 channels each) of a raw stage
+constexpr int kRawPieces = (kPsi * 2 + 63) / 64;             // 22 DMA pieces
 constexpr unsigned kRawB = kRawPieces * 1024u;               // 21 504 B per stage
 constexpr unsigned kV0 = 2u * kRawB;                         // 43 008
 constexpr unsigned kUW = 3072u;                              // a wave's U slot (three pieces); two slots per wave
@@ -141,10 +146,13 @@ constexpr int ppe_of(int rpb) { return (ppw_of(rpb) + 1) & ~1; }                
 // (the fused form has no register left for the loader's offsets and parks them in LDS; the row-split forms keep them in registers --
 // two blocks of RPB = 2 then fit a CU)
 constexpr unsigned lds_all_of(int rpb) { return lds_of(rpb) + (rpb == 6 ? (unsigned)(2 * rpb) * 64u * (unsigned)ppe_of(rpb) * 4u : 0u); }
-static_assert(kPH == 18 && kPW == 34 && lds_all_of(6) <= 160u * 1024u, "tile shape");
+static_assert(kPS == 18 && lds_all_of(6) <= 160u * 1024u, "tile shape");
 
-// pixel entry of patch position (row r, column c) relative to the entry of (4 ty, 4 tx): compile-time part of psi
-__host__ __device__ constexpr int psi_k(int r, int c) { return ((c >> 1) & 1) * 324 + r * 18 + (c & 1) * 9 + (c >> 2); }
+// Pixel entry of patch position (R, C) of a square: psi = R * 19 + colpos(C), colpos = the columns de-interleaved by C mod 4 (0..4 | 5..9 |
+// 10..13 | 14..17), so that the stride-4 windows of a tile row are consecutive entries.  psi_k(r, c): the compile-time part for window
+// position (r, c) of tile (ty, tx): psi = 19 (4 ty + r) + colbase(c & 3) + tx + (c >> 2).
+__host__ __device__ constexpr int colbase(int cr) { return cr == 0 ? 0 : (cr == 1 ? 5 : (cr == 2 ? 10 : 14)); }
+__host__ __device__ constexpr int psi_k(int r, int c) { return r * kPitch + colbase(c & 3) + (c >> 2); }
 
 // ABL (development ablations, timing only -- results invalid): 1 = no DMA, 2 = no transform, 4 = no MFMA, 8 = no epilogue stores,
 // 16 = no barrier in the main loop, 32 = no operand reads (A / B fragments) in the main loop, 64 = every block stores into the first
@@ -154,7 +162,7 @@ __host__ __device__ constexpr int psi_k(int r, int c) { return ((c >> 1) & 1) * 
 // a block owns RPB rows (2 RPB waves, several blocks per CU), does the column pass of A^T M A on them and writes s[i][b] (four values per
 // row, tile and channel) to a scratch buffer; k_wino4_rowpass finishes.  Same expressions on the same values: the forms give the same bits.
 template <int ABL = 0, int RPB = 6>
-__global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void k_conv_wino4(ConvArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void k_conv_wino4(ConvArgs a, int sx_n, int sy_n) {
     constexpr int NW = 2 * RPB, PPW = ppw_of(RPB), PPE = ppe_of(RPB);
     constexpr unsigned kVB = vb_of(RPB), kU0 = u0_of(RPB), kLds = lds_of(RPB);
     extern __shared__ __attribute__((aligned(64))) float lds[];   // [raw 0][raw 1][V 0][V 1][U: NW waves x 2 slots][offsets]
@@ -166,10 +174,19 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
     const int rg = RPB == 6 ? 0 : ntile % (6 / RPB);          // row group of a row-split block
     if constexpr (RPB != 6) ntile /= (6 / RPB);
     const int wi = rg * RPB + rl;                             // frequency row
-    const int btx = mt % tiles_x, bty = (mt / tiles_x) % tiles_y, n = mt / (tiles_x * tiles_y);
     const int ho = a.out.h, wo = a.out.w;
     const int nsteps = a.cin_g >> 2, nstages = nsteps >> 1;   // a raw stage = 8 channels = 2 steps
-    const int oy0 = bty * kOH, ox0 = btx * kOW;
+    // the block's two squares: sample, origin, validity (a launch with an odd number of squares leaves the last block's second one empty)
+    int sqn[2], sqy[2], sqx[2];
+    bool sqv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sq = 2 * mt + q, per = sx_n * sy_n;
+        sqv[q] = sq < a.out.n * per;
+        sqn[q] = sq / per;
+        const int rem = sq - sqn[q] * per;
+        sqy[q] = (rem / sx_n) * kSQ; sqx[q] = (rem % sx_n) * kSQ;
+    }
 
     i32x4 ra, rb;
     {
@@ -213,12 +230,12 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
             if (pp > kRawPieces - 1) pp = kRawPieces - 1;
             const int g = 64 * pp + lane;
             const int psi = g >> 1, sl = g & 1;
-            const int crh = psi / 324, rem = psi - crh * 324, R = rem / 18, r2 = rem - R * 18, c1 = r2 / 9, cq = r2 - c1 * 9;
-            const int C = 4 * cq + 2 * crh + c1;
-            const int slot = sl ^ ((R >> 2) & 1);
-            const int iy = oy0 - 1 + R, ix = ox0 - 1 + C;
-            const bool v = psi < kPsi && C < kPW && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
-            offP[q] = v ? (unsigned)(((n * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
+            const int sq = psi >= kSqEnt ? 1 : 0, rem = psi - sq * kSqEnt, R = rem / kPitch, cp = rem - R * kPitch;
+            const int cr = cp < 5 ? 0 : (cp < 10 ? 1 : (cp < 14 ? 2 : 3)), C = 4 * (cp - colbase(cr)) + cr;
+            const int slot = sl ^ ((R >> 3) & 1);
+            const int iy = (sq ? sqy[1] : sqy[0]) - 1 + R, ix = (sq ? sqx[1] : sqx[0]) - 1 + C;
+            const bool v = psi < kPsi && cp < kPS && (sq ? sqv[1] : sqv[0]) && iy >= 0 && iy < a.in.h && ix >= 0 && ix < a.in.w;
+            offP[q] = v ? (unsigned)((((sq ? sqn[1] : sqn[0]) * a.in.h + iy) * a.in.w + ix) * a.in.ld + slot * 4) * 4u : kOob;
         }
         if constexpr (RPB == 6) {
 #pragma unroll
@@ -233,9 +250,10 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
     }
 
     // ---- fragment / unit addresses ----
-    const int tx = li & 7, ty = li >> 3;
-    const unsigned ubase = lds0 + (unsigned)(ty * 72 + tx) * 32u + (unsigned)nh * 8u;      // (this wave transforms steps sn = nh mod 2: half nh)
-    const unsigned bxA = ubase + (unsigned)((lh ^ (ty & 1)) << 4), bxB = ubase + (unsigned)((lh ^ ((ty + 1) & 1)) << 4);
+    const int tx = li & 3, ty = (li >> 2) & 3, tq = li >> 4;                               // tile li = square tq, tile row ty, tile column tx
+    const unsigned ubase = lds0 + (unsigned)(tq * kSqEnt + ty * 4 * kPitch + tx) * 32u + (unsigned)nh * 8u;      // (this wave transforms steps sn = nh mod 2: half nh)
+    // granule slot ^ ((R >> 3) & 1) with R = 4 ty + r: window rows r < 4 see (ty >> 1) & 1, rows 4, 5 see ((ty + 1) >> 1) & 1
+    const unsigned bxA = ubase + (unsigned)((lh ^ ((ty >> 1) & 1)) << 4), bxB = ubase + (unsigned)((lh ^ (((ty + 1) >> 1) & 1)) << 4);
     const unsigned vlane = lds0 + kV0 + (unsigned)lh * 256u + (unsigned)li * 8u + (unsigned)(rl * 6) * 512u;     // + parity kVB + j 512
     const unsigned vdst = vlane + (unsigned)nh * kVB;
     // transform unit of this lane: frequency ROW wi of tile li, k-half lh, two channels.  ONE code path for all six rows:
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
         const int rP = rowB ? (wi == 0 ? 0 : 1) : 1, rQ = rowB ? rP : 3, rR = rowB ? rP + 2 : 2, rS = rR + 2;
         const int rr[4] = {rP, rQ, rR, rS};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rowb[k] = ((rr[k] >> 2) ? bxB : bxA) + (unsigned)(rr[k] * 18 * 32);
+        for (int k = 0; k < 4; ++k) rowb[k] = ((rr[k] >> 2) ? bxB : bxA) + (unsigned)(rr[k] * kPitch * 32);
     }
 
     auto sgf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, v))); };
@@ -410,22 +428,19 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
         static_for<16>([&](auto RR) {
             constexpr int r = decltype(RR)::value;
             const f32x4n sv = at6(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r]);
-            const int txg = btx * kTX + (r & 3) + 4 * le_h, tyg = bty * kTY + (r >> 2);
-            if (txg < tx_n && tyg < ty_n)
-                *reinterpret_cast<f32x4n *>(sp + (((int64_t)n * ty_n + tyg) * tx_n + txg) * (int64_t)(24 * a.cout_g)) = sv;
+            constexpr int q = r >> 3;                          // element r: square r >> 3, tile row 2 ((r >> 2) & 1) + lh, tile column r & 3
+            const int txg = (sqx[q] >> 2) + (r & 3), tyg = (sqy[q] >> 2) + 2 * ((r >> 2) & 1) + le_h;
+            if (sqv[q] && txg < tx_n && tyg < ty_n)
+                *reinterpret_cast<f32x4n *>(sp + (((int64_t)sqn[q] * ty_n + tyg) * tx_n + txg) * (int64_t)(24 * a.cout_g)) = sv;
         });
         return;
     }
     const int ldo = a.out.ld, ldr = a.res.ld;
     const unsigned xw = lds0 + (unsigned)wave * 8192u + (unsigned)lane_e * 8u;
     const unsigned xr = lds0 + (unsigned)(6 * nh) * 8192u + (unsigned)lane_e * 8u;
-    // Stores and residual loads go through range-checked buffer descriptors of THIS sample's output / residual view: a pixel outside the
-    // map gets the offset 2^31 and is dropped (loads return 0) by the hardware -- no divergent control flow on ragged block tiles
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out.p + (int64_t)n * ho * wo * ldo, 0,
-                                                                         (int)((((int64_t)ho * wo - 1) * ldo + a.out.c) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(a.res_mode ? a.res.p + (int64_t)n * ho * wo * ldr : a.out.p, 0,
-                                                                          a.res_mode ? (int)((((int64_t)ho * wo - 1) * ldr + a.res.c) * 4) : 0, 0x00020000);
-    const bool full = oy0 + kOH <= ho && ox0 + kOW <= wo;     // block-uniform: interior block tiles skip the per-pixel range tests
+    // Stores and residual loads go through range-checked buffer descriptors of the SAMPLE's output / residual view (round h of the
+    // exchange = square h of the block): a pixel outside the map gets the offset 2^31 and is dropped (loads return 0) by the hardware --
+    // no divergent control flow on ragged squares
     const f32x2n k8 = {sgf(8.0f), 0.0f};
     // the contract's output transform O6 on PAIRS (v_pk_*: the same IEEE operations per component): components = two accumulator
     // elements (column pass) / two tiles (row pass)
@@ -446,8 +461,14 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
         f32x2n S[6], Y[4];
 #pragma unroll
         for (int i = 0; i < 6; ++i) S[i] = lds_read2(xr + (unsigned)i * 8192u + (unsigned)u * 512u);
-        const int r0 = 8 * h + 2 * pr;                         // elements r0, r0 + 1: tiles (tx, ty) = ((r0 & 3) + 4 lh + e, r0 >> 2) of the block's 8 x 4
-        const int oyb = oy0 + 4 * (r0 >> 2), oxb = ox0 + 4 * ((r0 & 3) + 4 * le_h) + b;
+        // elements r0 = 8 h + 2 pr and r0 + 1: square h, tile row 2 ((r0 >> 2) & 1) + lh, tile columns (r0 & 3) + e
+        const int r0 = 8 * h + 2 * pr, sn = h ? sqn[1] : sqn[0], sy = h ? sqy[1] : sqy[0], sx = h ? sqx[1] : sqx[0];
+        const bool sv = h ? sqv[1] : sqv[0];
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out.p + (int64_t)sn * ho * wo * ldo, 0,
+                                                                             sv ? (int)((((int64_t)ho * wo - 1) * ldo + a.out.c) * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(has_res ? a.res.p + (int64_t)sn * ho * wo * ldr : a.out.p, 0,
+                                                                              (has_res && sv) ? (int)((((int64_t)ho * wo - 1) * ldr + a.res.c) * 4) : 0, 0x00020000);
+        const int oyb = sy + 4 * (2 * ((r0 >> 2) & 1) + le_h), oxb = sx + 4 * (r0 & 3) + b;
         const unsigned pix = (unsigned)(oyb * wo + oxb);
         unsigned vb = (pix * (unsigned)ldo + (unsigned)co) * 4u;
         const unsigned vbr = (pix * (unsigned)ldr + (unsigned)co) * 4u;
@@ -456,7 +477,7 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
         static_for<8>([&](auto E) {
             constexpr int e = decltype(E)::value & 1, aa = decltype(E)::value >> 1;
             float v = (e ? Y[aa].y : Y[aa].x) + bias;
-            const bool ok = is_full || (oyb + aa < ho && oxb + 4 * e < wo);
+            const bool ok = is_full || (oyb + aa < ho && oxb + 4 * e < wo);      // (an empty square's descriptor has no records: everything is dropped)
             const int so = (ABL & 64) ? 0 : (aa * wo + 4 * e) * ldo * 4;
             if constexpr (has_res) {
                 const float rv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr_, ok ? (int)vbr : (int)kOob, (aa * wo + 4 * e) * ldr * 4, 0));
@@ -499,6 +520,7 @@ __global__ __launch_bounds__(128 * RPB, RPB == 1 ? 1 : (RPB == 6 ? 3 : 2)) void 
         }
         wait_barrier<0>();
         // row pass (over i) + bias / residual / activation: this wave finishes units wi, wi + 6, wi + 12 (< 16) of the round
+        const bool full = (h ? sqy[1] : sqy[0]) + kSQ <= ho && (h ? sqx[1] : sqx[0]) + kSQ <= wo;     // an interior square skips the per-pixel range tests
         for (int u = wi; u < 16; u += 6) {
             if (a.res_mode) { if (full) finish_act(std::true_type{}, std::true_type{}, h, u); else finish_act(std::false_type{}, std::true_type{}, h, u); }
             else if (full) finish_act(std::true_type{}, std::false_type{}, h, u);
@@ -562,12 +584,12 @@ bool wino4_eligible(const ConvArgs &a) {
 int64_t wino4_scratch_floats(int n, int h, int w, int cout) { return (int64_t)n * ((h + 3) / 4) * ((w + 3) / 4) * 24 * cout; }
 
 template <int ABL, int RPB>
-static int launch_form(const ConvArgs &a, int tiles_x, int tiles_y, hipStream_t st) {
+static int launch_form(const ConvArgs &a, int sx_n, int sy_n, hipStream_t st) {
     static KernelPrep prep;
     const auto kern = &k_conv_wino4<ABL, RPB>;
     (void)prep.ensure([&] { return prepare_kernel(kern, 128 * RPB, lds_all_of(RPB)); });
     dim3 grid(a.m_tiles, (a.cout_g / 64) * (6 / RPB), 1);
-    kern<<<grid, 128 * RPB, lds_all_of(RPB), st>>>(a, tiles_x, tiles_y);
+    kern<<<grid, 128 * RPB, lds_all_of(RPB), st>>>(a, sx_n, sy_n);
     int rc = csm::check_launch("k_conv_wino4");
     if (rc || RPB == 6) return rc;
     const int tx_n = (a.out.w + 3) / 4, ty_n = (a.out.h + 3) / 4;
@@ -598,8 +620,8 @@ static int choose_form(const ConvArgs &a) {
 
 static int launch_conv_wino4_chunk(const ConvArgs &a0, hipStream_t st) {
     ConvArgs a = a0;
-    const int tiles_x = (a.out.w + kOW - 1) / kOW, tiles_y = (a.out.h + kOH - 1) / kOH;
-    a.m_tiles = tiles_x * tiles_y * a.out.n;
+    const int tiles_x = (a.out.w + kSQ - 1) / kSQ, tiles_y = (a.out.h + kSQ - 1) / kSQ;      // squares of 16 x 16 output pixels per sample
+    a.m_tiles = (tiles_x * tiles_y * a.out.n + 1) / 2;                                     // two squares per block
 #ifdef CSM_WINO_DEV
     const char *ve = getenv("CSM_WINO4_VARIANT");
     const int variant = ve ? atoi(ve) : 0;

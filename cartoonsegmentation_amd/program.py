@@ -326,8 +326,8 @@ class Program:
         ksplit, scr = (1 if stem or wino else self.choose_ksplit(ho * wo, cout, kh * kw * ((cin_sg + 31) // 32), groups)), None
         if ksplit > 1:
             scr = self.buffer(x.n, ho, wo, ksplit * cout)
-        elif wino4 and x.n * ((ho + 15) // 16) * ((wo + 31) // 32) * (cout // WINO_BN) < WINO4_SPLIT_BELOW:
-            # fewer 32 x 16-pixel block tiles than would fill the chip: the library may run a ROW-SPLIT form of the same arithmetic
+        elif wino4 and (x.n * ((ho + 15) // 16) * ((wo + 15) // 16) + 1) // 2 * (cout // WINO_BN) < WINO4_SPLIT_BELOW:
+            # fewer block tiles (two 16 x 16-pixel squares x 64 channels each) than would fill the chip: the library may run a ROW-SPLIT form of the same arithmetic
             # (csrc/wino4.hip, speed only) and needs 24 floats of scratch per 4x4 tile and channel for it
             scr = self.buffer(x.n, (ho + 3) // 4, (wo + 3) // 4, 24 * cout)
         return self._emit(OP_CONV, x, res, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, groups=sg, cin_g=cin_sg,
