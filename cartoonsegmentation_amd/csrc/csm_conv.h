@@ -188,5 +188,9 @@ int launch_conv_wino(const ConvArgs &a, hipStream_t st);
 bool wino4_eligible(const ConvArgs &a);
 int64_t wino4_scratch_floats(int n, int h, int w, int cout);      // scratch of the row-split forms: 24 floats per 4x4 tile and channel
 int launch_conv_wino4(const ConvArgs &a, hipStream_t st);
+// narrow grouped 3x3 convolutions on the vector pipe (grouped.hip): k_conv_grouped for an op that carries CSM_CONV_FLAG_GROUPED
+// (direct arithmetic, own weight image; csm_op.groups / cin_g / cout_g are the REAL groups there)
+bool grouped_eligible(const ConvArgs &a);
+int launch_conv_grouped(const ConvArgs &a, hipStream_t st);
 
 }  // namespace csmconv

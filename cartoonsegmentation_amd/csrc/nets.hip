@@ -2551,6 +2551,12 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                     if (rc) return rc;
                     break;
                 }
+                if (op.flags & CSM_CONV_FLAG_GROUPED) {       // narrow groups on the vector pipe: the direct chain, its own weight image (grouped.hip)
+                    if (!grouped_eligible(a)) { csm::set_error("op %d: grouped-conv flag on an ineligible convolution (3x3 / stride 1 / pad 1 / cin_g == cout_g in {8, 16, 32} / channels %% 32 / ksplit 1)", i); return CSM_ERR_ARG; }
+                    rc = launch_conv_grouped(a, st);
+                    if (rc) return rc;
+                    break;
+                }
                 if (op.flags & 2) {      // stem: (tap, channel)-packed K (weights packed by the host for exactly this kernel)
                     if (op.groups != 1 || op.cin_g != 4 || a.ksplit != 1) { csm::set_error("op %d: stem flag needs groups 1, cin 4, ksplit 1", i); return CSM_ERR_ARG; }
                     dim3 grid((a.M + 63) / 64, (op.cout_g + 63) / 64, 1);
@@ -2756,7 +2762,7 @@ extern "C" int csm_conv_autotune(csm_op *ops, int n_ops, const csm_tensor_desc *
     int tuned = 0, rc = CSM_OK;
     for (int i = 0; i < n_ops && rc == CSM_OK; ++i) {
         csm_op &op = ops[i];
-        if (op.kind != CSM_OP_CONV || (op.flags & (CSM_CONV_FLAG_STEM | CSM_CONV_FLAG_WINOGRAD | CSM_CONV_FLAG_WINOGRAD4))) continue;          // stems and Winograd layers have one dedicated kernel
+        if (op.kind != CSM_OP_CONV || (op.flags & (CSM_CONV_FLAG_STEM | CSM_CONV_FLAG_WINOGRAD | CSM_CONV_FLAG_WINOGRAD4 | CSM_CONV_FLAG_GROUPED))) continue;          // stems, Winograd and vector-pipe grouped layers have one dedicated kernel
         const int npad = (op.cout_g + 31) / 32 * 32;
         static const int cand_all[] = {CFG_64x64, CFG_128x32, CFG_64x16, CFG_D64x64, CFG_D128x64, CFG_D64x128, CFG_D128x128,
                                        CFG_D128x128_8w, CFG_D256x128_8w, CFG_D128x32, CFG_NARROW, CFG_D96x128, CFG_D160x128,

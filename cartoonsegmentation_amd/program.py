@@ -80,6 +80,31 @@ KSPLIT_BELOW = int(os.environ.get('CSM_KSPLIT_BELOW', '512'))
 KSPLIT_TARGET = int(os.environ.get('CSM_KSPLIT_TARGET', '768'))
 
 
+# Narrow grouped 3x3 convolutions (ResNeXt conv2: 8 / 16 / 32 channels per group): csrc/grouped.hip runs them on the vector pipe with the
+# DIRECT chain (same bits as the block-diagonal matrix-pipe form above) from its own weight image.  Speed only; CSM_GROUPED_VALU=0 keeps
+# the super-group form, CSM_GROUPED_VALU_MAX_CG bounds the channels per group that take it.
+GROUPED_VALU = os.environ.get('CSM_GROUPED_VALU', '1') != '0'
+GROUPED_VALU_MAX_CG = int(os.environ.get('CSM_GROUPED_VALU_MAX_CG', '32'))
+CONV_FLAG_GROUPED = 16
+_CHAIN8 = (0, 4, 1, 5, 2, 6, 3, 7)
+
+
+def grouped_valu_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ld=None):
+    c = groups * cin_g
+    return (GROUPED_VALU and groups > 1 and kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and cout == c
+            and cin_g in (8, 16, 32) and cin_g <= GROUPED_VALU_MAX_CG and c % 32 == 0 and (ld is None or ld % 4 == 0))
+
+
+def pack_grouped_weights(w, groups):
+    """w [cout, cin_g, 3, 3] with cout_g == cin_g in {8, 16, 32} -> the image of include/csm355.h "CSM_CONV_FLAG_GROUPED":
+    [group][octet][tap][kb][h][chain position i][t] = w[group cin_g + 8 octet + 4 h + t][8 kb + 4 (i & 1) + (i >> 1)][ky][kx]"""
+    cout, cg, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cout == groups * cg and cg % 8 == 0
+    og = kb = cg // 8
+    wg = w.reshape(groups, og, 2, 4, kb, 8, 9)[:, :, :, :, :, _CHAIN8, :]          # [g][octet][h][t][kb][i][tap]
+    return np.ascontiguousarray(wg.transpose(0, 1, 6, 4, 2, 5, 3)).reshape(-1)      # [g][octet][tap][kb][h][i][t]
+
+
 def pack_stem_weights(w):
     """stem convs (cin padded to 4, groups 1): K is packed as (tap, channel) -- 8 taps x 4 channels per 32-wide chunk instead of
     one chunk per tap with 4 of 32 channels used.  w [cout, 4, kh, kw] -> packed [chunk][npad][32]; within each 8-block the positions
@@ -305,8 +330,11 @@ class Program:
         stem = groups == 1 and cin_g == 4 and cout > 4        # k_conv_stem: (tap, channel)-packed K, csm_op.flags bit 1
         wino4 = self.winograd and self.winograd4 and wino4_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c)
         wino = wino4 or (self.winograd and wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c))
+        gvalu = self.grouped_valu and grouped_valu_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ld=x.buf.c)
         if stem:
             packed, sg, cin_sg, cout_sg = pack_stem_weights(w), 1, 4, cout
+        elif gvalu:
+            packed, sg, cin_sg, cout_sg = pack_grouped_weights(w, groups), groups, cin_g, cout // groups
         elif wino4:
             packed, sg, cin_sg, cout_sg = pack_wino4_weights(w), 1, cin_g, cout
         elif wino:
@@ -333,11 +361,12 @@ class Program:
         return self._emit(OP_CONV, x, res, out, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, groups=sg, cin_g=cin_sg,
                           cout_g=cout_sg, act=ACT[act], res_mode=res_mode if res is not None else 0, w_off=w_h, b_off=b_h,
                           aux_off=a_h, ksplit=ksplit, scratch=-1 if scr is None else scr.id, scratch_view=scr,
-                          flags=CONV_FLAG_STEM if stem else (CONV_FLAG_WINOGRAD4 if wino4 else (CONV_FLAG_WINOGRAD if wino else 0)),
+                          flags=CONV_FLAG_STEM if stem else (CONV_FLAG_GROUPED if gvalu else CONV_FLAG_WINOGRAD4 if wino4 else (CONV_FLAG_WINOGRAD if wino else 0)),
                           nat=dict(groups=groups, cin_g=cin_g, cout_g=cout // groups, w_off=w_n, b_off=b_n, aux_off=a_n))
 
     split_k = True
     winograd = WINO_ENABLE          # (class default; a test may lower one program with / without it)
+    grouped_valu = GROUPED_VALU     # narrow grouped 3x3 layers on the vector pipe (csrc/grouped.hip; same bits as the super-group form)
     winograd4 = WINO4_ENABLE        # F(4x4) for the Winograd layers of at least WINO4_MIN_PIXELS pixels (else F(2x2))
 
     def choose_ksplit(self, M, N, T, groups):

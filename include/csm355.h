@@ -267,6 +267,12 @@ typedef struct csm_tensor_desc {
 #define CSM_CONV_FLAG_STEM 2
 #define CSM_CONV_FLAG_WINOGRAD 4
 #define CSM_CONV_FLAG_WINOGRAD4 8
+/* Narrow grouped 3x3 convolutions on the vector pipe (csm_op.flags & CSM_CONV_FLAG_GROUPED; csrc/grouped.hip::k_conv_grouped): the DIRECT
+ * arithmetic above, unchanged (same fmaf chain, same bits as the block-diagonal matrix-pipe form) -- the flag only says which weight image
+ * the op carries.  3x3, stride 1, dilation 1, pad 1, cin_g == cout_g in {8, 16, 32}, channels % 32 == 0, ksplit 1; groups / cin_g /
+ * cout_g are the REAL groups (not super-groups).  Packed device weights, one 32-float half unit per (tap, 8-channel block kb, half h):
+ *   [group][octet][tap = 3 ky + kx][kb][h][chain position i][t] = w[group cin_g + 8 octet + 4 h + t][8 kb + 4 (i & 1) + (i >> 1)][ky][kx] */
+#define CSM_CONV_FLAG_GROUPED 16
 
 typedef struct csm_op {
     int32_t kind;
@@ -283,7 +289,9 @@ typedef struct csm_op {
                                 U = G g G^T packed for k_conv_wino; part of the NUMERICAL contract (set by the lowering from the layer's
                                 per-sample shape, never by the tuner) -- see "Winograd contract" below.
                                 CONV bit 3 (CSM_CONV_FLAG_WINOGRAD4): the same layer class in the F(4x4, 3x3) arithmetic (weights = its own
-                                36-frequency panels packed for k_conv_wino4); bits 2 and 3 are exclusive */
+                                36-frequency panels packed for k_conv_wino4); bits 2 and 3 are exclusive.
+                                CONV bit 4 (CSM_CONV_FLAG_GROUPED): narrow groups on the vector pipe -- direct arithmetic, its own
+                                weight image, REAL groups in groups / cin_g / cout_g (see above) */
     int32_t ksplit;          /* CONV: K is cut into `ksplit` runs of (32-channel block, tap) chunks (block-major), run s = chunks
                                 [s*T/ksplit, (s+1)*T/ksplit); each run is its own fmaf chain (run 0 starts at the bias,
                                 the others at 0) and the runs are added in order ((p0+p1)+p2)...  1 = single chain */
