@@ -657,7 +657,7 @@ class FrameWorkload(Workload):
         ach_nat = tot_fl / (tot_ms * 1e-3) / 1e12
         tot_fl /= self.frames_per_step
         tot_ex /= self.frames_per_step
-        return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_wino4+k_conv_wino8+k_conv_mfma (fp32 implicit GEMM / Winograd F(4x4,3x3) and F(2x2,3x3), all conv launches of one step = %d frames)" % self.frames_per_step,
+        return {"bound": "mfma", "kernel": "k_conv_dma+k_conv_wino4+k_conv_wino8+k_conv_mfma+k_conv_grouped (fp32 implicit GEMM / Winograd F(4x4,3x3) and F(2x2,3x3) / vector-pipe narrow groups, all conv launches of one step = %d frames)" % self.frames_per_step,
                 "vendor_fp32_gemm_context": self._vendor_gemm_context() if self.frames_per_step == 8 else None,
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                 "flops_basis": "executed MFMA FLOPs (Winograd layers: F(4x4) 36 products per 4x4 output tile and channel pair, F(2x2) 16 per 2x2)",

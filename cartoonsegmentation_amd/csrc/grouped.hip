@@ -30,6 +30,8 @@ typedef float f32x2g __attribute__((ext_vector_type(2)));
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 typedef float f32x16g __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) f32x4g *lds_f4g;
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4g *lds_u4g;
 
 // 16 wave-uniform floats -> SGPRs (asynchronous: the consumer waits on lgkmcnt)
 __device__ __forceinline__ f32x16g sload16(const float *p) {
@@ -38,9 +40,9 @@ __device__ __forceinline__ f32x16g sload16(const float *p) {
     return v;
 }
 
-__device__ __forceinline__ f32x4g lds_read4_async(unsigned byte_addr) {
+template <int OFF> __device__ __forceinline__ f32x4g lds_read4_async(unsigned byte_addr) {
     f32x4g v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
     return v;
 }
 
@@ -58,7 +60,7 @@ constexpr size_t grouped_lds_bytes(int px) { return (size_t)kGrpPH * (8 * px + 2
 
 template <int CG, int PX>
 __global__ __launch_bounds__(256, 3) void k_conv_grouped(ConvArgs a, int tx_n, int ty_n, int nslab) {
-    constexpr int KB = CG / 8, OG = CG / 8, TW = 8 * PX, PW = TW + 2, PH = kGrpPH, NSLOT = PH * PW * 8, NF = (NSLOT + 255) / 256;
+    constexpr int KB = CG / 8, OG = CG / 8, TW = 8 * PX, PW = TW + 2, PH = kGrpPH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane >> 3, q = lane & 7;
@@ -67,19 +69,30 @@ __global__ __launch_bounds__(256, 3) void k_conv_grouped(ConvArgs a, int tx_n, i
     const int tx = tile % tx_n, t2 = tile / tx_n, ty = t2 % ty_n, n = t2 / ty_n;
     const int H = a.in.h, W = a.in.w;
     const int y0 = ty * kGrpRows - 1, x0 = tx * TW - 1;                     // patch origin in the image
-    {   // ---- the slab's input patch -> LDS
-        f32x4g v[NF];
-        const float *src = a.in.p + (int64_t)n * H * W * a.in.ld + slab * 32;
+    {   // ---- the slab's input patch -> LDS.  A wave-level load covers 8 consecutive pixels of ONE patch row x the 8 slots of their
+        // 128-byte lines: the row and the run of eight are wave-uniform (scalar arithmetic), a lane adds its pixel and slot once.  Pixels
+        // outside the image read as zeros through the buffer range check (offset 2^31).  KR runs per row, units dealt round-robin to the waves.
+        constexpr int KR = (PW + 7) / 8, NU = PH * KR, UPW = (NU + 3) / 4;
+        const int ldi = a.in.ld;
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in.p) + (int64_t)n * H * W * ldi + slab * 32, 0,
+                                                                              (int)(((int64_t)H * W - 1) * ldi + 32) * 4, 0x00020000);
+        const int pl = lane >> 3, cq = lane & 7;
+        const unsigned lane_off = (unsigned)(pl * ldi + 4 * cq) * 4u;          // byte offset of (pixel pl of a run, slot cq)
+        u32x4g v[UPW];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int e = tid + 256 * i, px = e >> 3, cq = e & 7, row = px / PW, col = px - row * PW, iy = y0 + row, ix = x0 + col;
-            v[i] = f32x4g{0.0f, 0.0f, 0.0f, 0.0f};
-            if (e < NSLOT && iy >= 0 && iy < H && ix >= 0 && ix < W) v[i] = *reinterpret_cast<const f32x4g *>(src + ((int64_t)iy * W + ix) * a.in.ld + 4 * cq);
+        for (int t = 0; t < UPW; ++t) {
+            const int id = wave + 4 * t, row = id / KR, k = id - row * KR;   // (wave-uniform)
+            const int iy = y0 + row, ix = x0 + 8 * k + pl, col = 8 * k + pl;
+            const bool rowok = id < NU && iy >= 0 && iy < H;
+            const bool ok = rowok && ix >= 0 && ix < W && col < PW;
+            const int soff = rowok ? ((iy * W + x0 + 8 * k) * ldi) * 4 : 0;    // (scalar; may be negative at the left edge: the lanes that use it are inside)
+            v[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? (int)lane_off + soff : (int)0x80000000u, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int e = tid + 256 * i, px = e >> 3, cq = e & 7, row = px / PW, col = px - row * PW;
-            if (e < NSLOT) *(lds_f4g)(size_t)(lds0 + (unsigned)(px * 8 + (cq ^ ((col + row) & 7))) * 16u) = v[i];
+        for (int t = 0; t < UPW; ++t) {
+            const int id = wave + 4 * t, row = id / KR, k = id - row * KR, col = 8 * k + pl;
+            if (id < NU && col < PW)
+                *(lds_u4g)(size_t)(lds0 + (unsigned)((row * PW + col) * 8 + (cq ^ ((pl + row) & 7))) * 16u) = v[t];
         }
     }
     const int co0 = slab * 32 + wave * 8;                                    // this wave's eight output channels
@@ -108,11 +121,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_grouped(ConvArgs a, int tx_n, i
         const unsigned base = lds0 + (unsigned)(((r + ky) * PW + q + kx) * 8) * 16u;
         const unsigned sa = (unsigned)(gs * (CG / 4) + 2 * kb), sb = sa + 1u;
         const unsigned aa = base + ((sa ^ sw) << 4), ab = base + ((sb ^ sw) << 4);
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            da[j] = lds_read4_async(aa + (unsigned)j * 1024u);
-            db[j] = lds_read4_async(ab + (unsigned)j * 1024u);
-        }
+        [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
+            ((da[J] = lds_read4_async<J * 1024>(aa), db[J] = lds_read4_async<J * 1024>(ab)), ...);
+        }(std::make_integer_sequence<int, PX>{});
     };
     auto half_unit = [&](int h, const f32x16g &w0, const f32x16g &w1, const f32x4g (&xa)[PX], const f32x4g (&xb)[PX]) __attribute__((always_inline)) {
 #pragma unroll

@@ -82,9 +82,11 @@ KSPLIT_TARGET = int(os.environ.get('CSM_KSPLIT_TARGET', '768'))
 
 # Narrow grouped 3x3 convolutions (ResNeXt conv2: 8 / 16 / 32 channels per group): csrc/grouped.hip runs them on the vector pipe with the
 # DIRECT chain (same bits as the block-diagonal matrix-pipe form above) from its own weight image.  Speed only; CSM_GROUPED_VALU=0 keeps
-# the super-group form, CSM_GROUPED_VALU_MAX_CG bounds the channels per group that take it.
+# the super-group form, CSM_GROUPED_VALU_MAX_CG bounds the channels per group that take it (default 16: at 32 channels per group the
+# vector kernel is 6 % ahead at batch 8 -- 81 against 87 us at 8 x 40^2 x 1024 -- and a third BEHIND on one sample, 29 against 21 us,
+# where a launch is 160 blocks of one wave per SIMD; profiles/r06_grouped_conv.txt).
 GROUPED_VALU = os.environ.get('CSM_GROUPED_VALU', '1') != '0'
-GROUPED_VALU_MAX_CG = int(os.environ.get('CSM_GROUPED_VALU_MAX_CG', '32'))
+GROUPED_VALU_MAX_CG = int(os.environ.get('CSM_GROUPED_VALU_MAX_CG', '16'))
 CONV_FLAG_GROUPED = 16
 _CHAIN8 = (0, 4, 1, 5, 2, 6, 3, 7)
 

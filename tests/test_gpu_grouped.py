@@ -14,8 +14,8 @@ from test_gpu_nets import rnd, run_both  # noqa: E402
 
 
 def _layer(valu, n, h, w, cg, groups, act, res_mode, sliced=False, tag=''):
-    old = Program.grouped_valu
-    Program.grouped_valu = valu
+    old = (Program.grouped_valu, P.GROUPED_VALU_MAX_CG)
+    Program.grouped_valu, P.GROUPED_VALU_MAX_CG = valu, 32          # (the default rule stops at 16 channels per group; the kernel covers 32)
     try:
         c = cg * groups
         p = Program("grouped")
@@ -41,7 +41,7 @@ def _layer(valu, n, h, w, cg, groups, act, res_mode, sliced=False, tag=''):
         y = p.conv(x, W, b, pad=1, groups=groups, act=act, slope=slope, res=res, res_mode=res_mode, out=out)
         p.to_nchw(y, y_ext)
     finally:
-        Program.grouped_valu = old
+        Program.grouped_valu, P.GROUPED_VALU_MAX_CG = old
     flagged = [o for o in p.ops if o['kind'] == 1 and o['flags'] & P.CONV_FLAG_GROUPED]
     assert len(flagged) == (1 if valu else 0)
     return p, ext_in, (n, c, h, w)

@@ -9,8 +9,8 @@ from cartoonsegmentation_amd.runtime import CompiledProgram
 
 
 def build(valu, n, h, w, cg, groups):
-    old = P.Program.grouped_valu
-    P.Program.grouped_valu = valu
+    old = (P.Program.grouped_valu, P.GROUPED_VALU_MAX_CG)
+    P.Program.grouped_valu, P.GROUPED_VALU_MAX_CG = valu, 32
     rng = np.random.default_rng(0)
     c = cg * groups
     p = P.Program('g')
@@ -20,7 +20,7 @@ def build(valu, n, h, w, cg, groups):
     b = (rng.standard_normal(c) * 0.1).astype(np.float32)
     y = p.conv(x, wt, b, pad=1, groups=groups, act='relu')
     p.to_nchw(y, y_ext)
-    P.Program.grouped_valu = old
+    P.Program.grouped_valu, P.GROUPED_VALU_MAX_CG = old
     return p
 
 
