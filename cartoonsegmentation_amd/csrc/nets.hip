@@ -1941,6 +1941,35 @@ __global__ __launch_bounds__(256) void k_bilinear(View in, View out, int align, 
     }
 }
 
+// The same resize with the output ROW as the block coordinate (grid = (runs of 256 (pixel, 4-channel) pairs, out.h, out.n)): the sample
+// and the row's source rows / weights are wave-uniform, the column index needs one magic-number division -- k_bilinear<4> spends most of
+// its instructions in three 64-bit divisions per output word (3.5 TB/s in + out on the 2x decoder upsamplings; this form: see
+// profiles/r06_elementwise.txt).  Same expressions per element, same bits.
+__global__ __launch_bounds__(256) void k_bilinear_rows(View in, View out, int align, float sh, float sw, int act, const float *__restrict__ slope,
+                                                       unsigned cv_mul, unsigned cv_shr) {
+    const int cv = out.c >> 2, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= out.w * cv) return;
+    const int oy = blockIdx.y, n = blockIdx.z;
+    const int ox = (int)fast_div((unsigned)j, cv_mul, cv_shr), c = (j - ox * cv) * 4;
+    int y0, y1, x0, x1; float hl0, hl1, wl0, wl1;
+    src_index(oy, in.h, out.h, sh, align != 0, y0, y1, hl0, hl1);
+    src_index(ox, in.w, out.w, sw, align != 0, x0, x1, wl0, wl1);
+    const float *P = in.p + (int64_t)n * in.h * in.w * in.ld + c;
+    const float *r0 = P + (int64_t)y0 * in.w * in.ld, *r1 = P + (int64_t)y1 * in.w * in.ld;
+    const float4 p00 = *reinterpret_cast<const float4 *>(r0 + x0 * in.ld), p01 = *reinterpret_cast<const float4 *>(r0 + x1 * in.ld);
+    const float4 p10 = *reinterpret_cast<const float4 *>(r1 + x0 * in.ld), p11 = *reinterpret_cast<const float4 *>(r1 + x1 * in.ld);
+    float4 r;
+    r.x = hl0 * (wl0 * p00.x + wl1 * p01.x) + hl1 * (wl0 * p10.x + wl1 * p11.x);
+    r.y = hl0 * (wl0 * p00.y + wl1 * p01.y) + hl1 * (wl0 * p10.y + wl1 * p11.y);
+    r.z = hl0 * (wl0 * p00.z + wl1 * p01.z) + hl1 * (wl0 * p10.z + wl1 * p11.z);
+    r.w = hl0 * (wl0 * p00.w + wl1 * p01.w) + hl1 * (wl0 * p10.w + wl1 * p11.w);
+    if (act) {
+        r.x = apply_act(r.x, act, slope ? slope[c] : 0.0f); r.y = apply_act(r.y, act, slope ? slope[c + 1] : 0.0f);
+        r.z = apply_act(r.z, act, slope ? slope[c + 2] : 0.0f); r.w = apply_act(r.w, act, slope ? slope[c + 3] : 0.0f);
+    }
+    *reinterpret_cast<float4 *>(out.p + (((int64_t)n * out.h + oy) * out.w + ox) * out.ld + c) = r;
+}
+
 __global__ __launch_bounds__(256) void k_nearest(View in, View out) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = (int64_t)out.n * out.h * out.w * (out.c >> 2);
@@ -2604,7 +2633,11 @@ static int run_ops(const csm_op *ops, int n_ops, const csm_tensor_desc *tensors,
                 else { sh = (float)in.h / (float)out.h; sw = (float)in.w / (float)out.w; }
                 bool vec = !(out.c & 3) && !(in.ld & 3) && !(out.ld & 3) && !(((uintptr_t)in.p | (uintptr_t)out.p) & 15);
                 const float *bsl = op.aux_off >= 0 ? weights + op.aux_off : nullptr;
-                if (vec) k_bilinear<4><<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw, op.act, bsl);
+                if (vec && out.h <= 65535 && out.n <= 65535 && (int64_t)out.w * (out.c >> 2) < (1ll << 30)) {
+                    unsigned mul, shr;
+                    set_fast_div((unsigned)(out.c >> 2), mul, shr);
+                    k_bilinear_rows<<<dim3(blocks_for((int64_t)out.w * (out.c >> 2)), (unsigned)out.h, (unsigned)out.n), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw, op.act, bsl, mul, shr);
+                } else if (vec) k_bilinear<4><<<blocks_for((int64_t)out.n * out.h * out.w * (out.c >> 2)), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw, op.act, bsl);
                 else k_bilinear<1><<<blocks_for((int64_t)out.n * out.h * out.w * out.c), 256, 0, st>>>(in, out, align ? 1 : 0, sh, sw, op.act, bsl);
                 break;
             }

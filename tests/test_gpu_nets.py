@@ -433,3 +433,28 @@ def test_zoe_tail_group_is_padded_to_the_resident_batch():
         assert torch.equal(got, ref)
     other = pipe._depth_est_zoe_batch([torch.from_numpy(synth.image_u8(128, 160, 9)).cuda()] * 2)     # another frame size: no padding
     assert len(other) == 2
+
+
+@pytest.mark.parametrize("n,h,w,c,act", [(1, 8, 16, 32, 'silu'), (2, 37, 45, 64, 'silu'), (1, 80, 80, 128, 'relu'), (3, 5, 3, 32, None), (1, 20, 20, 512, 'silu')])
+def test_dwconv5_bit_exact(n, h, w, c, act):
+    """RTMDet's 5 x 5 depthwise layers (k_dwconv_lds) at full / ragged tiles: bias, then taps in (ky, kx) order, bit-exact against the oracle"""
+    p = Program("dw5")
+    x_ext = p.ext_nchw(n, c, h, w)
+    y_ext = p.ext_nchw(n, c, h, w)
+    y = p.dwconv(p.to_nhwc(x_ext), rnd('dw5w%d' % c, (c, 1, 5, 5), 0.2), rnd('dw5b%d' % c, (c,), 0.1), pad=2, act=act)
+    p.to_nchw(y, y_ext)
+    (yo,), (yd,) = run_both(p, [rnd('dw5x%d%d%d' % (n, h, w), (n, c, h, w))], [(n, c, h, w)])
+    assert np.isfinite(yd).all() and np.array_equal(yo, yd)
+
+
+@pytest.mark.parametrize("n,h,w,c,ho,wo,align", [(2, 23, 23, 32, 45, 45, False), (1, 45, 45, 64, 90, 90, False), (2, 12, 12, 32, 23, 23, True),
+                                                  (1, 20, 20, 256, 80, 80, False), (1, 17, 31, 8, 40, 50, True), (3, 9, 9, 4, 9, 9, False)])
+def test_bilinear_row_kernel_bit_exact(n, h, w, c, ho, wo, align):
+    """k_bilinear_rows (output row = block coordinate, one magic-number division per word) against the oracle's resize"""
+    p = Program("bil")
+    x_ext = p.ext_nchw(n, c, h, w)
+    y_ext = p.ext_nchw(n, c, ho, wo)
+    y = p.bilinear(p.to_nhwc(x_ext), (ho, wo), align_corners=align)
+    p.to_nchw(y, y_ext)
+    (yo,), (yd,) = run_both(p, [rnd('bilx%d%d%d%d' % (n, h, w, c), (n, c, h, w))], [(n, c, ho, wo)])
+    assert np.isfinite(yd).all() and np.array_equal(yo, yd)

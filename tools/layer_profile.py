@@ -44,6 +44,17 @@ def prof(name, prog, ext, top=TOP):
         a = agg.setdefault((k, d), [0.0, 0, 0]); a[0] += t; a[1] += 1; a[2] += fl
     for (k, d), (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
         print("   %7.3f ms  x%-3d %-7s %-52s %6.1f TF/s" % (t, n, k, d, fl / t / 1e9 if t > 0 else 0))
+    if os.environ.get('LP_NONCONV'):            # the memory-bound ops: bytes moved (input view + output view) and TB/s
+        agg = {}
+        for t, o in zip(ms, prog.ops):
+            if o['kind'] == 1:
+                continue
+            vi, vo = prog.views[o['in0']], prog.views[o['out']]
+            by = 4.0 * (vi.n * vi.h * vi.w * vi.c + vo.n * vo.h * vo.w * vo.c) + (4.0 * vo.n * vo.h * vo.w * vo.c if o['kind'] == 6 else 0.0)
+            a = agg.setdefault((KIND[o['kind']], "%dx%dx%dx%d->%dx%dx%d k%d s%d" % (vi.n, vi.h, vi.w, vi.c, vo.h, vo.w, vo.c, o['kh'], o['stride'])), [0.0, 0, 0.0])
+            a[0] += t; a[1] += 1; a[2] += by
+        for (k, d), (t, n, by) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
+            print("   %7.3f ms  x%-3d %-8s %-44s %6.1f MB each  %5.2f TB/s" % (t, n, k, d, by / n / 1e6, by / t / 1e9))
 
 
 if __name__ == '__main__':
