@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_grouped(ConvArgs a, int tx_n, i
         constexpr int KR = (PW + 7) / 8, NU = PH * KR, UPW = (NU + 3) / 4;
         const int ldi = a.in.ld;
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in.p) + (int64_t)n * H * W * ldi + slab * 32, 0,
-                                                                              (int)(((int64_t)H * W - 1) * ldi + 32) * 4, 0x00020000);
+                                                                              (int)((((int64_t)H * W - 1) * ldi + 32) * 4), 0x00020000);
         const int pl = lane >> 3, cq = lane & 7;
         const unsigned lane_off = (unsigned)(pl * ldi + 4 * cq) * 4u;          // byte offset of (pixel pl of a run, slot cq)
         u32x4g v[UPW];
@@ -219,6 +219,7 @@ bool grouped_eligible(const ConvArgs &a) {
     return a.groups > 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil == 1 && a.pad == 1 && a.cin_g == a.cout_g &&
            (a.cin_g == 8 || a.cin_g == 16 || a.cin_g == 32) && C % 32 == 0 && a.ksplit == 1 && a.in.c == C && a.out.c == C &&
            a.out.h == a.in.h && a.out.w == a.in.w && !(a.in.ld & 3) && !(a.out.ld & 3) && !(((uintptr_t)a.in.p | (uintptr_t)a.out.p) & 15) &&
+           (int64_t)a.in.h * a.in.w * a.in.ld * 4 < (1ll << 31) &&          // one sample's input view is addressed with 32-bit byte offsets (buffer loads)
            (!a.res_mode || (!(a.res.ld & 3) && !(((uintptr_t)a.res.p) & 15)));
 }
 

@@ -91,10 +91,13 @@ CONV_FLAG_GROUPED = 16
 _CHAIN8 = (0, 4, 1, 5, 2, 6, 3, 7)
 
 
-def grouped_valu_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ld=None):
+def grouped_valu_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ld=None, h=0, w=0):
+    """(mirrors csrc/grouped.hip::grouped_eligible, including its 32-bit byte-offset bound on ONE sample's input view: the weights of a
+    flagged op exist in the vector kernel's image only, so a layer the kernel would refuse must not be flagged)"""
     c = groups * cin_g
     return (GROUPED_VALU and groups > 1 and kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and cout == c
-            and cin_g in (8, 16, 32) and cin_g <= GROUPED_VALU_MAX_CG and c % 32 == 0 and (ld is None or ld % 4 == 0))
+            and cin_g in (8, 16, 32) and cin_g <= GROUPED_VALU_MAX_CG and c % 32 == 0 and (ld is None or ld % 4 == 0)
+            and h * w * (ld or c) * 4 < 2 ** 31)
 
 
 def pack_grouped_weights(w, groups):
@@ -332,7 +335,7 @@ class Program:
         stem = groups == 1 and cin_g == 4 and cout > 4        # k_conv_stem: (tap, channel)-packed K, csm_op.flags bit 1
         wino4 = self.winograd and self.winograd4 and wino4_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c)
         wino = wino4 or (self.winograd and wino_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ho, wo, ld=x.buf.c))
-        gvalu = self.grouped_valu and grouped_valu_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ld=x.buf.c)
+        gvalu = self.grouped_valu and grouped_valu_eligible(kh, kw, stride, pad, dil, groups, cin_g, cout, ld=x.buf.c, h=x.h, w=x.w)
         if stem:
             packed, sg, cin_sg, cout_sg = pack_stem_weights(w), 1, 4, cout
         elif gvalu:

@@ -42,6 +42,8 @@ def test_grouped_rule_is_per_layer_shape_and_switchable():
     assert _flags(1, 80, 80, 8, 3)[0] == 0                             # 24 channels: not a multiple of the 32-channel slab
     assert _flags(1, 80, 80, 8, 4, cout=64)[0] == 0                    # cout_g != cin_g
     assert _flags(1, 80, 80, 8, 4) == (P.CONV_FLAG_GROUPED, 4, 8, 8)
+    assert _flags(1, 1500, 1500, 8, 32)[0] == 0                        # one sample's view >= 2 GiB: beyond the kernel's 32-bit byte offsets
+    assert _flags(4, 1400, 1400, 8, 32)[0] == P.CONV_FLAG_GROUPED      # (the bound is per sample, not per batch)
     old = P.Program.grouped_valu
     P.Program.grouped_valu = False
     try:
